@@ -1,0 +1,127 @@
+/* librtdiff — C ABI of the MI355X (gfx950) region-diffusion sampling engine.
+ *
+ * Drop-in boundary for the denoising hot path of songweige/rich-text-to-image.  The reference has no
+ * native code and no FFI: its "operator interface" for this path is the Python call surface cited
+ * beside each entry point below (file:line under /root/reference).  The Python facade in
+ * rich-text-to-image_amd/ binds these symbols with ctypes and mirrors the reference classes.
+ *
+ * Conventions
+ *   - every function returns int: 0 = ok, negative = RT_E_*; rt_last_error() gives the message
+ *   - all tensor pointers are DEVICE pointers unless the parameter is documented as host
+ *   - the caller owns every tensor it passes and keeps it alive until the stream is synchronised;
+ *     the engine owns its weight arena, K/V caches, workspace and sampler state
+ *   - one engine = one device = one HIP stream; calls on one engine are not re-entrant
+ *   - no allocation happens inside forward / step calls
+ */
+#ifndef RTDIFF_H
+#define RTDIFF_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_OK 0
+#define RT_E_INVALID (-1)
+#define RT_E_HIP (-2)
+#define RT_E_STATE (-3)
+#define RT_E_MISSING_WEIGHT (-4)
+#define RT_E_UNSUPPORTED (-5)
+
+#define RT_MAX_LEVELS 4
+#define RT_MAX_STREAMS 16
+
+enum { RT_DTYPE_F32 = 0, RT_DTYPE_F16 = 1, RT_DTYPE_BF16 = 2 };
+enum { RT_SCHED_EULER = 0, RT_SCHED_PNDM = 1 };
+
+/* Architecture of the UNet: the constructor arguments of UNet2DConditionModel that SD-v1.5 / SDXL use
+ * (models/unet_2d_condition.py:160-215). */
+typedef struct rt_config {
+    int n_levels;
+    int block_out_channels[RT_MAX_LEVELS];
+    int down_has_attn[RT_MAX_LEVELS];   /* CrossAttnDownBlock2D (1) vs DownBlock2D (0) */
+    int up_has_attn[RT_MAX_LEVELS];     /* CrossAttnUpBlock2D (1) vs UpBlock2D (0), in up_blocks order */
+    int layers_per_block[RT_MAX_LEVELS];
+    int transformer_layers[RT_MAX_LEVELS];
+    int heads[RT_MAX_LEVELS];           /* `attention_head_dim` of the config = number of heads */
+    int cross_attention_dim;
+    int norm_groups;
+    float norm_eps;
+    int use_linear_projection;
+    int addition_text_time;             /* addition_embed_type == "text_time" */
+    int addition_time_embed_dim;
+    int projection_class_embeddings_input_dim;
+    int in_channels, out_channels;      /* 4, 4 */
+    int latent_h, latent_w;             /* largest latent the workspace is sized for */
+    int max_streams;                    /* UNet forwards batched per launch (<= RT_MAX_STREAMS) */
+    int max_prompts;                    /* prompts resident in the cross-attention K/V cache */
+} rt_config;
+
+typedef struct rt_engine rt_engine;
+
+/* lifecycle -------------------------------------------------------------------------------------- */
+int rt_create(const rt_config* cfg, int device, rt_engine** out);   /* RegionDiffusion.__init__ rd.py:16-47, xl.py:56-134 */
+int rt_destroy(rt_engine* e);
+const char* rt_last_error(rt_engine* e);                             /* e may be NULL: last error of failed rt_create */
+int rt_set_stream(rt_engine* e, void* hip_stream);
+int rt_synchronize(rt_engine* e);
+
+/* weights: names are the reference UNet's state_dict keys (unet.load_state_dict, rd.py:32, xl.py:115) --- */
+int rt_weight_count(rt_engine* e);
+int rt_weight_info(rt_engine* e, int idx, char* name, int name_cap, int64_t* shape4, int* ndim);
+int rt_bind_weight(rt_engine* e, const char* name, const void* dev_ptr, int dtype, const int64_t* shape, int ndim);
+int rt_weights_missing(rt_engine* e, char* buf, int cap);            /* returns count; names ';'-joined into buf */
+int rt_arena_info(rt_engine* e, void** dev_ptr, uint64_t* bytes);    /* packed arena, for one RCCL broadcast */
+int rt_arena_mark_bound(rt_engine* e);                               /* after the arena was filled by a broadcast */
+
+/* per image -------------------------------------------------------------------------------------- */
+/* text conditioning: prompt_embeds [P,77,D] f32, pooled [P,Dp] f32 (SDXL) or NULL, time_ids[6] (host) or NULL.
+ * rd.py:49-84 / xl.py:256-442,741-762; index 0 = negative prompt, 1..P-2 = region prompts, P-1 = base prompt */
+int rt_set_prompts(rt_engine* e, const float* prompt_embeds, const float* pooled, const float* time_ids_host,
+                   int n_prompts, int pooled_dim);
+/* region masks (model.masks, rd.py:97,119-128 / xl.py:775,810-821): [R,4,h,w] f32 */
+int rt_set_masks(rt_engine* e, const float* masks, int n_regions, int h, int w);
+/* font-size control (text_format_dict['word_pos'|'font_size'], richtext_utils.py:188-209): HOST arrays; n = 0 disables */
+int rt_set_fontsize(rt_engine* e, const int64_t* word_pos_host, const float* font_size_host, int n);
+/* scheduler tables (HOST arrays): Euler: sigmas[n+1], timesteps[n]; PNDM: alphas_cumprod[1000], timesteps[n_iter] */
+int rt_set_schedule(rt_engine* e, int kind, const float* timesteps_host, int n_timesteps, const float* table_host,
+                    int n_table, int num_inference_steps);
+/* sampler state: latents [1,4,h,w] f32 (copied in); the reference stream starts as a clone (rd.py:93, xl.py:774) */
+int rt_set_latents(rt_engine* e, const float* latents, int h, int w);
+int rt_get_latents(rt_engine* e, float* latents_out, float* latents_ref_out /* may be NULL */);
+
+/* hot path ---------------------------------------------------------------------------------------- */
+/* one iteration of the rich-text loop (rd.py:99-173 / xl.py:779-872 without colour guidance):
+ * all R+1 / R+3 UNet forwards batched, mask combine, CFG, scheduler step, background blend */
+int rt_region_step(rt_engine* e, int step_index, float guidance_scale, float inject_selfattn, float inject_background,
+                   int xl_semantics, int elide_dead_forwards);
+/* one iteration of the plain-text loop (rd.py:200-214 / xl.py:880-905): batch-2 forward, CFG, step */
+int rt_plain_step(rt_engine* e, int step_index, float guidance_scale);
+
+/* operator level (parity tests, AttnProcessor / unet(...) seams; unet_2d_condition.py:703-717) ------------ */
+/* x [B,4,h,w] f32 NCHW; per-stream: input scale, prompt index, font-size flag, self-attention Q/K source
+ * stream (== own index for normal attention), resnet-feature source stream or -1; out [B,4,h,w] f32 NCHW */
+int rt_unet_forward(rt_engine* e, const float* x, int B, int h, int w, float timestep, const float* in_scale_host,
+                    const int* prompt_idx_host, const int* fontsize_host, const int* qk_src_host,
+                    const int* res_src_host, float* out);
+
+int rt_op_gemm(const void* A, const void* W, const float* bias, void* out, const float* res, const float* temb,
+               int mode, int epi, int M, int N, int K, int lda, int ldw, int ldo, int ldres, int temb_ld,
+               int rows_per_batch, int Hin, int Win, int Cin, int Hout, int Wout, void* stream);
+int rt_op_attention(const void* Q, int ldq, const void* K, int ldk, const void* VT, int ldvt, void* O, int ldo,
+                    const int* q_src_host, const int* k_src_host, const int* v_src_host, const int* wset_host,
+                    const float* wabs, const float* wsgn, int B, int H, int N, int NK, int nk_valid, int DP, int cross,
+                    void* stream);
+int rt_op_groupnorm(const void* x1, const void* x2, int in_bf16, int C1, int C2, int G, int B, int HW,
+                    const float* gamma, const float* beta, float eps, int silu, void* out_bf16, void* raw_out_bf16,
+                    void* stream);
+int rt_op_layernorm(const float* x, const float* gamma, const float* beta, void* out_bf16, int rows, int C, float eps,
+                    void* stream);
+int rt_op_small_linear(const float* a, int lda, const void* W_bf16, int ldw, const float* bias, float* out, int ldo,
+                       int B, int N, int K, int silu_in, int accumulate, void* stream);
+int rt_op_timestep_embed(const float* t, int n, int dim, float* out, int ldo, void* stream);
+const char* rt_op_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

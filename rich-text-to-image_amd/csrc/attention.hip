@@ -1,0 +1,226 @@
+// Fused attention (QK^T -> softmax -> PV) for gfx950, bf16 MFMA 32x32x16, fp32 softmax/accumulate.
+//
+// Replaces Attention.get_attention_scores + bmm(P, V) of the reference
+// (models/attention_processor.py:359-407 and :476-545) for
+//   * self-attention (attn1), incl. the rich-text *injection* mode: the reference stores the full
+//     per-head probability tensor of the `text_ref` forward (region_diffusion_sdxl.py:1064-1106) and
+//     feeds it to the region forwards (:1018-1062, attention_processor.py:522-524).  softmax(QK^T) only
+//     depends on Q,K, so injecting P_ref is identical to attending with (Q_ref, K_ref, V_region): the
+//     kernel takes Q/K rows from batch entry q_src[b]/k_src[b] and V^T columns from v_src[b] and never
+//     materialises P.
+//   * cross-attention (attn2) with the font-size re-weighted softmax (attention_processor.py:386-401):
+//       e_k = exp(s_k - max) * |fs_k| ;  p_k = sign(fs_k) * e_k / sum_k e_k
+//     expressed as two per-key multiplier vectors (wabs, wsgn); padded keys have wabs = 0.
+//
+// Layout: "swapped" products so that softmax statistics are lane-local:
+//   S^T[key, query] = K * Q^T   (A = K tile from LDS, B = Q fragments held in registers)
+//   O^T[d,   query] = V^T * P^T (A = V^T tile from LDS, B = P^T straight from the S^T accumulators:
+//                                the MFMA k-slot (lane>>5, j) is bound to the same key on both operands,
+//                                so no cross-lane shuffle of P is needed)
+// One workgroup = 4 waves x 32 queries; K and V^T tiles are staged with global_load_lds into a double
+// buffer of 64-byte-row sub-tiles, XOR-swizzled on 16-B slots via the source address.
+#include "common.h"
+#include <math.h>
+
+template <int DP, int KT, bool CROSS>
+__global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TILE = KT * DP * 2;          // bytes of one K (or V^T) tile
+    constexpr int STAGE = 2 * TILE;
+    constexpr int NCH = KT * DP / 8;           // 16-B chunks per tile
+    constexpr int NJ = KT / 32;                // key sub-tiles
+    constexpr int ND = DP / 32;                // d sub-tiles
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
+    const int qb = p.q_src[b], kb = p.k_src[b], vb = p.v_src[b];
+
+    float* wl = (float*)(smem + 2 * STAGE);    // cross: [2][KT] multipliers
+    if (CROSS) {
+        const int ws = p.wset[b];
+        for (int i = tid; i < KT; i += 256) {
+            wl[i] = p.wabs[ws * p.NK + i];
+            wl[KT + i] = p.wsgn[ws * p.NK + i];
+        }
+    }
+
+    // Q fragments (B operand of S^T): query = lane&31, d = 16*ks + 8*hi + [0,8)
+    const int q = q0 + wave * 32 + l31;
+    const int qc = q < p.N ? q : p.N - 1;
+    const bf16_t* qptr = p.Q + ((size_t)qb * p.N + qc) * p.ldq + h * DP + hi * 8;
+    bf16x8 qf[DP / 16];
+#pragma unroll
+    for (int ks = 0; ks < DP / 16; ++ks) qf[ks] = *(const bf16x8*)(qptr + ks * 16);
+
+    const bf16_t* kbase = p.K + (size_t)kb * p.NK * p.ldk + h * DP;
+    const bf16_t* vbase = p.VT + (size_t)h * DP * p.ldvt + (size_t)vb * p.NK;
+
+    auto stage = [&](int s, int key0) {
+        char* ks_ = smem + s * STAGE;
+        char* vs_ = ks_ + TILE;
+#pragma unroll
+        for (int c0 = 0; c0 < NCH; c0 += 256) {
+            const int idx = c0 + tid;
+            if (idx < NCH) {   // wave-uniform: NCH % 64 == 0
+                const int rl = idx >> 2, ps = idx & 3;
+                {
+                    const int sub = rl / KT, row = rl - sub * KT;
+                    const int ls = ps ^ ((row >> 2) & 3);
+                    glds16(kbase + (size_t)(key0 + row) * p.ldk + sub * 32 + ls * 8, ks_ + (c0 + wave * 64) * 16);
+                }
+                {
+                    const int sub = rl / DP, row = rl - sub * DP;
+                    const int ls = ps ^ ((row >> 2) & 3);
+                    glds16(vbase + (size_t)row * p.ldvt + key0 + sub * 32 + ls * 8, vs_ + (c0 + wave * 64) * 16);
+                }
+            }
+        }
+    };
+
+    f32x16 o[ND];
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m = -1e30f, l = 0.f;
+
+    const int ntile = p.NK / KT;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < ntile; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < ntile) stage(cur ^ 1, (kt + 1) * KT);
+        const char* ks_ = smem + cur * STAGE;
+        const char* vs_ = ks_ + TILE;
+
+        // ---- S^T = K Q^T
+        f32x16 s[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[j][r] = 0.f;
+            const int row = j * 32 + l31;
+            const int key = (row >> 2) & 3;
+#pragma unroll
+            for (int ks = 0; ks < DP / 16; ++ks) {
+                const int ls = ((ks & 1) * 2 + hi) ^ key;
+                const bf16x8 kf = *(const bf16x8*)(ks_ + ((ks >> 1) * KT + row) * 64 + ls * 16);
+                s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[j], 0, 0, 0);
+            }
+        }
+        // ---- online softmax (lane holds 16 of the 32 keys of each sub-tile for its query; partner = lane^32)
+        float mx = m;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (CROSS) {
+                    const int key = kt * KT + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (key >= p.nk_valid) s[j][r] = -INFINITY;
+                }
+                mx = fmaxf(mx, s[j][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float alpha = exp2f(m - mx);
+        m = mx;
+        float rs = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float pv = exp2f(s[j][r] - mx);
+                if (CROSS) {
+                    const int kl = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    pv *= wl[kl];
+                    rs += pv;
+                    pv *= wl[KT + kl];
+                } else {
+                    rs += pv;
+                }
+                s[j][r] = pv;
+            }
+        l = l * alpha + rs;
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+
+        // ---- O^T += V^T P^T
+#pragma unroll
+        for (int kk = 0; kk < KT / 16; ++kk) {
+            const int j = kk >> 1, hh = kk & 1;
+            bf16x8 pf;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pf[e] = (__bf16)s[j][8 * hh + e];
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt) {
+                const int row = dt * 32 + l31;
+                const int key = (row >> 2) & 3;
+                const char* rp = vs_ + (j * DP + row) * 64 + hi * 8;
+                const bf16x4 lo = *(const bf16x4*)(rp + (((2 * hh) ^ key) << 4));
+                const bf16x4 hi4 = *(const bf16x4*)(rp + (((2 * hh + 1) ^ key) << 4));
+                const bf16x8 vf = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    l += __shfl_xor(l, 32);
+    const float inv = 1.f / l;
+    if (q < p.N) {
+        bf16_t* optr = p.O + ((size_t)b * p.N + q) * p.ldo + h * DP + 4 * hi;
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 v;
+                v.x = pack_bf16x2(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv);
+                v.y = pack_bf16x2(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+                *(uint2*)(optr + dt * 32 + 8 * g) = v;
+            }
+    }
+}
+
+template <int DP, int KT, bool CROSS>
+static void launch_t(const AttnArgs& a, hipStream_t st) {
+    const size_t lds = 4 * (size_t)KT * DP * 2 + (CROSS ? 2 * KT * sizeof(float) : 0);
+    static bool attr = false;
+    if (!attr) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)attn_kernel<DP, KT, CROSS>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    dim3 grid(cdiv(a.N, 128), a.H, a.B), block(256);
+    hipLaunchKernelGGL((attn_kernel<DP, KT, CROSS>), grid, block, lds, st, a);
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_attention(const AttnArgs& a, hipStream_t st) {
+    RT_REQUIRE(a.B >= 1 && a.B <= RT_MAXB, "attention: batch must be in [1,16]");
+    RT_REQUIRE(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldvt % 8 == 0 && a.ldo % 4 == 0, "attention: leading dims");
+    RT_REQUIRE(((uintptr_t)a.Q & 15) == 0 && ((uintptr_t)a.K & 15) == 0 && ((uintptr_t)a.VT & 15) == 0 &&
+               ((uintptr_t)a.O & 7) == 0, "attention: alignment");
+    if (a.cross) {
+        RT_REQUIRE(a.NK == 96 && a.nk_valid <= 96 && a.wabs && a.wsgn, "cross-attention expects 77 keys padded to 96");
+        switch (a.DP) {
+            case 32: launch_t<32, 96, true>(a, st); break;
+            case 64: launch_t<64, 96, true>(a, st); break;
+            case 96: launch_t<96, 96, true>(a, st); break;
+            case 160: launch_t<160, 96, true>(a, st); break;
+            default: throw rt_error(RT_E_UNSUPPORTED, "attention: unsupported padded head dim");
+        }
+    } else {
+        RT_REQUIRE(a.NK % 64 == 0, "self-attention: key count must be a multiple of 64");
+        switch (a.DP) {
+            case 32: launch_t<32, 64, false>(a, st); break;
+            case 64: launch_t<64, 64, false>(a, st); break;
+            case 96: launch_t<96, 64, false>(a, st); break;
+            case 160: launch_t<160, 64, false>(a, st); break;
+            default: throw rt_error(RT_E_UNSUPPORTED, "attention: unsupported padded head dim");
+        }
+    }
+}

@@ -1,0 +1,145 @@
+// Shared device/host helpers for the region-diffusion engine (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <stdexcept>
+
+typedef uint16_t bf16_t;   // raw bf16 bits in memory
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define RT_OK 0
+#define RT_E_INVALID (-1)
+#define RT_E_HIP (-2)
+#define RT_E_STATE (-3)
+#define RT_E_MISSING_WEIGHT (-4)
+#define RT_E_UNSUPPORTED (-5)
+
+struct rt_error : std::runtime_error {
+    int code;
+    rt_error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define HIP_CHECK(expr)                                                                        \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            throw rt_error(RT_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));       \
+    } while (0)
+
+#define RT_REQUIRE(cond, msg)                                                                  \
+    do {                                                                                       \
+        if (!(cond)) throw rt_error(RT_E_INVALID, std::string(msg) + " [" #cond "]");          \
+    } while (0)
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// round-to-nearest-even, NaN preserved
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// async global -> LDS copy of 16 B per lane (LDS destination = wave-uniform base + lane*16)
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// ---------------------------------------------------------------- GEMM / implicit-GEMM conv
+enum { A_DENSE = 0, A_CONV3 = 1, A_CONV3_S2 = 2, A_CONV3_UP2 = 3 };
+enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_BF16_TEMB = 2, EPI_GEGLU = 3 };
+
+struct GemmArgs {
+    const bf16_t* A;   // dense: [M, lda]; conv: NHWC input [B, Hin, Win, Cin]
+    const bf16_t* W;   // [N, ldw] (K contiguous)
+    const float* bias; // [N] or null
+    void* out;         // bf16 or f32, [M, ldo]
+    const float* res;  // EPI_F32: optional residual [M, ldres]
+    const float* temb; // EPI_BF16_TEMB: [B, temb_ld]
+    const bf16_t* zero; // >= 16 B of zeros
+    int mode, epi;
+    int M, N, K;
+    int lda, ldw, ldo, ldres, temb_ld;
+    int rows_per_batch;              // Hout*Wout (conv and temb)
+    int Hin, Win, Cin, Hout, Wout;   // conv geometry (Cin padded to a multiple of 8; K = 9*Cin)
+};
+void launch_gemm(const GemmArgs& a, hipStream_t st);
+
+// ---------------------------------------------------------------- attention
+#define RT_MAXB 16
+struct AttnArgs {
+    const bf16_t* Q;  int ldq;   // [*, ldq]  row (q_src[b]*N + n), head h at column h*DP; pre-scaled by d^-1/2 * log2(e)
+    const bf16_t* K;  int ldk;   // [*, ldk]  row (k_src[b]*NK + key), head h at column h*DP
+    const bf16_t* VT; int ldvt;  // [H*DP, ldvt] row (h*DP + d), column (v_src[b]*NK + key)
+    bf16_t* O;        int ldo;   // [B*N, ldo] row (b*N + n), head h at column h*DP
+    int q_src[RT_MAXB], k_src[RT_MAXB], v_src[RT_MAXB], wset[RT_MAXB];
+    const float* wabs;           // cross: [nsets, NK] |font size| multiplier per key; null => plain softmax
+    const float* wsgn;           // cross: [nsets, NK] sign multiplier per key
+    int B, H, N;                 // queries per batch entry
+    int NK;                      // keys per batch entry in K / V^T (multiple of the key tile)
+    int nk_valid;                // cross: keys >= nk_valid are masked out
+    int DP;                      // padded head dim (multiple of 32)
+    int cross;
+};
+void launch_attention(const AttnArgs& a, hipStream_t st);
+
+// ---------------------------------------------------------------- norms / elementwise
+struct GroupNormArgs {
+    const void* x1; const void* x2;   // x2 may be null; virtual concat along channels [C1 | C2]
+    int in_bf16;                       // 0: fp32 inputs, 1: bf16 input (x2 must be null)
+    int C1, C2, G, B, HW;
+    const float* gamma; const float* beta; float eps;
+    int silu;
+    bf16_t* out;                       // [B, HW, C1+C2] normalised (+SiLU)
+    bf16_t* raw_out;                   // optional: un-normalised bf16 copy of the (concatenated) input
+    float* partial;                    // workspace [B, nchunk, G, 2]
+    int nchunk, rows_per_chunk;        // from groupnorm_nchunk / groupnorm_rows_per_chunk
+};
+int groupnorm_rows_per_chunk(int HW);
+void launch_groupnorm(const GroupNormArgs& a, hipStream_t st);
+int groupnorm_nchunk(int HW);
+
+void launch_layernorm(const float* x, const float* gamma, const float* beta, bf16_t* out, int rows, int C,
+                      float eps, hipStream_t st);
+void launch_cast_f32_bf16(const float* x, bf16_t* out, size_t n, hipStream_t st);
+// out[b][n] (+)= sum_k act(a[b][k]) * W[n][k] + bias[n];  B <= 8
+void launch_small_linear(const float* a, int lda, const bf16_t* W, int ldw, const float* bias, float* out, int ldo,
+                         int B, int N, int K, int silu_in, int accumulate, hipStream_t st);
+void launch_timestep_embed(const float* t, int n, int dim, float* out, int ldo, hipStream_t st);
+
+// weight packing (device side): strided gather fp32/fp16/bf16 -> bf16 (or f32) with scale.
+//   dst (r, c) <- scale * src[ srow(r)*s_r + (c / c_inner)*s_co + (c % c_inner)*s_ci ]   (0 where invalid)
+//   row_map 0: srow = r
+//           1: GEGLU interleave: per 64-row block [32 value rows | 32 gate rows]; gate rows start at rows/2
+//           2: head padding: srow = (r / rm_a) * rm_b + r % rm_a, valid iff r % rm_a < rm_b   (rm_a = DP, rm_b = d)
+//   column validity: (c % c_inner) < ci_valid
+enum { PACK_ROWS_ID = 0, PACK_ROWS_GEGLU = 1, PACK_ROWS_HEADPAD = 2 };
+struct PackArgs {
+    const void* src; int src_dtype;   // 0 f32, 1 f16, 2 bf16
+    void* dst; int dst_f32;
+    int rows, cols, ld_dst;
+    int row_map, rm_a, rm_b;
+    int c_inner, ci_valid;
+    long s_r, s_co, s_ci;
+    float scale;
+};
+void launch_pack(const PackArgs& a, hipStream_t st);
+
+// NCHW fp32 latents -> NHWC bf16 [B, HW, 8] (channels 4..7 zero), scaled per batch entry
+struct PrepArgs {
+    const float* src[RT_MAXB];   // each [4, HW]
+    float scale[RT_MAXB];
+    bf16_t* dst; int B, HW;
+};
+void launch_prep_latents(const PrepArgs& a, hipStream_t st);

@@ -1,0 +1,145 @@
+// Small HBM-/latency-bound kernels: dtype casts, weight packing, timestep embeddings, skinny linears.
+#include "common.h"
+#include <hip/hip_fp16.h>
+
+__global__ void cast_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, size_t n4) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = ((const float4*)x)[i];
+        uint2 o; o.x = pack_bf16x2(v.x, v.y); o.y = pack_bf16x2(v.z, v.w);
+        ((uint2*)out)[i] = o;
+    }
+}
+void launch_cast_f32_bf16(const float* x, bf16_t* out, size_t n, hipStream_t st) {
+    RT_REQUIRE(n % 4 == 0, "cast: n must be a multiple of 4");
+    const size_t n4 = n / 4;
+    int grid = (int)((n4 + 255) / 256); if (grid > 2048) grid = 2048; if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(cast_kernel, dim3(grid), dim3(256), 0, st, x, out, n4);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------- weight packing
+__global__ void pack_kernel(PackArgs p) {
+    const size_t total = (size_t)p.rows * p.cols;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / p.cols), c = (int)(i % p.cols);
+        long srow = r; bool ok = true;
+        if (p.row_map == PACK_ROWS_GEGLU) {
+            const int blk = r >> 6, w = r & 63;
+            srow = (w < 32) ? (long)blk * 32 + w : (long)(p.rows >> 1) + blk * 32 + (w - 32);
+        } else if (p.row_map == PACK_ROWS_HEADPAD) {
+            const int hh = r / p.rm_a, dd = r % p.rm_a;
+            ok = dd < p.rm_b; srow = (long)hh * p.rm_b + dd;
+        }
+        const int co = c / p.c_inner, ci = c % p.c_inner;
+        ok = ok && ci < p.ci_valid;
+        float v = 0.f;
+        if (ok) {
+            const long off = srow * p.s_r + co * p.s_co + ci * p.s_ci;
+            if (p.src_dtype == 0) v = ((const float*)p.src)[off];
+            else if (p.src_dtype == 1) v = __half2float(((const __half*)p.src)[off]);
+            else v = bf16_to_f32(((const bf16_t*)p.src)[off]);
+            v *= p.scale;
+        }
+        if (p.dst_f32) ((float*)p.dst)[(size_t)r * p.ld_dst + c] = v;
+        else ((bf16_t*)p.dst)[(size_t)r * p.ld_dst + c] = f32_to_bf16(v);
+    }
+}
+void launch_pack(const PackArgs& a, hipStream_t st) {
+    const size_t total = (size_t)a.rows * a.cols;
+    if (total == 0) return;
+    int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(256), 0, st, a);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------- sinusoidal embedding
+// diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): [cos(t f_j) | sin(t f_j)]
+// (reference call sites: models/unet_2d_condition.py:784,849)
+__global__ void timestep_embed_kernel(const float* __restrict__ t, int n, int dim, float* __restrict__ out, int ldo) {
+    const int half = dim >> 1;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n * dim; i += gridDim.x * blockDim.x) {
+        const int r = i / dim, j = i % dim;
+        const int jj = j < half ? j : j - half;
+        const float f = expf(-9.210340371976184f * (float)jj / (float)half);
+        const float a = t[r] * f;
+        out[(size_t)r * ldo + j] = j < half ? cosf(a) : sinf(a);
+    }
+}
+void launch_timestep_embed(const float* t, int n, int dim, float* out, int ldo, hipStream_t st) {
+    hipLaunchKernelGGL(timestep_embed_kernel, dim3(cdiv(n * dim, 256)), dim3(256), 0, st, t, n, dim, out, ldo);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------- skinny linear (M <= 16 rows): weight-streaming, HBM-bound
+// one wave per output feature; bf16 weights, fp32 activations and accumulation.
+__global__ __launch_bounds__(256) void small_linear_kernel(const float* __restrict__ a, int lda, const bf16_t* __restrict__ W,
+                                                           int ldw, const float* __restrict__ bias, float* __restrict__ out,
+                                                           int ldo, int B, int N, int K, int silu_in, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float acc[RT_MAXB];
+#pragma unroll
+    for (int b = 0; b < RT_MAXB; ++b) acc[b] = 0.f;
+    for (int k = lane * 8; k < K; k += 512) {
+        const uint4 wv = *(const uint4*)(W + (size_t)n * ldw + k);
+        float w[8];
+        w[0] = __uint_as_float(wv.x << 16); w[1] = __uint_as_float(wv.x & 0xffff0000u);
+        w[2] = __uint_as_float(wv.y << 16); w[3] = __uint_as_float(wv.y & 0xffff0000u);
+        w[4] = __uint_as_float(wv.z << 16); w[5] = __uint_as_float(wv.z & 0xffff0000u);
+        w[6] = __uint_as_float(wv.w << 16); w[7] = __uint_as_float(wv.w & 0xffff0000u);
+#pragma unroll
+        for (int b = 0; b < RT_MAXB; ++b) {
+            if (b < B) {
+                const float4 x0 = *(const float4*)(a + (size_t)b * lda + k);
+                const float4 x1 = *(const float4*)(a + (size_t)b * lda + k + 4);
+                float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float xv = x[e];
+                    if (silu_in) xv = xv / (1.f + __expf(-xv));
+                    acc[b] += xv * w[e];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < RT_MAXB; ++b) {
+        if (b < B) {
+            float s = acc[b];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if (lane == 0) {
+                s += bias ? bias[n] : 0.f;
+                float* dst = out + (size_t)b * ldo + n;
+                *dst = accumulate ? *dst + s : s;
+            }
+        }
+    }
+}
+void launch_small_linear(const float* a, int lda, const bf16_t* W, int ldw, const float* bias, float* out, int ldo,
+                         int B, int N, int K, int silu_in, int accumulate, hipStream_t st) {
+    RT_REQUIRE(B >= 1 && B <= RT_MAXB, "small_linear: B must be in [1,16]");
+    RT_REQUIRE(K % 8 == 0 && lda % 4 == 0 && ldw % 8 == 0, "small_linear: K multiple of 8");
+    hipLaunchKernelGGL(small_linear_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, a, lda, W, ldw, bias, out, ldo, B, N, K,
+                       silu_in, accumulate);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------- latents NCHW f32 -> NHWC bf16 (8 channels)
+__global__ void prep_latents_kernel(PrepArgs p) {
+    const int b = blockIdx.y;
+    const float* src = p.src[b];
+    const float sc = p.scale[b];
+    for (int pix = blockIdx.x * blockDim.x + threadIdx.x; pix < p.HW; pix += gridDim.x * blockDim.x) {
+        uint4 o;
+        o.x = pack_bf16x2(src[pix] * sc, src[p.HW + pix] * sc);
+        o.y = pack_bf16x2(src[2 * p.HW + pix] * sc, src[3 * p.HW + pix] * sc);
+        o.z = 0; o.w = 0;
+        *(uint4*)(p.dst + ((size_t)b * p.HW + pix) * 8) = o;
+    }
+}
+void launch_prep_latents(const PrepArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(prep_latents_kernel, dim3(cdiv(a.HW, 256), a.B), dim3(256), 0, st, a);
+    HIP_CHECK(hipGetLastError());
+}

@@ -1,0 +1,881 @@
+// Host-side engine: weight arena, execution plan, batched UNet forward and the rich-text step driver.
+//
+// One engine = one GPU = one HIP stream.  The reference (pure Python, one process, batch 1) runs the
+// R+1 / R+3 UNet forwards of a rich-text step sequentially and rewires nn.Module hooks between them
+// (models/region_diffusion.py:99-173, models/region_diffusion_sdxl.py:779-872).  Here all forwards of
+// a step are ONE batched forward ("streams"); the hook families become per-stream mode words:
+//   font-size hooks (rd.py:465-494)        -> fontsize[b]  : multiplier set used by cross-attention
+//   selfattn capture + replacement hooks   -> qk_src[b]    : stream whose Q,K drive self-attention
+//   resnet feature capture/injection       -> res_src[b]   : stream whose up_blocks.1.resnets.1 residual
+//                                                            branch replaces this stream's (resnet.py:639-643)
+// The text_ref stream is in the same batch, so its Q/K and resnet feature are available to the region
+// streams at every layer without storing 5.9 GB of probabilities per step.
+#include "common.h"
+#include "../../include/rtdiff.h"
+#include <map>
+#include <vector>
+#include <string>
+#include <cmath>
+#include <cstring>
+#include <functional>
+
+static thread_local std::string g_create_error;
+static thread_local std::string g_op_error;
+
+// ------------------------------------------------------------------------------------------------
+// memory helpers
+struct Arena {           // bump allocator over one device allocation; base == nullptr => measuring pass
+    char* base = nullptr;
+    size_t off = 0, cap = 0;
+    void* alloc(size_t bytes) {
+        off = (off + 255) & ~(size_t)255;
+        void* p = base ? base + off : (void*)(uintptr_t)(off + 256);   // fake non-null pointer when measuring
+        off += bytes;
+        if (base && off > cap) throw rt_error(RT_E_STATE, "arena overflow");
+        return p;
+    }
+};
+
+struct Workspace {       // stack allocator with mark/release; dry == true measures the peak only
+    char* base = nullptr;
+    size_t off = 0, cap = 0, peak = 0;
+    bool dry = false;
+    void* alloc(size_t bytes) {
+        off = (off + 255) & ~(size_t)255;
+        void* p = base ? base + off : (void*)(uintptr_t)(off + 256);
+        off += bytes;
+        if (off > peak) peak = off;
+        if (!dry && off > cap) throw rt_error(RT_E_STATE, "workspace overflow");
+        return p;
+    }
+    float* f32(size_t n) { return (float*)alloc(n * 4); }
+    bf16_t* b16(size_t n) { return (bf16_t*)alloc(n * 2); }
+    size_t mark() const { return off; }
+    void release(size_t m) { off = m; }
+};
+struct Scope {
+    Workspace& w; size_t m;
+    explicit Scope(Workspace& ws) : w(ws), m(ws.mark()) {}
+    ~Scope() { w.release(m); }
+};
+
+// ------------------------------------------------------------------------------------------------
+// plan
+struct NormW { float* g = nullptr; float* b = nullptr; int C = 0; };
+struct MatW { bf16_t* w = nullptr; float* b = nullptr; int N = 0, K = 0; };   // packed [N, K] bf16 (+ f32 bias)
+
+struct ResnetP {
+    std::string name;
+    int cin = 0, cout = 0;
+    NormW n1, n2;
+    MatW c1, c2, temb, sc;
+    bool has_sc = false;
+};
+struct TBlockP {
+    NormW ln1, ln2, ln3;
+    MatW qk1, v1, out1, q2, k2, v2, out2, ff1, ff2;
+    bf16_t* kcache = nullptr;    // [maxP*96, H*DP]
+    bf16_t* vtcache = nullptr;   // [H*DP, maxP*96]
+};
+struct TransformerP {
+    std::string name;
+    int C = 0, heads = 0, d = 0, DP = 0;
+    NormW gn;
+    MatW pin, pout;
+    std::vector<TBlockP> blocks;
+};
+struct DownP { std::vector<ResnetP> res; std::vector<TransformerP> attn; bool has_attn = false, has_down = false; MatW down; int C = 0; };
+struct UpP { std::vector<ResnetP> res; std::vector<TransformerP> attn; bool has_attn = false, has_up = false; MatW up; int C = 0; };
+
+struct WeightSlot {
+    std::string name;
+    std::vector<int64_t> shape;
+    PackArgs pack;     // everything except src/src_dtype
+    bool bound = false;
+};
+
+static int pad_head_dim(int d) {
+    if (d <= 32) return 32;
+    if (d <= 64) return 64;
+    if (d <= 96) return 96;
+    if (d <= 160) return 160;
+    throw rt_error(RT_E_UNSUPPORTED, "head dim > 160 not supported");
+}
+
+struct Tensor { float* p; int C; };   // fp32 trunk tensor [B, HW, C]
+
+struct FwdIn {
+    int B = 0, h = 0, w = 0;
+    const float* x[RT_MAXB];
+    float scale[RT_MAXB];
+    float t = 0;
+    int prompt[RT_MAXB], fontsize[RT_MAXB], qk_src[RT_MAXB], res_src[RT_MAXB];
+    float* eps_out = nullptr;    // [B, HW, 4] fp32
+};
+
+// step epilogue kernels (defined in step.hip)
+struct StepArgs;
+void launch_step_epilogue(const StepArgs& a, hipStream_t st);
+void launch_gather_add_rows(const float* base, const float* table, const int* /*host*/ idx, float* out, int B, int C, hipStream_t st);
+void launch_inject_add(float* out, const float* sc, const float* hres, const int* /*host*/ src, int B, size_t per_batch, hipStream_t st);
+void launch_nhwc4_to_nchw(const float* in, float* out, int B, int HW, hipStream_t st);
+void launch_pad_ctx(const float* ctx, bf16_t* out, int P, int D, hipStream_t st);
+
+#include "step.h"
+
+struct rt_engine {
+    rt_config cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    Arena arena;                 // packed weights only (this is what a multi-GPU launch broadcasts)
+    Arena sarena;                // K/V caches + per-image sampler state
+    char* arena_base = nullptr;
+    char* sarena_base = nullptr;
+    size_t arena_bytes = 0, sarena_bytes = 0;
+    Workspace ws;
+    bf16_t* zero = nullptr;
+
+    std::vector<WeightSlot> slots;
+    std::map<std::string, int> slot_index;
+
+    // plan
+    MatW conv_in, conv_out, t1, t2, a1, a2;
+    NormW norm_out;
+    std::vector<DownP> down;
+    std::vector<UpP> up;
+    ResnetP mid_r0, mid_r1;
+    TransformerP mid_t;
+    int temb_dim = 0;
+
+    // per-image state
+    int n_prompts = 0;
+    float* aug_emb = nullptr;        // [maxP, temb_dim] (zeros when no addition embedding)
+    float* wabs = nullptr;           // [2, 96]
+    float* wsgn = nullptr;
+    float* masks = nullptr;          // [R, 4, HW]
+    int n_regions = 0, mask_hw = 0;
+    float* lat = nullptr;            // [4, HW]
+    float* lat_ref = nullptr;
+    float* eps = nullptr;            // [maxB, HW, 4]
+    float* ets = nullptr;            // PNDM history [4][2][4*HW]
+    float* cur_sample = nullptr;     // PNDM [2][4*HW]
+    int lat_h = 0, lat_w = 0;
+    // schedule (host)
+    int sched_kind = 0, num_inference_steps = 0;
+    std::vector<float> timesteps, table;
+    int pndm_counter = 0, pndm_nets = 0, pndm_head = 0;
+    int steps_done = 0;
+
+    // ---------------------------------------------------------------------------- plan building
+    void add_slot(const std::string& name, std::vector<int64_t> shape, const PackArgs& pk) {
+        WeightSlot s; s.name = name; s.shape = std::move(shape); s.pack = pk;
+        slot_index[name] = (int)slots.size();
+        slots.push_back(s);
+    }
+    static PackArgs pk_matrix(void* dst, int rows, int cols, int ld, long s_r) {
+        PackArgs p{}; p.dst = dst; p.dst_f32 = 0; p.rows = rows; p.cols = cols; p.ld_dst = ld;
+        p.row_map = PACK_ROWS_ID; p.c_inner = cols; p.ci_valid = cols; p.s_r = s_r; p.s_co = 0; p.s_ci = 1; p.scale = 1.f;
+        return p;
+    }
+    static PackArgs pk_vec(void* dst, int n) {
+        PackArgs p{}; p.dst = dst; p.dst_f32 = 1; p.rows = n; p.cols = 1; p.ld_dst = 1;
+        p.row_map = PACK_ROWS_ID; p.c_inner = 1; p.ci_valid = 1; p.s_r = 1; p.s_co = 0; p.s_ci = 0; p.scale = 1.f;
+        return p;
+    }
+    NormW mk_norm(const std::string& name, int C) {
+        NormW n; n.C = C;
+        n.g = (float*)arena.alloc((size_t)C * 4); n.b = (float*)arena.alloc((size_t)C * 4);
+        add_slot(name + ".weight", {C}, pk_vec(n.g, C));
+        add_slot(name + ".bias", {C}, pk_vec(n.b, C));
+        return n;
+    }
+    // nn.Linear [N, K] (optionally a 1x1 conv [N, K, 1, 1])
+    MatW mk_linear(const std::string& name, int K, int N, bool bias, bool as_conv1x1 = false) {
+        MatW m; m.N = N; m.K = K;
+        m.w = (bf16_t*)arena.alloc((size_t)N * K * 2);
+        std::vector<int64_t> shp = as_conv1x1 ? std::vector<int64_t>{N, K, 1, 1} : std::vector<int64_t>{N, K};
+        add_slot(name + ".weight", shp, pk_matrix(m.w, N, K, K, K));
+        if (bias) { m.b = (float*)arena.alloc((size_t)N * 4); add_slot(name + ".bias", {N}, pk_vec(m.b, N)); }
+        return m;
+    }
+    // nn.Conv2d 3x3 [Cout, Cin, 3, 3] -> [Cout, 9*CinP], K index = tap*CinP + c
+    MatW mk_conv3(const std::string& name, int Cin, int Cout) {
+        const int CinP = (Cin + 7) & ~7;
+        MatW m; m.N = Cout; m.K = 9 * CinP;
+        m.w = (bf16_t*)arena.alloc((size_t)Cout * m.K * 2);
+        PackArgs p{}; p.dst = m.w; p.rows = Cout; p.cols = m.K; p.ld_dst = m.K; p.row_map = PACK_ROWS_ID;
+        p.c_inner = CinP; p.ci_valid = Cin; p.s_r = (long)Cin * 9; p.s_co = 1; p.s_ci = 9; p.scale = 1.f;
+        add_slot(name + ".weight", {Cout, Cin, 3, 3}, p);
+        m.b = (float*)arena.alloc((size_t)Cout * 4);
+        add_slot(name + ".bias", {Cout}, pk_vec(m.b, Cout));
+        return m;
+    }
+    ResnetP mk_resnet(const std::string& name, int cin, int cout) {
+        RT_REQUIRE(cin % 8 == 0 && cout % 8 == 0, "resnet: channel counts must be multiples of 8");
+        ResnetP r; r.name = name; r.cin = cin; r.cout = cout;
+        r.n1 = mk_norm(name + ".norm1", cin);
+        r.c1 = mk_conv3(name + ".conv1", cin, cout);
+        r.temb = mk_linear(name + ".time_emb_proj", temb_dim, cout, true);
+        r.n2 = mk_norm(name + ".norm2", cout);
+        r.c2 = mk_conv3(name + ".conv2", cout, cout);
+        r.has_sc = cin != cout;
+        if (r.has_sc) r.sc = mk_linear(name + ".conv_shortcut", cin, cout, true, true);
+        return r;
+    }
+    // q/k/v projection with head padding d -> DP on the output rows
+    MatW mk_headproj(const std::string& wname, int K, int H, int d, int DP, float scale, bf16_t* dst_rows, int ld) {
+        MatW m; m.N = H * DP; m.K = K; m.w = dst_rows;
+        PackArgs p = pk_matrix(dst_rows, H * DP, K, ld, K);
+        p.row_map = PACK_ROWS_HEADPAD; p.rm_a = DP; p.rm_b = d; p.scale = scale;
+        add_slot(wname + ".weight", {H * d, K}, p);
+        return m;
+    }
+    MatW mk_outproj(const std::string& name, int C, int H, int d, int DP) {
+        MatW m; m.N = C; m.K = H * DP;
+        m.w = (bf16_t*)arena.alloc((size_t)C * m.K * 2);
+        PackArgs p{}; p.dst = m.w; p.rows = C; p.cols = m.K; p.ld_dst = m.K; p.row_map = PACK_ROWS_ID;
+        p.c_inner = DP; p.ci_valid = d; p.s_r = (long)H * d; p.s_co = d; p.s_ci = 1; p.scale = 1.f;
+        add_slot(name + ".weight", {C, H * d}, p);
+        m.b = (float*)arena.alloc((size_t)C * 4);
+        add_slot(name + ".bias", {C}, pk_vec(m.b, C));
+        return m;
+    }
+    TransformerP mk_transformer(const std::string& name, int C, int heads, int nlayers) {
+        TransformerP t; t.name = name; t.C = C; t.heads = heads; t.d = C / heads; t.DP = pad_head_dim(t.d);
+        RT_REQUIRE(C % heads == 0, "channels not divisible by heads");
+        const int HD = heads * t.DP, D = cfg.cross_attention_dim;
+        const float qscale = (float)(std::pow((double)t.d, -0.5) * 1.4426950408889634);   // d^-1/2 * log2(e)
+        t.gn = mk_norm(name + ".norm", C);
+        t.pin = mk_linear(name + ".proj_in", C, C, true, !cfg.use_linear_projection);
+        for (int li = 0; li < nlayers; ++li) {
+            const std::string b = name + ".transformer_blocks." + std::to_string(li);
+            TBlockP k;
+            k.ln1 = mk_norm(b + ".norm1", C);
+            bf16_t* qk = (bf16_t*)arena.alloc((size_t)2 * HD * C * 2);
+            k.qk1 = mk_headproj(b + ".attn1.to_q", C, heads, t.d, t.DP, qscale, qk, C);
+            mk_headproj(b + ".attn1.to_k", C, heads, t.d, t.DP, 1.f, qk + (size_t)HD * C, C);
+            k.qk1.N = 2 * HD;
+            bf16_t* v = (bf16_t*)arena.alloc((size_t)HD * C * 2);
+            k.v1 = mk_headproj(b + ".attn1.to_v", C, heads, t.d, t.DP, 1.f, v, C);
+            k.out1 = mk_outproj(b + ".attn1.to_out.0", C, heads, t.d, t.DP);
+            k.ln2 = mk_norm(b + ".norm2", C);
+            bf16_t* q2 = (bf16_t*)arena.alloc((size_t)HD * C * 2);
+            k.q2 = mk_headproj(b + ".attn2.to_q", C, heads, t.d, t.DP, qscale, q2, C);
+            bf16_t* k2 = (bf16_t*)arena.alloc((size_t)HD * D * 2);
+            k.k2 = mk_headproj(b + ".attn2.to_k", D, heads, t.d, t.DP, 1.f, k2, D);
+            bf16_t* v2 = (bf16_t*)arena.alloc((size_t)HD * D * 2);
+            k.v2 = mk_headproj(b + ".attn2.to_v", D, heads, t.d, t.DP, 1.f, v2, D);
+            k.out2 = mk_outproj(b + ".attn2.to_out.0", C, heads, t.d, t.DP);
+            k.ln3 = mk_norm(b + ".norm3", C);
+            // GEGLU: nn.Linear(C, 8C); rows interleaved per 64-block [32 value | 32 gate]
+            k.ff1.N = 8 * C; k.ff1.K = C;
+            k.ff1.w = (bf16_t*)arena.alloc((size_t)8 * C * C * 2);
+            k.ff1.b = (float*)arena.alloc((size_t)8 * C * 4);
+            RT_REQUIRE((4 * C) % 32 == 0, "GEGLU width must be a multiple of 32");
+            { PackArgs p = pk_matrix(k.ff1.w, 8 * C, C, C, C); p.row_map = PACK_ROWS_GEGLU; add_slot(b + ".ff.net.0.proj.weight", {8 * C, C}, p); }
+            { PackArgs p = pk_vec(k.ff1.b, 8 * C); p.row_map = PACK_ROWS_GEGLU; add_slot(b + ".ff.net.0.proj.bias", {8 * C}, p); }
+            k.ff2 = mk_linear(b + ".ff.net.2", 4 * C, C, true);
+            k.kcache = (bf16_t*)sarena.alloc((size_t)cfg.max_prompts * 96 * HD * 2);
+            k.vtcache = (bf16_t*)sarena.alloc((size_t)cfg.max_prompts * 96 * HD * 2);
+            t.blocks.push_back(k);
+        }
+        t.pout = mk_linear(name + ".proj_out", C, C, true, !cfg.use_linear_projection);
+        return t;
+    }
+
+    void build_plan() {
+        slots.clear(); slot_index.clear(); down.clear(); up.clear();
+        const int L = cfg.n_levels;
+        const int* boc = cfg.block_out_channels;
+        temb_dim = boc[0] * 4;
+        zero = (bf16_t*)sarena.alloc(256);
+        conv_in = mk_conv3("conv_in", cfg.in_channels, boc[0]);
+        t1 = mk_linear("time_embedding.linear_1", boc[0], temb_dim, true);
+        t2 = mk_linear("time_embedding.linear_2", temb_dim, temb_dim, true);
+        if (cfg.addition_text_time) {
+            a1 = mk_linear("add_embedding.linear_1", cfg.projection_class_embeddings_input_dim, temb_dim, true);
+            a2 = mk_linear("add_embedding.linear_2", temb_dim, temb_dim, true);
+        }
+        int out_c = boc[0];
+        for (int i = 0; i < L; ++i) {
+            DownP d; const int in_c = out_c; out_c = boc[i]; d.C = out_c;
+            d.has_attn = cfg.down_has_attn[i]; d.has_down = i != L - 1;
+            const std::string pre = "down_blocks." + std::to_string(i);
+            for (int j = 0; j < cfg.layers_per_block[i]; ++j) {
+                d.res.push_back(mk_resnet(pre + ".resnets." + std::to_string(j), j == 0 ? in_c : out_c, out_c));
+                if (d.has_attn) d.attn.push_back(mk_transformer(pre + ".attentions." + std::to_string(j), out_c, cfg.heads[i], cfg.transformer_layers[i]));
+            }
+            if (d.has_down) d.down = mk_conv3(pre + ".downsamplers.0.conv", out_c, out_c);
+            down.push_back(d);
+        }
+        mid_r0 = mk_resnet("mid_block.resnets.0", boc[L - 1], boc[L - 1]);
+        mid_t = mk_transformer("mid_block.attentions.0", boc[L - 1], cfg.heads[L - 1], cfg.transformer_layers[L - 1]);
+        mid_r1 = mk_resnet("mid_block.resnets.1", boc[L - 1], boc[L - 1]);
+        out_c = boc[L - 1];
+        for (int i = 0; i < L; ++i) {
+            UpP u; const int prev = out_c; out_c = boc[L - 1 - i];
+            const int in_c = boc[L - 1 - std::min(i + 1, L - 1)];
+            u.C = out_c; u.has_attn = cfg.up_has_attn[i]; u.has_up = i != L - 1;
+            const int nl = cfg.layers_per_block[L - 1 - i] + 1;
+            const std::string pre = "up_blocks." + std::to_string(i);
+            for (int j = 0; j < nl; ++j) {
+                const int skip_c = j == nl - 1 ? in_c : out_c;
+                const int res_in = j == 0 ? prev : out_c;
+                u.res.push_back(mk_resnet(pre + ".resnets." + std::to_string(j), res_in + skip_c, out_c));
+                if (u.has_attn) u.attn.push_back(mk_transformer(pre + ".attentions." + std::to_string(j), out_c, cfg.heads[L - 1 - i], cfg.transformer_layers[L - 1 - i]));
+            }
+            if (u.has_up) u.up = mk_conv3(pre + ".upsamplers.0.conv", out_c, out_c);
+            up.push_back(u);
+        }
+        norm_out = mk_norm("conv_norm_out", boc[0]);
+        conv_out = mk_conv3("conv_out", boc[0], cfg.out_channels);
+        // per-image sampler state
+        const size_t HW = (size_t)cfg.latent_h * cfg.latent_w;
+        aug_emb = (float*)sarena.alloc((size_t)cfg.max_prompts * temb_dim * 4);
+        wabs = (float*)sarena.alloc(2 * 96 * 4); wsgn = (float*)sarena.alloc(2 * 96 * 4);
+        masks = (float*)sarena.alloc((size_t)RT_MAXB * 4 * HW * 4);
+        lat = (float*)sarena.alloc(4 * HW * 4); lat_ref = (float*)sarena.alloc(4 * HW * 4);
+        eps = (float*)sarena.alloc((size_t)cfg.max_streams * HW * 4 * 4);
+        ets = (float*)sarena.alloc((size_t)4 * 2 * 4 * HW * 4);
+        cur_sample = (float*)sarena.alloc((size_t)2 * 4 * HW * 4);
+    }
+
+    // ---------------------------------------------------------------------------- launch helpers
+    bool dry() const { return ws.dry; }
+    void gemm(const bf16_t* A, int lda, const MatW& W, int M, void* out, int ldo, int epi, const float* res = nullptr,
+              int ldres = 0, const float* temb = nullptr, int rows_per_batch = 0) {
+        if (dry()) return;
+        GemmArgs g{}; g.A = A; g.W = W.w; g.bias = W.b; g.out = out; g.res = res; g.temb = temb; g.zero = zero;
+        g.mode = A_DENSE; g.epi = epi; g.M = M; g.N = W.N; g.K = W.K; g.lda = lda; g.ldw = W.K; g.ldo = ldo;
+        g.ldres = ldres; g.temb_ld = W.N; g.rows_per_batch = rows_per_batch;
+        launch_gemm(g, stream);
+    }
+    // V^T = Wv [HD, K] x X[M, K]^T -> [HD, M]
+    void gemm_vt(const MatW& Wv, const bf16_t* X, int ldx, int M, bf16_t* out, int ldo) {
+        if (dry()) return;
+        GemmArgs g{}; g.A = Wv.w; g.W = X; g.bias = nullptr; g.out = out; g.zero = zero;
+        g.mode = A_DENSE; g.epi = EPI_BF16; g.M = Wv.N; g.N = M; g.K = Wv.K; g.lda = Wv.K; g.ldw = ldx; g.ldo = ldo;
+        launch_gemm(g, stream);
+    }
+    void conv3(const bf16_t* in, int mode, const MatW& W, int B, int Hin, int Win, int CinP, void* out, int epi,
+               const float* res = nullptr, const float* temb = nullptr) {
+        if (dry()) return;
+        int Hout = Hin, Wout = Win;
+        if (mode == A_CONV3_S2) { Hout = (Hin + 1) / 2; Wout = (Win + 1) / 2; }   // k3 s2 p1
+        if (mode == A_CONV3_UP2) { Hout = Hin * 2; Wout = Win * 2; }
+        GemmArgs g{}; g.A = in; g.W = W.w; g.bias = W.b; g.out = out; g.res = res; g.temb = temb; g.zero = zero;
+        g.mode = mode; g.epi = epi; g.M = B * Hout * Wout; g.N = W.N; g.K = W.K; g.lda = 0; g.ldw = W.K; g.ldo = W.N;
+        g.ldres = W.N; g.temb_ld = W.N; g.rows_per_batch = Hout * Wout;
+        g.Hin = Hin; g.Win = Win; g.Cin = CinP; g.Hout = Hout; g.Wout = Wout;
+        RT_REQUIRE(W.K == 9 * CinP, "conv: weight/input channel mismatch");
+        launch_gemm(g, stream);
+    }
+    void groupnorm(const void* x1, const void* x2, bool in_bf16, int C1, int C2, int B, int HW, const NormW& n, float eps_,
+                   bool silu, bf16_t* out, bf16_t* raw) {
+        Scope sc(ws);
+        const int nchunk = groupnorm_nchunk(HW);
+        float* partial = ws.f32((size_t)B * nchunk * cfg.norm_groups * 2);
+        if (dry()) return;
+        GroupNormArgs a{}; a.x1 = x1; a.x2 = x2; a.in_bf16 = in_bf16; a.C1 = C1; a.C2 = C2; a.G = cfg.norm_groups; a.B = B;
+        a.HW = HW; a.gamma = n.g; a.beta = n.b; a.eps = eps_; a.silu = silu; a.out = out; a.raw_out = raw;
+        a.partial = partial; a.nchunk = nchunk; a.rows_per_chunk = groupnorm_rows_per_chunk(HW);
+        launch_groupnorm(a, stream);
+    }
+    void layernorm(const float* x, const NormW& n, bf16_t* out, int rows) {
+        if (dry()) return;
+        launch_layernorm(x, n.g, n.b, out, rows, n.C, 1e-5f, stream);
+    }
+
+    // ---------------------------------------------------------------------------- blocks
+    // ResnetBlock2D.forward (models/resnet.py:591-645); x2 = skip tensor of the up path (virtual concat)
+    Tensor resnet(const ResnetP& r, const FwdIn& in, int HW, int Hh, int Ww, Tensor x1, const Tensor* x2, const float* emb,
+                  bool inject_here) {
+        const int B = in.B, M = B * HW;
+        const int c1 = x1.C, c2 = x2 ? x2->C : 0;
+        RT_REQUIRE(c1 + c2 == r.cin, "resnet: input channel mismatch");
+        float* out = ws.f32((size_t)M * r.cout);
+        {
+            Scope sc(ws);
+            bf16_t* h1 = ws.b16((size_t)M * r.cin);
+            bf16_t* raw = r.has_sc ? ws.b16((size_t)M * r.cin) : nullptr;
+            groupnorm(x1.p, x2 ? x2->p : nullptr, false, c1, c2, B, HW, r.n1, cfg.norm_eps, true, h1, raw);
+            float* tp = ws.f32((size_t)B * r.cout);
+            if (!dry()) launch_small_linear(emb, temb_dim, r.temb.w, r.temb.K, r.temb.b, tp, r.cout, B, r.cout, temb_dim, 1, 0, stream);
+            bf16_t* h2 = ws.b16((size_t)M * r.cout);
+            conv3(h1, A_CONV3, r.c1, B, Hh, Ww, r.cin, h2, EPI_BF16_TEMB, nullptr, tp);
+            bf16_t* h3 = ws.b16((size_t)M * r.cout);
+            groupnorm(h2, nullptr, true, r.cout, 0, B, HW, r.n2, cfg.norm_eps, true, h3, nullptr);
+            const float* resid = x1.p;
+            if (r.has_sc) { gemm(raw, r.cin, r.sc, M, out, r.cout, EPI_F32); resid = out; }
+            else RT_REQUIRE(!x2, "resnet without shortcut cannot take a concat input");
+            bool any_inject = false;
+            if (inject_here) for (int b = 0; b < B; ++b) any_inject |= in.res_src[b] >= 0;
+            if (!any_inject) {
+                conv3(h3, A_CONV3, r.c2, B, Hh, Ww, r.cout, out, EPI_F32, resid);
+            } else {
+                // rich-text feature injection (resnet.py:639-643): out[b] = shortcut(x[b]) + hidden[res_src[b]]
+                float* hres = ws.f32((size_t)M * r.cout);
+                conv3(h3, A_CONV3, r.c2, B, Hh, Ww, r.cout, hres, EPI_F32, nullptr);
+                int src[RT_MAXB];
+                for (int b = 0; b < B; ++b) src[b] = in.res_src[b] >= 0 ? in.res_src[b] : b;
+                if (!dry()) launch_inject_add(out, resid, hres, src, B, (size_t)HW * r.cout, stream);
+            }
+        }
+        return Tensor{out, r.cout};
+    }
+
+    // Transformer2DModel.forward (models/transformer_2d.py:270-310) + BasicTransformerBlock (attention.py:131-206)
+    Tensor transformer(const TransformerP& t, const FwdIn& in, int HW, Tensor x) {
+        const int B = in.B, M = B * HW, C = t.C, HD = t.heads * t.DP;
+        RT_REQUIRE(x.C == C, "transformer: channel mismatch");
+        RT_REQUIRE(HW % 64 == 0, "transformer: token count must be a multiple of 64");
+        float* out = ws.f32((size_t)M * C);
+        {
+            Scope sc(ws);
+            float* hcur = ws.f32((size_t)M * C);
+            {
+                Scope s2(ws);
+                bf16_t* g = ws.b16((size_t)M * C);
+                groupnorm(x.p, nullptr, false, C, 0, B, HW, t.gn, 1e-6f, false, g, nullptr);
+                gemm(g, C, t.pin, M, hcur, C, EPI_F32);
+            }
+            for (const TBlockP& k : t.blocks) {
+                Scope s2(ws);
+                bf16_t* n = ws.b16((size_t)M * C);
+                // --- attn1 (self; attention_processor.py:476-545)
+                layernorm(hcur, k.ln1, n, M);
+                bf16_t* qk = ws.b16((size_t)M * 2 * HD);
+                bf16_t* vt = ws.b16((size_t)HD * M);
+                bf16_t* o = ws.b16((size_t)M * HD);
+                gemm(n, C, k.qk1, M, qk, 2 * HD, EPI_BF16);
+                gemm_vt(k.v1, n, C, M, vt, M);
+                if (!dry()) {
+                    AttnArgs a{}; a.Q = qk; a.ldq = 2 * HD; a.K = qk + HD; a.ldk = 2 * HD; a.VT = vt; a.ldvt = M; a.O = o; a.ldo = HD;
+                    for (int b = 0; b < B; ++b) { a.q_src[b] = in.qk_src[b]; a.k_src[b] = in.qk_src[b]; a.v_src[b] = b; a.wset[b] = 0; }
+                    a.B = B; a.H = t.heads; a.N = HW; a.NK = HW; a.nk_valid = HW; a.DP = t.DP; a.cross = 0;
+                    launch_attention(a, stream);
+                }
+                gemm(o, HD, k.out1, M, hcur, C, EPI_F32, hcur, C);
+                // --- attn2 (cross, K/V from the per-prompt cache; font-size softmax on flagged streams)
+                layernorm(hcur, k.ln2, n, M);
+                gemm(n, C, k.q2, M, qk, HD, EPI_BF16);
+                if (!dry()) {
+                    AttnArgs a{}; a.Q = qk; a.ldq = HD; a.K = k.kcache; a.ldk = HD; a.VT = k.vtcache; a.ldvt = cfg.max_prompts * 96;
+                    a.O = o; a.ldo = HD;
+                    for (int b = 0; b < B; ++b) { a.q_src[b] = b; a.k_src[b] = in.prompt[b]; a.v_src[b] = in.prompt[b]; a.wset[b] = in.fontsize[b] ? 1 : 0; }
+                    a.wabs = wabs; a.wsgn = wsgn;
+                    a.B = B; a.H = t.heads; a.N = HW; a.NK = 96; a.nk_valid = 77; a.DP = t.DP; a.cross = 1;
+                    launch_attention(a, stream);
+                }
+                gemm(o, HD, k.out2, M, hcur, C, EPI_F32, hcur, C);
+                // --- GEGLU feed-forward (attention.py:209-304)
+                layernorm(hcur, k.ln3, n, M);
+                bf16_t* gg = ws.b16((size_t)M * 4 * C);
+                gemm(n, C, k.ff1, M, gg, 4 * C, EPI_GEGLU);
+                gemm(gg, 4 * C, k.ff2, M, hcur, C, EPI_F32, hcur, C);
+            }
+            bf16_t* hb = ws.b16((size_t)M * C);
+            if (!dry()) launch_cast_f32_bf16(hcur, hb, (size_t)M * C, stream);
+            gemm(hb, C, t.pout, M, out, C, EPI_F32, x.p, C);
+        }
+        return Tensor{out, C};
+    }
+
+    // UNet2DConditionModel.forward (models/unet_2d_condition.py:703-983), batched over streams
+    void unet_forward(const FwdIn& in) {
+        const int B = in.B, Hh = in.h, Ww = in.w, HW0 = Hh * Ww;
+        RT_REQUIRE(B >= 1 && B <= cfg.max_streams && B <= RT_MAXB, "forward: too many streams");
+        RT_REQUIRE(Hh <= cfg.latent_h && Ww <= cfg.latent_w, "forward: latent larger than configured");
+        RT_REQUIRE((Hh % (1 << (cfg.n_levels - 1))) == 0 && (Ww % (1 << (cfg.n_levels - 1))) == 0, "forward: latent size not divisible");
+        const size_t m0 = ws.mark();
+        // time / addition embeddings (unet_2d_condition.py:784-877)
+        float* emb = ws.f32((size_t)B * temb_dim);
+        {
+            Scope sc(ws);
+            float* tv = ws.f32(4); float* tsin = ws.f32(cfg.block_out_channels[0]);
+            float* e1 = ws.f32(temb_dim); float* e2 = ws.f32(temb_dim);
+            if (!dry()) {
+                HIP_CHECK(hipMemcpyAsync(tv, &in.t, 4, hipMemcpyHostToDevice, stream));
+                launch_timestep_embed(tv, 1, cfg.block_out_channels[0], tsin, cfg.block_out_channels[0], stream);
+                launch_small_linear(tsin, cfg.block_out_channels[0], t1.w, t1.K, t1.b, e1, temb_dim, 1, temb_dim, t1.K, 0, 0, stream);
+                launch_small_linear(e1, temb_dim, t2.w, t2.K, t2.b, e2, temb_dim, 1, temb_dim, temb_dim, 1, 0, stream);
+                launch_gather_add_rows(e2, aug_emb, in.prompt, emb, B, temb_dim, stream);
+            }
+        }
+        std::vector<Tensor> skips;
+        Tensor x;
+        {
+            float* x0 = ws.f32((size_t)B * HW0 * cfg.block_out_channels[0]);
+            Scope sc(ws);
+            bf16_t* x8 = ws.b16((size_t)B * HW0 * 8);
+            if (!dry()) {
+                PrepArgs p{}; p.B = B; p.HW = HW0; p.dst = x8;
+                for (int b = 0; b < B; ++b) { p.src[b] = in.x[b]; p.scale[b] = in.scale[b]; }
+                launch_prep_latents(p, stream);
+            }
+            conv3(x8, A_CONV3, conv_in, B, Hh, Ww, 8, x0, EPI_F32);
+            x = Tensor{x0, cfg.block_out_channels[0]};
+        }
+        skips.push_back(x);
+        int ch = Hh, cw = Ww;
+        for (size_t i = 0; i < down.size(); ++i) {
+            const DownP& d = down[i];
+            for (size_t j = 0; j < d.res.size(); ++j) {
+                x = resnet(d.res[j], in, ch * cw, ch, cw, x, nullptr, emb, false);
+                if (d.has_attn) x = transformer(d.attn[j], in, ch * cw, x);
+                skips.push_back(x);
+            }
+            if (d.has_down) {
+                const int nh = (ch + 1) / 2, nw = (cw + 1) / 2;
+                float* y = ws.f32((size_t)B * nh * nw * d.C);
+                {
+                    Scope sc(ws);
+                    bf16_t* xb = ws.b16((size_t)B * ch * cw * d.C);
+                    if (!dry()) launch_cast_f32_bf16(x.p, xb, (size_t)B * ch * cw * d.C, stream);
+                    conv3(xb, A_CONV3_S2, d.down, B, ch, cw, d.C, y, EPI_F32);
+                }
+                ch = nh; cw = nw;
+                x = Tensor{y, d.C};
+                skips.push_back(x);
+            }
+        }
+        x = resnet(mid_r0, in, ch * cw, ch, cw, x, nullptr, emb, false);
+        x = transformer(mid_t, in, ch * cw, x);
+        x = resnet(mid_r1, in, ch * cw, ch, cw, x, nullptr, emb, false);
+        for (size_t i = 0; i < up.size(); ++i) {
+            const UpP& u = up[i];
+            for (size_t j = 0; j < u.res.size(); ++j) {
+                Tensor sk = skips.back(); skips.pop_back();
+                const bool inject_here = (i == 1 && j == 1);        // 'up_blocks.1.resnets.1' (rd.py:350, xl.py:1101)
+                x = resnet(u.res[j], in, ch * cw, ch, cw, x, &sk, emb, inject_here);
+                if (u.has_attn) x = transformer(u.attn[j], in, ch * cw, x);
+            }
+            if (u.has_up) {
+                float* y = ws.f32((size_t)B * ch * cw * 4 * u.C);
+                {
+                    Scope sc(ws);
+                    bf16_t* xb = ws.b16((size_t)B * ch * cw * u.C);
+                    if (!dry()) launch_cast_f32_bf16(x.p, xb, (size_t)B * ch * cw * u.C, stream);
+                    conv3(xb, A_CONV3_UP2, u.up, B, ch, cw, u.C, y, EPI_F32);
+                }
+                ch *= 2; cw *= 2;
+                x = Tensor{y, u.C};
+            }
+        }
+        {
+            Scope sc(ws);
+            bf16_t* hn = ws.b16((size_t)B * HW0 * x.C);
+            groupnorm(x.p, nullptr, false, x.C, 0, B, HW0, norm_out, cfg.norm_eps, true, hn, nullptr);
+            conv3(hn, A_CONV3, conv_out, B, Hh, Ww, x.C, in.eps_out, EPI_F32);
+        }
+        ws.release(m0);
+    }
+
+    // ---------------------------------------------------------------------------- per-image setup
+    void set_prompts(const float* pe, const float* pooled, const float* time_ids, int P, int pooled_dim) {
+        RT_REQUIRE(P >= 1 && P <= cfg.max_prompts, "set_prompts: too many prompts");
+        require_bound();
+        const int D = cfg.cross_attention_dim;
+        Scope sc(ws);
+        bf16_t* ctx = ws.b16((size_t)cfg.max_prompts * 96 * D);
+        launch_pad_ctx(pe, ctx, P, D, stream);
+        auto build = [&](TransformerP& t) {
+            const int HD = t.heads * t.DP;
+            for (TBlockP& k : t.blocks) {
+                gemm(ctx, D, k.k2, P * 96, k.kcache, HD, EPI_BF16);
+                gemm_vt(k.v2, ctx, D, P * 96, k.vtcache, cfg.max_prompts * 96);
+            }
+        };
+        for (auto& d : down) for (auto& t : d.attn) build(t);
+        build(mid_t);
+        for (auto& u : up) for (auto& t : u.attn) build(t);
+        HIP_CHECK(hipMemsetAsync(aug_emb, 0, (size_t)cfg.max_prompts * temb_dim * 4, stream));
+        if (cfg.addition_text_time) {
+            RT_REQUIRE(pooled && time_ids, "set_prompts: SDXL needs pooled embeds and time_ids");
+            const int td = cfg.addition_time_embed_dim, Kin = cfg.projection_class_embeddings_input_dim;
+            RT_REQUIRE(pooled_dim + 6 * td == Kin, "set_prompts: pooled_dim + 6*time_embed_dim != projection input dim");
+            float* tid = ws.f32(8); float* tsin = ws.f32((size_t)6 * td);
+            float* add = ws.f32((size_t)P * Kin); float* hmid = ws.f32((size_t)P * temb_dim);
+            HIP_CHECK(hipMemcpyAsync(tid, time_ids, 24, hipMemcpyHostToDevice, stream));
+            launch_timestep_embed(tid, 6, td, tsin, td, stream);
+            for (int p_ = 0; p_ < P; ++p_) {
+                HIP_CHECK(hipMemcpyAsync(add + (size_t)p_ * Kin, pooled + (size_t)p_ * pooled_dim, (size_t)pooled_dim * 4, hipMemcpyDeviceToDevice, stream));
+                HIP_CHECK(hipMemcpyAsync(add + (size_t)p_ * Kin + pooled_dim, tsin, (size_t)6 * td * 4, hipMemcpyDeviceToDevice, stream));
+            }
+            launch_small_linear(add, Kin, a1.w, a1.K, a1.b, hmid, temb_dim, P, temb_dim, Kin, 0, 0, stream);
+            launch_small_linear(hmid, temb_dim, a2.w, a2.K, a2.b, aug_emb, temb_dim, P, temb_dim, temb_dim, 1, 0, stream);
+        }
+        n_prompts = P;
+        HIP_CHECK(hipStreamSynchronize(stream));   // host buffers (time_ids) may go away
+    }
+
+    void set_fontsize(const int64_t* word_pos, const float* font_size, int n) {
+        // set 0: plain softmax; set 1: font-size softmax (attention_processor.py:386-396).  wabs = 0 on padded keys.
+        float ha[2 * 96], hs[2 * 96];
+        for (int s = 0; s < 2; ++s) for (int k = 0; k < 96; ++k) { ha[s * 96 + k] = k < 77 ? 1.f : 0.f; hs[s * 96 + k] = 1.f; }
+        for (int i = 0; i < n; ++i) {
+            RT_REQUIRE(word_pos[i] >= 0 && word_pos[i] < 77, "set_fontsize: word_pos out of range");
+        }
+        // torch index_put semantics with repeated indices: the last write wins for '=' and every '*=' on the
+        // gathered copy also resolves to a single write per index (attention_processor.py:393,396)
+        for (int i = 0; i < n; ++i) {
+            const int k = (int)word_pos[i];
+            ha[96 + k] = std::fabs(font_size[i]);
+            hs[96 + k] = font_size[i] > 0 ? 1.f : (font_size[i] < 0 ? -1.f : 0.f);
+        }
+        HIP_CHECK(hipMemcpyAsync(wabs, ha, sizeof(ha), hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(wsgn, hs, sizeof(hs), hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+    }
+
+    void require_bound() {
+        for (auto& s : slots) if (!s.bound) throw rt_error(RT_E_MISSING_WEIGHT, "weight not bound: " + s.name);
+    }
+
+    // ---------------------------------------------------------------------------- step drivers
+    void region_step(int i, float g, float inject_selfattn, float inject_background, bool xl, bool elide);
+    void plain_step(int i, float g);
+};
+
+#include "step_driver.inl"
+
+// ================================================================================================
+// C ABI
+#define RT_TRY(e, body)                                                            \
+    try { body; return RT_OK; }                                                    \
+    catch (const rt_error& ex) { (e)->err = ex.what(); return ex.code; }           \
+    catch (const std::exception& ex) { (e)->err = ex.what(); return RT_E_INVALID; }
+
+extern "C" {
+
+int rt_create(const rt_config* cfg, int device, rt_engine** out) {
+    rt_engine* e = nullptr;
+    try {
+        RT_REQUIRE(cfg && out, "rt_create: null argument");
+        RT_REQUIRE(cfg->n_levels >= 2 && cfg->n_levels <= RT_MAX_LEVELS, "rt_create: n_levels");
+        RT_REQUIRE(cfg->max_streams >= 1 && cfg->max_streams <= RT_MAXB, "rt_create: max_streams must be in [1,16]");
+        RT_REQUIRE(cfg->in_channels == 4 && cfg->out_channels == 4, "rt_create: latent channels must be 4");
+        RT_REQUIRE(cfg->cross_attention_dim % 8 == 0, "rt_create: cross_attention_dim % 8");
+        e = new rt_engine();
+        e->cfg = *cfg; e->device = device;
+        // pass 1: measure the arena (no device needed: lets CPU-only hosts enumerate the weight table)
+        e->arena = Arena(); e->sarena = Arena(); e->ws.dry = true;
+        e->build_plan();
+        e->arena_bytes = e->arena.off + 256; e->sarena_bytes = e->sarena.off + 256;
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0 || device < 0) {
+            // weight-table-only engine (CPU box): every device call will fail with RT_E_STATE
+            e->arena_base = nullptr;
+            *out = e;
+            return RT_OK;
+        }
+        HIP_CHECK(hipSetDevice(device));
+        HIP_CHECK(hipStreamCreate(&e->stream));
+        HIP_CHECK(hipMalloc((void**)&e->arena_base, e->arena_bytes));
+        HIP_CHECK(hipMemset(e->arena_base, 0, e->arena_bytes));
+        HIP_CHECK(hipMalloc((void**)&e->sarena_base, e->sarena_bytes));
+        HIP_CHECK(hipMemset(e->sarena_base, 0, e->sarena_bytes));
+        e->arena = Arena(); e->arena.base = e->arena_base; e->arena.cap = e->arena_bytes;
+        e->sarena = Arena(); e->sarena.base = e->sarena_base; e->sarena.cap = e->sarena_bytes;
+        e->build_plan();
+        // pass 2: measure the workspace with a dry forward at the largest shape
+        {
+            FwdIn in{}; in.B = cfg->max_streams; in.h = cfg->latent_h; in.w = cfg->latent_w;
+            for (int b = 0; b < in.B; ++b) { in.qk_src[b] = b; in.res_src[b] = b ? 0 : -1; in.prompt[b] = 0; }
+            e->ws = Workspace(); e->ws.dry = true;
+            e->unet_forward(in);
+            size_t peak = e->ws.peak;
+            // set_prompts scratch
+            size_t sp = (size_t)cfg->max_prompts * 96 * cfg->cross_attention_dim * 2 + (size_t)cfg->max_prompts * (cfg->projection_class_embeddings_input_dim + e->temb_dim) * 4 + (1 << 16);
+            if (sp > peak) peak = sp;
+            peak += 1 << 20;
+            e->ws = Workspace();
+            HIP_CHECK(hipMalloc((void**)&e->ws.base, peak));
+            e->ws.cap = peak;
+        }
+        *out = e;
+        return RT_OK;
+    } catch (const std::exception& ex) {
+        g_create_error = ex.what();
+        delete e;
+        return RT_E_INVALID;
+    }
+}
+
+int rt_destroy(rt_engine* e) {
+    if (!e) return RT_OK;
+    if (e->arena_base) { hipSetDevice(e->device); hipStreamSynchronize(e->stream); hipFree(e->arena_base); hipFree(e->sarena_base); hipFree(e->ws.base); hipStreamDestroy(e->stream); }
+    delete e;
+    return RT_OK;
+}
+
+const char* rt_last_error(rt_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+
+static void need_device(rt_engine* e) { if (!e->arena_base) throw rt_error(RT_E_STATE, "engine has no device (weight-table-only)"); }
+
+int rt_set_stream(rt_engine* e, void* s) { RT_TRY(e, { need_device(e); e->stream = (hipStream_t)s; }) }
+int rt_synchronize(rt_engine* e) { RT_TRY(e, { need_device(e); HIP_CHECK(hipStreamSynchronize(e->stream)); }) }
+
+int rt_weight_count(rt_engine* e) { return (int)e->slots.size(); }
+int rt_weight_info(rt_engine* e, int idx, char* name, int cap, int64_t* shape4, int* ndim) {
+    RT_TRY(e, {
+        RT_REQUIRE(idx >= 0 && idx < (int)e->slots.size(), "rt_weight_info: index");
+        const WeightSlot& s = e->slots[idx];
+        RT_REQUIRE((int)s.name.size() < cap, "rt_weight_info: name buffer too small");
+        std::strcpy(name, s.name.c_str());
+        *ndim = (int)s.shape.size();
+        for (size_t i = 0; i < s.shape.size(); ++i) shape4[i] = s.shape[i];
+    })
+}
+int rt_bind_weight(rt_engine* e, const char* name, const void* ptr, int dtype, const int64_t* shape, int ndim) {
+    RT_TRY(e, {
+        need_device(e);
+        auto it = e->slot_index.find(name);
+        if (it == e->slot_index.end()) throw rt_error(RT_E_INVALID, std::string("unknown weight: ") + name);
+        WeightSlot& s = e->slots[it->second];
+        RT_REQUIRE(ndim == (int)s.shape.size(), "rt_bind_weight: rank mismatch");
+        for (int i = 0; i < ndim; ++i)
+            if (shape[i] != s.shape[i]) throw rt_error(RT_E_INVALID, std::string("shape mismatch for ") + name);
+        RT_REQUIRE(dtype >= 0 && dtype <= 2, "rt_bind_weight: dtype");
+        PackArgs p = s.pack; p.src = ptr; p.src_dtype = dtype;
+        launch_pack(p, e->stream);
+        s.bound = true;
+    })
+}
+int rt_weights_missing(rt_engine* e, char* buf, int cap) {
+    int n = 0; std::string acc;
+    for (auto& s : e->slots) if (!s.bound) { ++n; if (acc.size() + s.name.size() + 2 < (size_t)cap) { acc += s.name; acc += ';'; } }
+    if (buf && cap > 0) { std::strncpy(buf, acc.c_str(), cap - 1); buf[cap - 1] = 0; }
+    return n;
+}
+int rt_arena_info(rt_engine* e, void** p, uint64_t* bytes) { RT_TRY(e, { need_device(e); *p = e->arena_base; *bytes = e->arena_bytes; }) }
+int rt_arena_mark_bound(rt_engine* e) { for (auto& s : e->slots) s.bound = true; return RT_OK; }
+
+int rt_set_prompts(rt_engine* e, const float* pe, const float* pooled, const float* tids, int P, int pooled_dim) {
+    RT_TRY(e, { need_device(e); e->set_prompts(pe, pooled, tids, P, pooled_dim); })
+}
+int rt_set_masks(rt_engine* e, const float* m, int R, int h, int w) {
+    RT_TRY(e, {
+        need_device(e);
+        RT_REQUIRE(R >= 1 && R <= RT_MAXB && h <= e->cfg.latent_h && w <= e->cfg.latent_w, "rt_set_masks: bad shape");
+        HIP_CHECK(hipMemcpyAsync(e->masks, m, (size_t)R * 4 * h * w * 4, hipMemcpyDeviceToDevice, e->stream));
+        e->n_regions = R; e->mask_hw = h * w;
+    })
+}
+int rt_set_fontsize(rt_engine* e, const int64_t* wp, const float* fs, int n) { RT_TRY(e, { need_device(e); e->set_fontsize(wp, fs, n); }) }
+int rt_set_schedule(rt_engine* e, int kind, const float* ts, int nts, const float* table, int ntab, int nsteps) {
+    RT_TRY(e, {
+        RT_REQUIRE(kind == RT_SCHED_EULER || kind == RT_SCHED_PNDM, "rt_set_schedule: kind");
+        e->sched_kind = kind; e->num_inference_steps = nsteps;
+        e->timesteps.assign(ts, ts + nts); e->table.assign(table, table + ntab);
+        if (kind == RT_SCHED_EULER) RT_REQUIRE(ntab == nts + 1, "euler: need n+1 sigmas");
+        e->pndm_counter = 0; e->pndm_nets = 0; e->pndm_head = 0; e->steps_done = 0;
+    })
+}
+int rt_set_latents(rt_engine* e, const float* l, int h, int w) {
+    RT_TRY(e, {
+        need_device(e);
+        RT_REQUIRE(h <= e->cfg.latent_h && w <= e->cfg.latent_w, "rt_set_latents: too large");
+        const size_t n = (size_t)4 * h * w * 4;
+        HIP_CHECK(hipMemcpyAsync(e->lat, l, n, hipMemcpyDeviceToDevice, e->stream));
+        HIP_CHECK(hipMemcpyAsync(e->lat_ref, l, n, hipMemcpyDeviceToDevice, e->stream));
+        e->lat_h = h; e->lat_w = w;
+        e->pndm_counter = 0; e->pndm_nets = 0; e->pndm_head = 0; e->steps_done = 0;
+    })
+}
+int rt_get_latents(rt_engine* e, float* out, float* out_ref) {
+    RT_TRY(e, {
+        need_device(e);
+        const size_t n = (size_t)4 * e->lat_h * e->lat_w * 4;
+        HIP_CHECK(hipMemcpyAsync(out, e->lat, n, hipMemcpyDeviceToDevice, e->stream));
+        if (out_ref) HIP_CHECK(hipMemcpyAsync(out_ref, e->lat_ref, n, hipMemcpyDeviceToDevice, e->stream));
+    })
+}
+int rt_region_step(rt_engine* e, int i, float g, float isa, float ibg, int xl, int elide) {
+    RT_TRY(e, { need_device(e); e->region_step(i, g, isa, ibg, xl != 0, elide != 0); })
+}
+int rt_plain_step(rt_engine* e, int i, float g) { RT_TRY(e, { need_device(e); e->plain_step(i, g); }) }
+
+int rt_unet_forward(rt_engine* e, const float* x, int B, int h, int w, float t, const float* in_scale, const int* prompt,
+                    const int* fontsize, const int* qk_src, const int* res_src, float* out) {
+    RT_TRY(e, {
+        need_device(e); e->require_bound();
+        RT_REQUIRE(B >= 1 && B <= e->cfg.max_streams, "rt_unet_forward: batch");
+        RT_REQUIRE(e->n_prompts > 0, "rt_unet_forward: call rt_set_prompts first");
+        FwdIn in{}; in.B = B; in.h = h; in.w = w; in.t = t; in.eps_out = e->eps;
+        for (int b = 0; b < B; ++b) {
+            in.x[b] = x + (size_t)b * 4 * h * w; in.scale[b] = in_scale ? in_scale[b] : 1.f;
+            in.prompt[b] = prompt ? prompt[b] : 0; in.fontsize[b] = fontsize ? fontsize[b] : 0;
+            in.qk_src[b] = qk_src ? qk_src[b] : b; in.res_src[b] = res_src ? res_src[b] : -1;
+            RT_REQUIRE(in.prompt[b] >= 0 && in.prompt[b] < e->n_prompts, "rt_unet_forward: prompt index");
+            RT_REQUIRE(in.qk_src[b] >= 0 && in.qk_src[b] < B && in.res_src[b] < B, "rt_unet_forward: source stream index");
+        }
+        e->unet_forward(in);
+        launch_nhwc4_to_nchw(e->eps, out, B, h * w, e->stream);
+    })
+}
+
+// ---- operator-level entry points (stateless; share one lazily allocated zero page per device) ----
+static bf16_t* op_zero_page() {
+    static thread_local bf16_t* z = nullptr;
+    if (!z) { HIP_CHECK(hipMalloc((void**)&z, 256)); HIP_CHECK(hipMemset(z, 0, 256)); }
+    return z;
+}
+#define OP_TRY(body)                                                         \
+    try { body; return RT_OK; }                                              \
+    catch (const rt_error& ex) { g_op_error = ex.what(); return ex.code; }   \
+    catch (const std::exception& ex) { g_op_error = ex.what(); return RT_E_INVALID; }
+
+const char* rt_op_last_error(void) { return g_op_error.c_str(); }
+
+int rt_op_gemm(const void* A, const void* W, const float* bias, void* out, const float* res, const float* temb, int mode,
+               int epi, int M, int N, int K, int lda, int ldw, int ldo, int ldres, int temb_ld, int rows_per_batch, int Hin,
+               int Win, int Cin, int Hout, int Wout, void* stream) {
+    OP_TRY({
+        GemmArgs g{}; g.A = (const bf16_t*)A; g.W = (const bf16_t*)W; g.bias = bias; g.out = out; g.res = res; g.temb = temb;
+        g.zero = op_zero_page(); g.mode = mode; g.epi = epi; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldo = ldo;
+        g.ldres = ldres; g.temb_ld = temb_ld; g.rows_per_batch = rows_per_batch; g.Hin = Hin; g.Win = Win; g.Cin = Cin;
+        g.Hout = Hout; g.Wout = Wout;
+        launch_gemm(g, (hipStream_t)stream);
+    })
+}
+int rt_op_attention(const void* Q, int ldq, const void* K, int ldk, const void* VT, int ldvt, void* O, int ldo, const int* q_src,
+                    const int* k_src, const int* v_src, const int* wset, const float* wabs, const float* wsgn, int B, int H,
+                    int N, int NK, int nk_valid, int DP, int cross, void* stream) {
+    OP_TRY({
+        RT_REQUIRE(B >= 1 && B <= RT_MAXB, "rt_op_attention: batch");
+        AttnArgs a{}; a.Q = (const bf16_t*)Q; a.ldq = ldq; a.K = (const bf16_t*)K; a.ldk = ldk; a.VT = (const bf16_t*)VT; a.ldvt = ldvt;
+        a.O = (bf16_t*)O; a.ldo = ldo; a.wabs = wabs; a.wsgn = wsgn;
+        for (int b = 0; b < B; ++b) { a.q_src[b] = q_src ? q_src[b] : b; a.k_src[b] = k_src ? k_src[b] : b; a.v_src[b] = v_src ? v_src[b] : b; a.wset[b] = wset ? wset[b] : 0; }
+        a.B = B; a.H = H; a.N = N; a.NK = NK; a.nk_valid = nk_valid; a.DP = DP; a.cross = cross;
+        launch_attention(a, (hipStream_t)stream);
+    })
+}
+int rt_op_groupnorm(const void* x1, const void* x2, int in_bf16, int C1, int C2, int G, int B, int HW, const float* gamma,
+                    const float* beta, float eps, int silu, void* out, void* raw, void* stream) {
+    OP_TRY({
+        GroupNormArgs a{}; a.x1 = x1; a.x2 = x2; a.in_bf16 = in_bf16; a.C1 = C1; a.C2 = C2; a.G = G; a.B = B; a.HW = HW;
+        a.gamma = gamma; a.beta = beta; a.eps = eps; a.silu = silu; a.out = (bf16_t*)out; a.raw_out = (bf16_t*)raw;
+        a.nchunk = groupnorm_nchunk(HW); a.rows_per_chunk = groupnorm_rows_per_chunk(HW);
+        float* partial = nullptr;
+        HIP_CHECK(hipMalloc((void**)&partial, (size_t)B * a.nchunk * G * 2 * 4));
+        a.partial = partial;
+        launch_groupnorm(a, (hipStream_t)stream);
+        HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+        HIP_CHECK(hipFree(partial));
+    })
+}
+int rt_op_layernorm(const float* x, const float* gamma, const float* beta, void* out, int rows, int C, float eps, void* stream) {
+    OP_TRY({ launch_layernorm(x, gamma, beta, (bf16_t*)out, rows, C, eps, (hipStream_t)stream); })
+}
+int rt_op_small_linear(const float* a, int lda, const void* W, int ldw, const float* bias, float* out, int ldo, int B, int N,
+                       int K, int silu_in, int accumulate, void* stream) {
+    OP_TRY({ launch_small_linear(a, lda, (const bf16_t*)W, ldw, bias, out, ldo, B, N, K, silu_in, accumulate, (hipStream_t)stream); })
+}
+int rt_op_timestep_embed(const float* t, int n, int dim, float* out, int ldo, void* stream) {
+    OP_TRY({ launch_timestep_embed(t, n, dim, out, ldo, (hipStream_t)stream); })
+}
+
+}  // extern "C"

@@ -1,0 +1,189 @@
+// GroupNorm (+SiLU, + virtual channel concat) and LayerNorm for NHWC / token-major activations.
+//
+// Replaces nn.GroupNorm + SiLU in ResnetBlock2D (models/resnet.py:594-624), Transformer2DModel.norm
+// (models/transformer_2d.py:137,274; eps 1e-6), conv_norm_out (models/unet_2d_condition.py:555-557,975-977)
+// and the three nn.LayerNorm of BasicTransformerBlock (models/attention.py:84,103,119).  The skip
+// concatenation of the up blocks (models/unet_2d_blocks.py:2107-2109, 2210-2212) is never materialised
+// in fp32: GroupNorm reads the two fp32 sources as one virtual [C1 | C2] tensor and writes the bf16
+// operand(s) of the following convolution.  HBM-bound kernels: 16-B vector loads, fp32 statistics,
+// deterministic two-level reduction (no atomics in global memory).
+#include "common.h"
+
+static inline int gn_rows_per_chunk(int HW) { int r = HW / 128; return r < 16 ? 16 : (r > 128 ? 128 : r); }
+int groupnorm_rows_per_chunk(int HW) { return gn_rows_per_chunk(HW); }
+int groupnorm_nchunk(int HW) { return cdiv(HW, gn_rows_per_chunk(HW)); }
+
+template <bool BF16IN>
+__device__ __forceinline__ void load4(const void* x1, const void* x2, int C1, int C2, size_t row, int c, float v[4]) {
+    if (BF16IN) {
+        const uint2 u = *(const uint2*)((const bf16_t*)x1 + row * C1 + c);
+        v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+        v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+    } else {
+        const float4 f = (c < C1) ? *(const float4*)((const float*)x1 + row * C1 + c)
+                                  : *(const float4*)((const float*)x2 + row * C2 + (c - C1));
+        v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+    }
+}
+
+// Thread decomposition shared by both kernels: nv = C/4 channel vectors per row.
+//   nv >= 256: every thread walks vectors tid, tid+256, ... over all rows of the chunk (1 row lane)
+//   nv <  256: 256/nv row lanes, each thread owns one vector and every (256/nv)-th row
+#define GN_MAXC 2560
+
+// grid (nchunk, B); partial[b][chunk][g][2] = (sum, sumsq) over this chunk's rows
+template <bool BF16IN>
+__global__ __launch_bounds__(256) void gn_stats_kernel(GroupNormArgs p) {
+    __shared__ float sh_s[GN_MAXC], sh_q[GN_MAXC];
+    const int C = p.C1 + p.C2, cpg = C / p.G, nv = C >> 2;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int r0 = chunk * p.rows_per_chunk;
+    const int r1 = min(r0 + p.rows_per_chunk, p.HW);
+    const int nrl = nv >= 256 ? 1 : 256 / nv;
+    const int rl = nv >= 256 ? 0 : threadIdx.x / nv;
+    const int v0 = nv >= 256 ? threadIdx.x : threadIdx.x % nv;
+    if (rl < nrl) {
+        for (int vec = v0; vec < nv; vec += 256) {
+            const int c = vec * 4;
+            float s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+            for (int r = r0 + rl; r < r1; r += nrl) {
+                float v[4];
+                load4<BF16IN>(p.x1, p.x2, p.C1, p.C2, (size_t)b * p.HW + r, c, v);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s[e] += v[e]; ss[e] += v[e] * v[e]; }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { sh_s[rl * C + c + e] = s[e]; sh_q[rl * C + c + e] = ss[e]; }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < p.G) {   // fixed summation order => deterministic
+        float s = 0.f, q = 0.f;
+        for (int k = 0; k < nrl; ++k)
+            for (int c = threadIdx.x * cpg; c < (threadIdx.x + 1) * cpg; ++c) { s += sh_s[k * C + c]; q += sh_q[k * C + c]; }
+        float* dst = p.partial + ((size_t)b * p.nchunk + chunk) * 2 * p.G + 2 * threadIdx.x;
+        dst[0] = s; dst[1] = q;
+    }
+}
+
+// grid (nchunk, B)
+template <bool BF16IN>
+__global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormArgs p) {
+    __shared__ float mean[32], rstd[32];
+    const int C = p.C1 + p.C2, cpg = C / p.G, nv = C >> 2;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    if (threadIdx.x < p.G) {
+        double s = 0.0, ss = 0.0;
+        for (int k = 0; k < p.nchunk; ++k) {
+            s += (double)p.partial[((size_t)b * p.nchunk + k) * 2 * p.G + 2 * threadIdx.x];
+            ss += (double)p.partial[((size_t)b * p.nchunk + k) * 2 * p.G + 2 * threadIdx.x + 1];
+        }
+        const double n = (double)cpg * p.HW;
+        const double mu = s / n;
+        double var = ss / n - mu * mu;
+        if (var < 0) var = 0;
+        mean[threadIdx.x] = (float)mu;
+        rstd[threadIdx.x] = (float)(1.0 / sqrt(var + (double)p.eps));
+    }
+    __syncthreads();
+    const int r0 = chunk * p.rows_per_chunk;
+    const int r1 = min(r0 + p.rows_per_chunk, p.HW);
+    const int nrl = nv >= 256 ? 1 : 256 / nv;
+    const int rl = nv >= 256 ? 0 : threadIdx.x / nv;
+    const int v0 = nv >= 256 ? threadIdx.x : threadIdx.x % nv;
+    if (rl >= nrl) return;
+    for (int vec = v0; vec < nv; vec += 256) {
+        const int c = vec * 4;
+        float ga[4], be[4], mu[4], rs[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int g = (c + e) / cpg;
+            ga[e] = p.gamma[c + e]; be[e] = p.beta[c + e]; mu[e] = mean[g]; rs[e] = rstd[g];
+        }
+        for (int r = r0 + rl; r < r1; r += nrl) {
+            const size_t row = (size_t)b * p.HW + r;
+            float v[4], y[4];
+            load4<BF16IN>(p.x1, p.x2, p.C1, p.C2, row, c, v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y[e] = (v[e] - mu[e]) * rs[e] * ga[e] + be[e];
+                if (p.silu) y[e] = y[e] / (1.f + __expf(-y[e]));
+            }
+            uint2 o; o.x = pack_bf16x2(y[0], y[1]); o.y = pack_bf16x2(y[2], y[3]);
+            *(uint2*)(p.out + row * C + c) = o;
+            if (p.raw_out) {
+                uint2 w; w.x = pack_bf16x2(v[0], v[1]); w.y = pack_bf16x2(v[2], v[3]);
+                *(uint2*)(p.raw_out + row * C + c) = w;
+            }
+        }
+    }
+}
+
+void launch_groupnorm(const GroupNormArgs& a, hipStream_t st) {
+    const int C = a.C1 + a.C2;
+    RT_REQUIRE(a.G >= 1 && a.G <= 32 && C % a.G == 0, "groupnorm: bad group count");
+    RT_REQUIRE(a.C1 % 4 == 0 && a.C2 % 4 == 0, "groupnorm: channels must be multiples of 4");
+    RT_REQUIRE(!(a.in_bf16 && a.x2), "groupnorm: bf16 input cannot be a concat");
+    RT_REQUIRE(a.nchunk == groupnorm_nchunk(a.HW) && a.rows_per_chunk == gn_rows_per_chunk(a.HW), "groupnorm: nchunk mismatch");
+    RT_REQUIRE(C <= GN_MAXC, "groupnorm: too many channels");
+    dim3 grid(a.nchunk, a.B), block(256);
+    if (a.in_bf16) {
+        hipLaunchKernelGGL(gn_stats_kernel<true>, grid, block, 0, st, a);
+        hipLaunchKernelGGL(gn_apply_kernel<true>, grid, block, 0, st, a);
+    } else {
+        hipLaunchKernelGGL(gn_stats_kernel<false>, grid, block, 0, st, a);
+        hipLaunchKernelGGL(gn_apply_kernel<false>, grid, block, 0, st, a);
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------- LayerNorm: one wave per row
+#define LN_MAXV 5   // C <= 1280 (float4 per lane per 256 channels)
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, bf16_t* __restrict__ out,
+                                                        int rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * C;
+    float4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = i * 256 + lane * 4;
+        if (c < C) { v[i] = *(const float4*)(xr + c); s += v[i].x + v[i].y + v[i].z + v[i].w; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mu = s / C;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = i * 256 + lane * 4;
+        if (c < C) {
+            const float a = v[i].x - mu, b = v[i].y - mu, d = v[i].z - mu, e = v[i].w - mu;
+            ss += a * a + b * b + d * d + e * e;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    const float rs = rsqrtf(ss / C + eps);
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = i * 256 + lane * 4;
+        if (c < C) {
+            const float4 g = *(const float4*)(gamma + c), bb = *(const float4*)(beta + c);
+            uint2 o;
+            o.x = pack_bf16x2((v[i].x - mu) * rs * g.x + bb.x, (v[i].y - mu) * rs * g.y + bb.y);
+            o.y = pack_bf16x2((v[i].z - mu) * rs * g.z + bb.z, (v[i].w - mu) * rs * g.w + bb.w);
+            *(uint2*)(out + (size_t)row * C + c) = o;
+        }
+    }
+}
+
+void launch_layernorm(const float* x, const float* gamma, const float* beta, bf16_t* out, int rows, int C,
+                      float eps, hipStream_t st) {
+    RT_REQUIRE(C % 4 == 0 && C <= LN_MAXV * 256, "layernorm: C must be a multiple of 4 and <= 1280");
+    hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, gamma, beta, out, rows, C, eps);
+    HIP_CHECK(hipGetLastError());
+}

@@ -1,0 +1,107 @@
+// Host step drivers (included by engine.hip).  Flag logic follows the reference loops line by line:
+//   SD  : models/region_diffusion.py:99-173        XL : models/region_diffusion_sdxl.py:779-872
+
+static void pndm_coeffs(rt_engine* e, int i, StepArgs& a) {
+    // PNDMScheduler.step_plms (diffusers 0.18.2, [memory]); see oracle/schedulers.py:OraclePNDM
+    const int ratio = 1000 / e->num_inference_steps;
+    int t = (int)e->timesteps[i];
+    int prev_t = t - ratio;
+    a.push = 0;
+    if (e->pndm_counter != 1) {
+        a.push = 1;
+        if (e->pndm_nets < 4) e->pndm_nets++;
+        e->pndm_head = (e->pndm_head + 3) & 3;        // new newest slot
+    } else {
+        prev_t = t; t = t + ratio;
+    }
+    const size_t per = (size_t)2 * 4 * e->lat_h * e->lat_w;
+    for (int k = 0; k < 4; ++k) a.ets[k] = e->ets + (size_t)((e->pndm_head + k) & 3) * per;
+    if (!a.push) { for (int k = 3; k >= 1; --k) a.ets[k] = a.ets[k - 1]; }   // ets[1] = newest stored
+    if (e->pndm_nets == 1 && e->pndm_counter == 0) a.pndm_mode = 0;
+    else if (e->pndm_nets == 1 && e->pndm_counter == 1) a.pndm_mode = 1;
+    else a.pndm_mode = e->pndm_nets;   // 2, 3, 4
+    RT_REQUIRE((int)e->table.size() >= 1000, "pndm: alphas_cumprod table missing");
+    const double a_t = e->table[t], a_p = prev_t >= 0 ? e->table[prev_t] : e->table[0];
+    const double b_t = 1 - a_t, b_p = 1 - a_p;
+    // computed in fp32 like the reference's tensor arithmetic on fp32 alphas
+    const float fa_t = (float)a_t, fa_p = (float)a_p, fb_t = (float)b_t, fb_p = (float)b_p;
+    const float sample_coeff = std::sqrt(fa_p / fa_t);
+    const float denom = fa_t * std::sqrt(fb_p) + std::sqrt(fa_t * fb_t * fa_p);
+    a.ca = sample_coeff; a.cb = (fa_p - fa_t) / denom;
+    a.cur_sample = e->cur_sample;
+    e->pndm_counter++;
+}
+
+void rt_engine::region_step(int i, float g, float isa, float ibg, bool xl, bool elide) {
+    require_bound();
+    const int n = (int)timesteps.size(), R = n_regions;
+    RT_REQUIRE(i >= 0 && i < n, "region_step: step index out of range");
+    RT_REQUIRE(R >= 1 && n_prompts == R + 1, "region_step: need R masks and R+1 prompts (rd.py:96-97)");
+    RT_REQUIRE(mask_hw == lat_h * lat_w && lat_h > 0, "region_step: masks/latents shape mismatch");
+    RT_REQUIRE((sched_kind == RT_SCHED_EULER) == xl, "region_step: SD uses PNDM, SDXL uses Euler");
+    const float t = timesteps[i];
+    const bool use_ref = isa > 0 || ibg > 0;
+    const double thr = (1.0 - (double)isa) * 1000.0;
+    auto feat_at = [&](int j) { return (double)timesteps[j] > thr; };
+    const bool feat = feat_at(i);
+    const int bg_index = (int)((double)ibg * n);
+    const bool blend = (i == bg_index) && ibg > 0;
+    bool step_ref = use_ref;
+    if (xl) step_ref = isa > 0 || ((double)i < (double)ibg * n);
+    bool run_ref = use_ref;
+    if (use_ref && elide) {
+        // the reference pair can only influence the output through injection at this step, or through
+        // latents_reference consumed by a later injected step or by the blend
+        int last_use = ibg > 0 ? bg_index : -1;
+        for (int j = 0; j < n; ++j) if (feat_at(j)) last_use = std::max(last_use, j);
+        run_ref = i <= last_use;
+    }
+    if (!run_ref) step_ref = false;
+
+    FwdIn in{}; in.h = lat_h; in.w = lat_w; in.t = t; in.eps_out = eps;
+    const float scale = xl ? 1.f / std::sqrt(table[i] * table[i] + 1.f) : 1.f;
+    StepArgs a{};
+    int F = 0;
+    auto add = [&](const float* x, int prompt, int fs) {
+        RT_REQUIRE(F < cfg.max_streams, "region_step: more streams than max_streams");
+        in.x[F] = x; in.scale[F] = scale; in.prompt[F] = prompt; in.fontsize[F] = fs; in.qk_src[F] = F; in.res_src[F] = -1;
+        return F++;
+    };
+    a.s_uncond = add(lat, 0, 0);
+    a.s_base = add(lat, R, 1);
+    a.s_uref = a.s_tref = -1;
+    if (run_ref) { a.s_uref = add(lat_ref, 0, 0); a.s_tref = add(lat_ref, R, 0); }
+    for (int r = 0; r < R - 1; ++r) {
+        const int s = add(lat, r + 1, 0);
+        if (feat && run_ref) { in.qk_src[s] = a.s_tref; in.res_src[s] = a.s_tref; }
+        a.s_region[r] = s;
+    }
+    in.B = F;
+    unet_forward(in);
+
+    a.eps = eps; a.masks = masks; a.lat = lat; a.lat_ref = lat_ref; a.HW = lat_h * lat_w; a.R = R; a.g = g; a.plain = 0;
+    a.sched = sched_kind; a.step_ref = step_ref ? 1 : 0; a.blend = blend ? 1 : 0;
+    if (sched_kind == RT_SCHED_EULER) a.dsigma = table[i + 1] - table[i];
+    else pndm_coeffs(this, i, a);
+    launch_step_epilogue(a, stream);
+    steps_done++;
+}
+
+void rt_engine::plain_step(int i, float g) {
+    require_bound();
+    const int n = (int)timesteps.size();
+    RT_REQUIRE(i >= 0 && i < n, "plain_step: step index out of range");
+    RT_REQUIRE(n_prompts >= 2, "plain_step: need [negative, text] prompts");
+    const bool xl = sched_kind == RT_SCHED_EULER;
+    FwdIn in{}; in.h = lat_h; in.w = lat_w; in.t = timesteps[i]; in.eps_out = eps; in.B = 2;
+    const float scale = xl ? 1.f / std::sqrt(table[i] * table[i] + 1.f) : 1.f;
+    for (int b = 0; b < 2; ++b) { in.x[b] = lat; in.scale[b] = scale; in.prompt[b] = b; in.fontsize[b] = 0; in.qk_src[b] = b; in.res_src[b] = -1; }
+    unet_forward(in);
+    StepArgs a{};
+    a.eps = eps; a.masks = masks; a.lat = lat; a.lat_ref = lat_ref; a.HW = lat_h * lat_w; a.R = 0; a.g = g; a.plain = 1;
+    a.s_uncond = 0; a.s_base = 1; a.s_uref = a.s_tref = -1; a.sched = sched_kind; a.step_ref = 0; a.blend = 0;
+    if (xl) a.dsigma = table[i + 1] - table[i];
+    else pndm_coeffs(this, i, a);
+    launch_step_epilogue(a, stream);
+    steps_done++;
+}

@@ -1,0 +1,283 @@
+"""GPU parity tests of the individual HIP kernels through the C ABI (rt_op_*).
+
+Each kernel is compared with a plain PyTorch fp32 evaluation of the same operator of the reference on
+IDENTICAL bf16-rounded inputs, so the tolerances only have to absorb fp32 accumulation order and the final
+bf16 rounding of the output (2^-9 relative), not input quantisation.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from hiputil import DEV, attention, bf, gemm, groupnorm, layernorm, report, small_linear, timestep_embed  # noqa: E402
+
+BF16_OUT = dict(atol=2e-2, rtol=1.2e-2)     # bf16 output rounding (0.4 %) + margin, values O(1..10)
+F32_OUT = dict(atol=2e-3, rtol=2e-3)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ----------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (448, 320, 320), (1000, 72, 200), (64, 640, 2048),
+                                   (4096, 1280, 1280)])
+def test_gemm_dense_f32_bias_residual(M, N, K):
+    A, W = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=K ** -0.5))
+    bias, res = rnd(N, seed=3).to(DEV), rnd(M, N, seed=4).to(DEV)
+    out = gemm(A, W, bias, epi=1, res=res)
+    ref = A.float() @ W.float().t() + bias + res
+    report(f"gemm_f32 {M}x{N}x{K}", out, ref, **F32_OUT)
+
+
+def test_gemm_is_transpose_detecting_and_asymmetric():
+    # A = I (padded) with asymmetric W catches swapped row/col mapping of the MFMA C layout
+    M = N = K = 128
+    A = bf(torch.eye(M, K))
+    W = bf(torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251 / 16.0)
+    out = gemm(A, W, None, epi=1)
+    report("gemm identity", out, W.float().t(), atol=0, rtol=0)
+
+
+def test_gemm_bf16_out_and_strided_output():
+    M, N, K = 320, 192, 256
+    A, W = bf(rnd(M, K, seed=5)), bf(rnd(N, K, seed=6, scale=K ** -0.5))
+    out = gemm(A, W, None, epi=0)
+    report("gemm_bf16", out, A.float() @ W.float().t(), **BF16_OUT)
+
+
+def test_gemm_geglu_epilogue():
+    M, C = 256, 64                      # Linear(C, 8C) -> a * gelu(gate)
+    A = bf(rnd(M, C, seed=7))
+    Wfull = rnd(8 * C, C, seed=8, scale=C ** -0.5)
+    bfull = rnd(8 * C, seed=9)
+    # engine packing: per 64-row block [32 value rows | 32 gate rows]
+    half = 4 * C
+    rows = []
+    for blk in range(half // 32):
+        rows += list(range(blk * 32, blk * 32 + 32)) + list(range(half + blk * 32, half + blk * 32 + 32))
+    Wp, bp = bf(Wfull[rows]), bfull[rows].to(DEV).contiguous()
+    out = gemm(A, Wp, bp, epi=3)
+    h = A.float() @ bf(Wfull).float().t() + bfull.to(DEV)
+    a, g = h.chunk(2, dim=-1)
+    report("gemm_geglu", out, a * F.gelu(g), **BF16_OUT)
+
+
+def test_gemm_temb_epilogue():
+    B, HW, N, K = 3, 64, 96, 128
+    A, W = bf(rnd(B * HW, K, seed=10)), bf(rnd(N, K, seed=11, scale=K ** -0.5))
+    bias, temb = rnd(N, seed=12).to(DEV), rnd(B, N, seed=13).to(DEV)
+    out = gemm(A, W, bias, epi=2, temb=temb, rows_per_batch=HW)
+    ref = (A.float() @ W.float().t() + bias).reshape(B, HW, N) + temb[:, None, :]
+    report("gemm_temb", out, ref.reshape(B * HW, N), **BF16_OUT)
+
+
+def _conv_weight_packed(w):          # [Cout, Cin, 3, 3] -> [Cout, 9*Cin], K = tap*Cin + c
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+
+
+@pytest.mark.parametrize("mode,B,H,W_,Cin,Cout", [(1, 2, 16, 16, 32, 64), (1, 1, 8, 24, 64, 320), (2, 2, 16, 16, 32, 32),
+                                                  (3, 2, 8, 8, 64, 32), (1, 3, 32, 32, 8, 32), (1, 2, 64, 64, 320, 320)])
+def test_conv3x3_implicit_gemm(mode, B, H, W_, Cin, Cout):
+    x = rnd(B, Cin, H, W_, seed=20)
+    w = rnd(Cout, Cin, 3, 3, seed=21, scale=(9 * Cin) ** -0.5)
+    bias = rnd(Cout, seed=22)
+    xb, wb = x.to(torch.bfloat16).float(), w.to(torch.bfloat16).float()
+    if mode == 1:
+        ref = F.conv2d(xb, wb, bias, padding=1)
+    elif mode == 2:
+        ref = F.conv2d(xb, wb, bias, stride=2, padding=1)
+    else:
+        ref = F.conv2d(F.interpolate(xb, scale_factor=2.0, mode="nearest"), wb, bias, padding=1)
+    Hout, Wout = ref.shape[2], ref.shape[3]
+    A = bf(x.permute(0, 2, 3, 1))                          # NHWC
+    out = gemm(A, bf(_conv_weight_packed(w)), bias.to(DEV), epi=1, mode=mode, conv=(Hout, Wout))
+    report(f"conv mode{mode} {B}x{H}x{W_}x{Cin}->{Cout}", out.reshape(B, Hout, Wout, Cout), ref.permute(0, 2, 3, 1), **F32_OUT)
+
+
+# ----------------------------------------------------------------------------------------------- attention
+def _ref_attention(q, k, v, heads, fontsize=None):
+    """q [B,N,C], k,v [B,NK,C] fp32: the reference math (attention_processor.py:476-545, 359-407)."""
+    B, N, Cc = q.shape
+    d = Cc // heads
+
+    def h2b(t):
+        return t.reshape(B, -1, heads, d).permute(0, 2, 1, 3).reshape(B * heads, -1, d)
+    qh, kh, vh = h2b(q), h2b(k), h2b(v)
+    s = d ** -0.5 * torch.bmm(qh, kh.transpose(1, 2))
+    if fontsize is not None:
+        wp, fs = fontsize
+        e = (s - s.max(-1, True)[0]).exp()
+        e[:, :, wp] = e[:, :, wp] * fs.abs()
+        p = e / e.sum(-1, True)
+        p[:, :, wp] *= fs.sign()
+    else:
+        p = s.softmax(-1)
+    o = torch.bmm(p, vh)
+    return o.reshape(B, heads, N, d).permute(0, 2, 1, 3).reshape(B, N, Cc), p
+
+
+def _pack_heads(t, heads, d, DP, scale=1.0):
+    """[rows, heads*d] -> bf16 [rows, heads*DP] zero padded"""
+    rows = t.shape[0]
+    out = torch.zeros(rows, heads, DP)
+    out[:, :, :d] = t.reshape(rows, heads, d) * scale
+    return bf(out.reshape(rows, heads * DP))
+
+
+@pytest.mark.parametrize("B,H,N,d", [(2, 2, 256, 64), (1, 4, 128, 8), (2, 3, 320, 40), (1, 2, 64, 160), (1, 2, 192, 80),
+                                     (2, 10, 1024, 64)])
+def test_self_attention(B, H, N, d):
+    DP = 32 if d <= 32 else 64 if d <= 64 else 96 if d <= 96 else 160
+    q, k, v = rnd(B, N, H * d, seed=30), rnd(B, N, H * d, seed=31), rnd(B, N, H * d, seed=32)
+    qs = d ** -0.5 * math.log2(math.e)
+    Q = _pack_heads(q.reshape(B * N, -1), H, d, DP, qs)
+    K = _pack_heads(k.reshape(B * N, -1), H, d, DP)
+    V = _pack_heads(v.reshape(B * N, -1), H, d, DP)
+    VT = V.t().contiguous()                                     # [H*DP, B*N]
+    out = attention(Q, K, VT, B, H, N, N, DP)
+    qr = (Q.float() / qs).reshape(B, N, H, DP)[..., :d].reshape(B, N, H * d)
+    kr = K.float().reshape(B, N, H, DP)[..., :d].reshape(B, N, H * d)
+    vr = V.float().reshape(B, N, H, DP)[..., :d].reshape(B, N, H * d)
+    ref, _ = _ref_attention(qr, kr, vr, H)
+    got = out.float().reshape(B, N, H, DP)
+    assert float(got[..., d:].abs().max()) == 0.0 if DP > d else True
+    report(f"self_attn B{B} H{H} N{N} d{d}", got[..., :d].reshape(B, N, H * d), ref, atol=1.5e-2, rtol=1.5e-2)
+
+
+def test_self_attention_injection_equals_injected_probs():
+    """inject(P_ref) == attention with (Q_ref, K_ref, V_region)  (attention_processor.py:522-525)."""
+    B, H, N, d, DP = 3, 2, 256, 32, 32
+    q, k, v = rnd(B, N, H * d, seed=40), rnd(B, N, H * d, seed=41), rnd(B, N, H * d, seed=42)
+    qs = d ** -0.5 * math.log2(math.e)
+    Q, K, V = (_pack_heads(t.reshape(B * N, -1), H, d, DP, s) for t, s in ((q, qs), (k, 1.0), (v, 1.0)))
+    out = attention(Q, K, V.t().contiguous(), B, H, N, N, DP, q_src=[0, 0, 2], k_src=[0, 0, 2], v_src=[0, 1, 2])
+    qr, kr, vr = Q.float().reshape(B, N, -1) / qs, K.float().reshape(B, N, -1), V.float().reshape(B, N, -1)
+    _, p_ref = _ref_attention(qr[:1], kr[:1], vr[:1], H)                       # probabilities of stream 0
+    vh = vr[1:2].reshape(1, N, H, d).permute(0, 2, 1, 3).reshape(H, N, d)
+    inj = torch.bmm(p_ref, vh).reshape(1, H, N, d).permute(0, 2, 1, 3).reshape(N, H * d)
+    report("self_attn injected stream", out.float().reshape(B, N, -1)[1], inj, atol=1.5e-2, rtol=1.5e-2)
+    own, _ = _ref_attention(qr[2:], kr[2:], vr[2:], H)
+    report("self_attn untouched stream", out.float().reshape(B, N, -1)[2], own[0], atol=1.5e-2, rtol=1.5e-2)
+
+
+def test_online_softmax_rescale_branch_with_spiked_keys():
+    """Force the running-max rescale: one key per later tile dominates (guide 5.4 rule 26)."""
+    B, H, N, d, DP = 1, 1, 256, 64, 64
+    q, k, v = rnd(B, N, d, seed=43), rnd(B, N, d, seed=44), rnd(B, N, d, seed=45)
+    k[0, 70] = q[0, 5] * 6.0          # spike in tile 1 for query 5
+    k[0, 200] = q[0, 5] * 12.0        # bigger spike in tile 3
+    k[0, 130] = q[0, 77] * 9.0
+    qs = d ** -0.5 * math.log2(math.e)
+    Q, K, V = _pack_heads(q[0], H, d, DP, qs), _pack_heads(k[0], H, d, DP), _pack_heads(v[0], H, d, DP)
+    out = attention(Q, K, V.t().contiguous(), B, H, N, N, DP)
+    ref, _ = _ref_attention(Q.float()[None] / qs, K.float()[None], V.float()[None], H)
+    report("self_attn spiked", out.float()[None], ref, atol=2e-2, rtol=2e-2)
+
+
+@pytest.mark.parametrize("use_fs", [False, True])
+def test_cross_attention_fontsize(use_fs):
+    B, H, N, d, DP, P = 3, 2, 256, 32, 32, 2
+    q = rnd(B, N, H * d, seed=50)
+    kc, vc = rnd(P, 77, H * d, seed=51), rnd(P, 77, H * d, seed=52)
+    qs = d ** -0.5 * math.log2(math.e)
+    Q = _pack_heads(q.reshape(B * N, -1), H, d, DP, qs)
+    Kp = torch.zeros(P, 96, H * d); Kp[:, :77] = kc
+    Vp = torch.zeros(P, 96, H * d); Vp[:, :77] = vc
+    K = _pack_heads(Kp.reshape(P * 96, -1), H, d, DP)
+    V = _pack_heads(Vp.reshape(P * 96, -1), H, d, DP)
+    wp, fs = torch.tensor([2, 9, 30]), torch.tensor([3.0, -1.5, 0.25])
+    wabs = torch.zeros(2, 96); wabs[:, :77] = 1.0
+    wsgn = torch.ones(2, 96)
+    wabs[1, wp] = fs.abs(); wsgn[1, wp] = fs.sign()
+    prompt = [0, 1, 1]
+    wset = [0, 1 if use_fs else 0, 0]
+    out = attention(Q, K, V.t().contiguous(), B, H, N, 96, DP, q_src=[0, 1, 2], k_src=prompt, v_src=prompt, cross=True,
+                    wabs=wabs.to(DEV), wsgn=wsgn.to(DEV), wset=wset, nk_valid=77)
+    qr = Q.float().reshape(B, N, -1) / qs
+    kr = K.float().reshape(P, 96, -1)[:, :77]
+    vr = V.float().reshape(P, 96, -1)[:, :77]
+    for b in range(B):
+        ref, _ = _ref_attention(qr[b:b + 1], kr[prompt[b]][None], vr[prompt[b]][None], H, (wp, fs) if wset[b] else None)
+        report(f"cross_attn stream {b} fs={wset[b]}", out.float().reshape(B, N, -1)[b], ref[0], atol=1.5e-2, rtol=1.5e-2)
+
+
+def test_attention_against_reference_module_golden():
+    """tests/golden/attention_ops.pt was produced by the UNMODIFIED reference Attention module."""
+    import os
+    g = torch.load(os.path.join(os.path.dirname(__file__), "golden", "attention_ops.pt"))
+    H, d, DP = 2, 32, 32
+    qs = d ** -0.5 * math.log2(math.e)
+    x, ctx = g["x"], g["ctx"]
+    B, N, Cc = x.shape
+    sd = g["cross_sd"]
+    q = F.linear(x, sd["to_q.weight"]); k = F.linear(ctx, sd["to_k.weight"]); v = F.linear(ctx, sd["to_v.weight"])
+    Q = _pack_heads(q.reshape(B * N, -1), H, d, DP, qs)
+    Kp = torch.zeros(B, 96, H * d); Kp[:, :77] = k
+    Vp = torch.zeros(B, 96, H * d); Vp[:, :77] = v
+    K = _pack_heads(Kp.reshape(B * 96, -1), H, d, DP); V = _pack_heads(Vp.reshape(B * 96, -1), H, d, DP)
+    wabs = torch.zeros(2, 96); wabs[:, :77] = 1.0
+    wsgn = torch.ones(2, 96)
+    wabs[1, g["word_pos"]] = g["font_size"].abs(); wsgn[1, g["word_pos"]] = g["font_size"].sign()
+    for name, ws in (("y_plain", [0, 0]), ("y_fs", [1, 1])):
+        o = attention(Q, K, V.t().contiguous(), B, H, N, 96, DP, k_src=[0, 1], v_src=[0, 1], cross=True, wabs=wabs.to(DEV),
+                      wsgn=wsgn.to(DEV), wset=ws, nk_valid=77)
+        y = F.linear(o.float().cpu(), sd["to_out.0.weight"], sd["to_out.0.bias"]).reshape(B, N, Cc)
+        report(f"reference Attention module {name}", y, g[name], atol=3e-2, rtol=3e-2)
+    # self attention + injection
+    sd = g["self_sd"]
+    q, k, v = (F.linear(x, sd[f"to_{n}.weight"]) for n in "qkv")
+    v2 = F.linear(g["x2"], sd["to_v.weight"])
+    Q = _pack_heads(torch.cat([q, q]).reshape(2 * B * N, -1), H, d, DP, qs)
+    K = _pack_heads(torch.cat([k, k]).reshape(2 * B * N, -1), H, d, DP)
+    V = _pack_heads(torch.cat([v, v2]).reshape(2 * B * N, -1), H, d, DP)
+    o = attention(Q, K, V.t().contiguous(), 2 * B, H, N, N, DP, q_src=[0, 1, 0, 1], k_src=[0, 1, 0, 1], v_src=[0, 1, 2, 3])
+    y = F.linear(o.float().cpu(), sd["to_out.0.weight"], sd["to_out.0.bias"]).reshape(2 * B, N, Cc)
+    report("reference Attention module y_self", y[:B], g["y_self"], atol=3e-2, rtol=3e-2)
+    report("reference Attention module y_inj (real_attn_probs)", y[B:], g["y_inj"], atol=3e-2, rtol=3e-2)
+
+
+# ----------------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("B,HW,C1,C2,G,silu,bf16in", [(2, 256, 64, 0, 8, True, False), (3, 1024, 320, 0, 32, True, False),
+                                                      (2, 64, 1280, 640, 32, True, False), (2, 4096, 640, 320, 32, True, False),
+                                                      (2, 256, 320, 0, 32, False, False), (2, 1024, 96, 0, 8, True, True),
+                                                      (1, 16384, 320, 0, 32, True, False)])
+def test_groupnorm(B, HW, C1, C2, G, silu, bf16in):
+    x1 = rnd(B, HW, C1, seed=60) * 2 + 0.5
+    x2 = rnd(B, HW, C2, seed=61) - 0.3 if C2 else None
+    gamma, beta = (1 + 0.1 * rnd(C1 + C2, seed=62)).to(DEV), (0.1 * rnd(C1 + C2, seed=63)).to(DEV)
+    eps = 1e-5 if silu else 1e-6
+    if bf16in:
+        x1 = x1.to(torch.bfloat16)
+    xin1 = x1.to(DEV).contiguous()
+    xin2 = x2.to(DEV).contiguous() if C2 else None
+    out, raw = groupnorm(xin1, xin2, G, gamma, beta, eps, silu, want_raw=True)
+    xc = torch.cat([x1.float(), x2], -1) if C2 else x1.float()
+    ref = F.group_norm(xc.permute(0, 2, 1).to(DEV), G, gamma, beta, eps).permute(0, 2, 1)
+    if silu:
+        ref = F.silu(ref)
+    report(f"groupnorm B{B} HW{HW} C{C1}+{C2}", out, ref, **BF16_OUT)
+    report("groupnorm raw copy", raw, xc, atol=1e-2, rtol=8e-3)
+
+
+@pytest.mark.parametrize("rows,C", [(100, 64), (512, 640), (1024, 1280), (77, 320)])
+def test_layernorm(rows, C):
+    x = (rnd(rows, C, seed=70) * 3 + 1).to(DEV)
+    gamma, beta = (1 + 0.1 * rnd(C, seed=71)).to(DEV), (0.1 * rnd(C, seed=72)).to(DEV)
+    out = layernorm(x, gamma, beta)
+    report(f"layernorm {rows}x{C}", out, F.layer_norm(x, (C,), gamma, beta, 1e-5), **BF16_OUT)
+
+
+def test_small_linear_and_timestep_embedding():
+    B, K, N = 7, 320, 1280
+    a, W, bias = rnd(B, K, seed=80).to(DEV), bf(rnd(N, K, seed=81, scale=K ** -0.5)), rnd(N, seed=82).to(DEV)
+    report("small_linear", small_linear(a, W, bias), a @ W.float().t() + bias, atol=1e-4, rtol=1e-4)
+    report("small_linear silu", small_linear(a, W, bias, True), F.silu(a) @ W.float().t() + bias, atol=1e-4, rtol=1e-4)
+    from oracle.unet import timestep_embedding
+    t = torch.tensor([981.0, 1.0, 500.0, 1024.0, 0.0])
+    for dim in (320, 256, 32):
+        report(f"timestep_embed {dim}", timestep_embed(t.to(DEV), dim), timestep_embedding(t, dim), atol=2e-4, rtol=0)
