@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Headline benchmark: denoising steps/sec of the rich-text (region-diffusion) loop.
+
+Workload = BASELINE.json configs[2] ("SDXL RegionDiffusionXL 1024x1024, 4 regions, inject_selfattn=0.5,
+50 steps, 1xMI355X"), the configuration the metric is quoted on:
+  R = 4 masks (3 region prompts + base), F = R+3 = 7 UNet forwards per step (uncond, base with font-size
+  softmax, uncond_ref, text_ref, 3 region forwards with self-attention / ResNet-feature injection while
+  t > 500), CFG 5.0, 50-step Euler schedule, latents 128x128, SDXL-base architecture with random-init
+  weights and synthetic conditioning (no checkpoints offline).
+A "step" is one iteration of the loop at models/region_diffusion_sdxl.py:779 (all F forwards, mask combine,
+CFG, scheduler step).  Every forward the reference executes is executed (no dead-forward elision).
+
+  python bench.py --gpus N --steps K --warmup W
+N > 1: launched by torch.distributed.run, one rank per GPU; each rank runs an independent image (own seed,
+latents, masks, prompts) after ONE broadcast of the packed weight arena (RCCL); no per-step collectives;
+value = N*K / max-over-ranks time ("weak" scaling).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SDXL_FWD_GFLOP = 6761.2          # SURVEY.md section 8 [probe]: FLOPs of one batch-1 SDXL UNet forward at 128x128
+PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+
+
+def synth_inputs(seed, R, hw, device):
+    g = torch.Generator().manual_seed(seed)
+    emb = torch.randn(R + 1, 77, 2048, generator=g)
+    pooled = torch.randn(R + 1, 1280, generator=g)
+    tid = torch.tensor([[hw * 8.0, hw * 8.0, 0.0, 0.0, hw * 8.0, hw * 8.0]])
+    m = torch.softmax(torch.randn(R, 1, hw // 4, hw // 4, generator=g) * 4, dim=0)
+    m = torch.nn.functional.interpolate(m, size=(hw, hw), mode="bilinear", align_corners=False)
+    m = (m / (m.sum(0, keepdim=True) + 1e-8)).repeat(1, 4, 1, 1)
+    lat = torch.randn(1, 4, hw, hw, generator=g)
+    return dict(emb=emb.to(device), pooled=pooled.to(device), tid=tid, masks=m.to(device), lat=lat)
+
+
+def euler_tables(n):
+    """EulerDiscreteScheduler tables (restated diffusers 0.18.2, see oracle/schedulers.py) computed inline so the
+    product path does not import the oracle."""
+    import numpy as np
+    betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float32) ** 2
+    ac = torch.cumprod(1.0 - betas, 0)
+    train_sig = (((1 - ac) / ac) ** 0.5).numpy().astype("float64")
+    ts = (np.arange(0, n) * (1000 // n)).round()[::-1].copy().astype("float32") + 1
+    sig = np.concatenate([np.interp(ts, np.arange(0, 1000), train_sig), [0.0]]).astype("float32")
+    return ts.tolist(), sig.tolist(), float((sig.max() ** 2 + 1) ** 0.5)
+
+
+def cpu_baseline(sd_cpu, threads):
+    """Reference-equivalent CPU path: the fp32 oracle restatement of the reference UNet (oracle/unet.py, pinned
+    against the unmodified reference) timed on the host cores of this box.  Bounded sample: ONE batch-1 SDXL
+    UNet forward at 128x128 (the step is 7 such forwards + negligible elementwise work)."""
+    from oracle.unet import SDXL_CONFIG, OracleUNet
+    torch.set_num_threads(threads)
+    o = OracleUNet(SDXL_CONFIG, sd_cpu)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 4, 128, 128, generator=g)
+    ctx = torch.randn(1, 77, 2048, generator=g)
+    added = {"text_embeds": torch.randn(1, 1280, generator=g), "time_ids": torch.tensor([[1024.0, 1024, 0, 0, 1024, 1024]])}
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        o.forward(x, 801.0, ctx, added)
+        dt = time.perf_counter() - t0
+    return dict(value=1.0 / (7 * dt), unit="steps/s", cores=threads, kind="port",
+                sample=f"1 batch-1 SDXL UNet forward (fp32 oracle, {dt:.2f} s) x 7 forwards/step extrapolated",
+                forward_seconds=dt)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--elide", action="store_true", help="skip reference forwards that cannot influence the output")
+    args = ap.parse_args()
+
+    from rich_text_to_image_amd import launcher
+    from rich_text_to_image_amd.engine import Engine, SDXL_CONFIG
+    rank, local_rank, world = launcher.init_distributed()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+
+    R, hw, nsched, gs, isa, ibg = 4, 128, 50, 5.0, 0.5, 0.0
+    eng = Engine(SDXL_CONFIG, hw, hw, device=local_rank, max_streams=8, max_prompts=8)
+
+    # ---- weights: rank 0 draws + packs them, everyone else receives the packed bf16 arena (one broadcast)
+    sd_cpu = None
+    if rank == 0:
+        keep_cpu = (world == 1 or True) and not args.no_cpu_baseline
+        g = torch.Generator(device=dev).manual_seed(0)
+        sd_cpu = {} if keep_cpu else None
+        for name, shape in eng.weight_table():
+            if name.endswith(".weight") and len(shape) >= 2:
+                fan_in = 1
+                for s in shape[1:]:
+                    fan_in *= s
+                t = (torch.rand(shape, generator=g, device=dev) * 2 - 1) / math.sqrt(fan_in)
+            elif name.endswith(".weight"):
+                t = 1.0 + 0.1 * (torch.rand(shape, generator=g, device=dev) * 2 - 1)
+            else:
+                t = 0.05 * (torch.rand(shape, generator=g, device=dev) * 2 - 1)
+            eng.bind_weight(name, t)
+            if keep_cpu:
+                sd_cpu[name] = t.cpu()
+            eng.synchronize()
+            del t
+    bcast_s = launcher.broadcast_weights(eng, src=0)
+    assert eng.weights_missing()[0] == 0
+
+    # ---- per-rank independent request
+    inp = synth_inputs(1000 + rank, R, hw, dev)
+    ts, sig, init_sigma = euler_tables(nsched)
+    eng.set_prompts(inp["emb"], inp["pooled"], inp["tid"])
+    eng.set_masks(inp["masks"])
+    eng.set_fontsize(torch.tensor([5, 6]), torch.tensor([20.0, 20.0]))
+    lat0 = (inp["lat"] * init_sigma).to(dev)
+
+    def reset():
+        eng.set_schedule(0, ts, sig, nsched)
+        eng.set_latents(lat0)
+
+    def run(k):
+        for i in range(k):
+            eng.region_step(i % nsched, gs, isa, ibg, xl=True, elide=args.elide)
+
+    reset()
+    run(args.warmup)
+    eng.synchronize()
+    reset()
+    launcher.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.steps)
+    eng.synchronize()
+    torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0
+    launcher.barrier()
+    dt = launcher.max_over_ranks(dt_local, device=dev if world > 1 else "cpu")
+    final = eng.read_latents(hw, hw)
+    finite = bool(torch.isfinite(final).all())
+
+    # ---- roofline leg (outside the timed region): HIP events around every MFMA kernel launch on the engine
+    # stream for one injected step (i=0) and one non-injected step (i=nsched-1)
+    roof = None
+    prof = None
+    if rank == 0:
+        reset()
+        eng.profile_enable(True)
+        eng.region_step(0, gs, isa, ibg, xl=True, elide=False)
+        eng.region_step(nsched - 1, gs, isa, ibg, xl=True, elide=False)
+        prof = eng.profile_read()
+        eng.profile_enable(False)
+        dom = max(prof, key=lambda k: prof[k]["total_ms"])
+        p = prof[dom]
+        achieved = p["total_flops"] / (p["total_ms"] * 1e-3) / 1e12
+        roof = dict(bound="mfma", kernel=dom, achieved=achieved, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+                    frac=achieved / PEAK_BF16_TFLOPS, traffic=None, launches=p["launches"],
+                    avg_launch_us=p["total_ms"] * 1e3 / max(1, p["launches"]),
+                    flops_per_launch=p["total_flops"] / max(1, p["launches"]),
+                    per_kernel={k: dict(launches=v["launches"], total_ms=round(v["total_ms"], 3),
+                                        tflops=(v["total_flops"] / (v["total_ms"] * 1e-3) / 1e12) if v["total_ms"] > 0 else 0.0)
+                                for k, v in prof.items()})
+
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline and sd_cpu is not None:
+        threads = max(1, min(os.cpu_count() or 1, 256))
+        try:
+            phys = len({l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("core id")}) * \
+                len({l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("physical id")})
+            if phys > 0:
+                threads = min(threads, phys)
+        except Exception:
+            pass
+        cpu = cpu_baseline(sd_cpu, threads)
+
+    if rank == 0:
+        value = world * args.steps / dt
+        step_tflop = 7 * SDXL_FWD_GFLOP / 1e3
+        line = {
+            "metric": "denoising steps/sec (SDXL 1024^2, 50-step, 4 regions)",
+            "value": value, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "SDXL RegionDiffusionXL 1024x1024, R=4 regions, inject_selfattn=0.5, 50-step Euler, "
+                                   "CFG 5.0, 7 UNet forwards/step batched, random-init SDXL-base weights",
+                       "global_batch": world, "parallelism": f"seed-parallel x{world} (1 weight broadcast, no per-step collectives)",
+                       "elide_dead_forwards": bool(args.elide)},
+            "whole_step_tflops_per_gpu": step_tflop / (dt / args.steps),
+            "whole_step_mfma_frac": step_tflop / (dt / args.steps) / PEAK_BF16_TFLOPS,
+            "weight_broadcast_s": bcast_s, "finite": finite,
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -97,6 +97,13 @@ int rt_region_step(rt_engine* e, int step_index, float guidance_scale, float inj
 /* one iteration of the plain-text loop (rd.py:200-214 / xl.py:880-905): batch-2 forward, CFG, step */
 int rt_plain_step(rt_engine* e, int step_index, float guidance_scale);
 
+/* per-launch HIP-event timing of the MFMA kernels on the engine's stream (bench.py roofline leg).
+ * Algorithmic FLOPs are counted per launch (2*M*N*K for GEMM/conv, 4*B*H*N*NK*d for attention; padded
+ * head dims / keys are not counted). */
+enum { RT_PROF_GEMM_DENSE = 0, RT_PROF_GEMM_CONV = 1, RT_PROF_ATTN_SELF = 2, RT_PROF_ATTN_CROSS = 3 };
+int rt_profile_enable(rt_engine* e, int on);     /* on: start recording (clears old records); off: stop */
+int rt_profile_read(rt_engine* e, int kernel_class, int* count, double* total_ms, double* total_flops);
+
 /* operator level (parity tests, AttnProcessor / unet(...) seams; unet_2d_condition.py:703-717) ------------ */
 /* x [B,4,h,w] f32 NCHW; per-stream: input scale, prompt index, font-size flag, self-attention Q/K source
  * stream (== own index for normal attention), resnet-feature source stream or -1; out [B,4,h,w] f32 NCHW */

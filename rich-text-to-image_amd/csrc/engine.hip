@@ -168,6 +168,19 @@ struct rt_engine {
     int pndm_counter = 0, pndm_nets = 0, pndm_head = 0;
     int steps_done = 0;
 
+    // optional per-launch HIP-event profiling of the MFMA kernels (bench.py roofline leg)
+    struct ProfRec { int cls; double flops; hipEvent_t a, b; };
+    bool profiling = false;
+    std::vector<ProfRec> prof;
+    void prof_begin(int cls, double flops) {
+        if (!profiling) return;
+        ProfRec r; r.cls = cls; r.flops = flops;
+        HIP_CHECK(hipEventCreate(&r.a)); HIP_CHECK(hipEventCreate(&r.b));
+        HIP_CHECK(hipEventRecord(r.a, stream));
+        prof.push_back(r);
+    }
+    void prof_end() { if (profiling) HIP_CHECK(hipEventRecord(prof.back().b, stream)); }
+
     // ---------------------------------------------------------------------------- plan building
     void add_slot(const std::string& name, std::vector<int64_t> shape, const PackArgs& pk) {
         WeightSlot s; s.name = name; s.shape = std::move(shape); s.pack = pk;
@@ -350,14 +363,18 @@ struct rt_engine {
         GemmArgs g{}; g.A = A; g.W = W.w; g.bias = W.b; g.out = out; g.res = res; g.temb = temb; g.zero = zero;
         g.mode = A_DENSE; g.epi = epi; g.M = M; g.N = W.N; g.K = W.K; g.lda = lda; g.ldw = W.K; g.ldo = ldo;
         g.ldres = ldres; g.temb_ld = W.N; g.rows_per_batch = rows_per_batch;
+        prof_begin(RT_PROF_GEMM_DENSE, 2.0 * M * W.N * W.K);
         launch_gemm(g, stream);
+        prof_end();
     }
     // V^T = Wv [HD, K] x X[M, K]^T -> [HD, M]
     void gemm_vt(const MatW& Wv, const bf16_t* X, int ldx, int M, bf16_t* out, int ldo) {
         if (dry()) return;
         GemmArgs g{}; g.A = Wv.w; g.W = X; g.bias = nullptr; g.out = out; g.zero = zero;
         g.mode = A_DENSE; g.epi = EPI_BF16; g.M = Wv.N; g.N = M; g.K = Wv.K; g.lda = Wv.K; g.ldw = ldx; g.ldo = ldo;
+        prof_begin(RT_PROF_GEMM_DENSE, 2.0 * M * Wv.N * Wv.K);
         launch_gemm(g, stream);
+        prof_end();
     }
     void conv3(const bf16_t* in, int mode, const MatW& W, int B, int Hin, int Win, int CinP, void* out, int epi,
                const float* res = nullptr, const float* temb = nullptr) {
@@ -370,7 +387,9 @@ struct rt_engine {
         g.ldres = W.N; g.temb_ld = W.N; g.rows_per_batch = Hout * Wout;
         g.Hin = Hin; g.Win = Win; g.Cin = CinP; g.Hout = Hout; g.Wout = Wout;
         RT_REQUIRE(W.K == 9 * CinP, "conv: weight/input channel mismatch");
+        prof_begin(RT_PROF_GEMM_CONV, 2.0 * g.M * W.N * W.K);
         launch_gemm(g, stream);
+        prof_end();
     }
     void groupnorm(const void* x1, const void* x2, bool in_bf16, int C1, int C2, int B, int HW, const NormW& n, float eps_,
                    bool silu, bf16_t* out, bf16_t* raw) {
@@ -455,7 +474,9 @@ struct rt_engine {
                     AttnArgs a{}; a.Q = qk; a.ldq = 2 * HD; a.K = qk + HD; a.ldk = 2 * HD; a.VT = vt; a.ldvt = M; a.O = o; a.ldo = HD;
                     for (int b = 0; b < B; ++b) { a.q_src[b] = in.qk_src[b]; a.k_src[b] = in.qk_src[b]; a.v_src[b] = b; a.wset[b] = 0; }
                     a.B = B; a.H = t.heads; a.N = HW; a.NK = HW; a.nk_valid = HW; a.DP = t.DP; a.cross = 0;
+                    prof_begin(RT_PROF_ATTN_SELF, 4.0 * B * t.heads * (double)HW * HW * t.d);
                     launch_attention(a, stream);
+                    prof_end();
                 }
                 gemm(o, HD, k.out1, M, hcur, C, EPI_F32, hcur, C);
                 // --- attn2 (cross, K/V from the per-prompt cache; font-size softmax on flagged streams)
@@ -467,7 +488,9 @@ struct rt_engine {
                     for (int b = 0; b < B; ++b) { a.q_src[b] = b; a.k_src[b] = in.prompt[b]; a.v_src[b] = in.prompt[b]; a.wset[b] = in.fontsize[b] ? 1 : 0; }
                     a.wabs = wabs; a.wsgn = wsgn;
                     a.B = B; a.H = t.heads; a.N = HW; a.NK = 96; a.nk_valid = 77; a.DP = t.DP; a.cross = 1;
+                    prof_begin(RT_PROF_ATTN_CROSS, 4.0 * B * t.heads * (double)HW * 77 * t.d);
                     launch_attention(a, stream);
+                    prof_end();
                 }
                 gemm(o, HD, k.out2, M, hcur, C, EPI_F32, hcur, C);
                 // --- GEGLU feed-forward (attention.py:209-304)
@@ -643,8 +666,8 @@ struct rt_engine {
 
 // ================================================================================================
 // C ABI
-#define RT_TRY(e, body)                                                            \
-    try { body; return RT_OK; }                                                    \
+#define RT_TRY(e, ...)                                                             \
+    try { __VA_ARGS__; return RT_OK; }                                                    \
     catch (const rt_error& ex) { (e)->err = ex.what(); return ex.code; }           \
     catch (const std::exception& ex) { (e)->err = ex.what(); return RT_E_INVALID; }
 
@@ -706,7 +729,11 @@ int rt_create(const rt_config* cfg, int device, rt_engine** out) {
 
 int rt_destroy(rt_engine* e) {
     if (!e) return RT_OK;
-    if (e->arena_base) { hipSetDevice(e->device); hipStreamSynchronize(e->stream); hipFree(e->arena_base); hipFree(e->sarena_base); hipFree(e->ws.base); hipStreamDestroy(e->stream); }
+    if (e->arena_base) {
+        (void)hipSetDevice(e->device); (void)hipStreamSynchronize(e->stream);
+        for (auto& r : e->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+        (void)hipFree(e->arena_base); (void)hipFree(e->sarena_base); (void)hipFree(e->ws.base); (void)hipStreamDestroy(e->stream);
+    }
     delete e;
     return RT_OK;
 }
@@ -817,14 +844,35 @@ int rt_unet_forward(rt_engine* e, const float* x, int B, int h, int w, float t, 
     })
 }
 
+int rt_profile_enable(rt_engine* e, int on) {
+    RT_TRY(e, {
+        need_device(e);
+        for (auto& r : e->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+        e->prof.clear();
+        e->profiling = on != 0;
+    })
+}
+int rt_profile_read(rt_engine* e, int cls, int* count, double* total_ms, double* total_flops) {
+    RT_TRY(e, {
+        need_device(e);
+        HIP_CHECK(hipStreamSynchronize(e->stream));
+        int n = 0; double ms = 0, fl = 0;
+        for (auto& r : e->prof) if (r.cls == cls) {
+            float t = 0; HIP_CHECK(hipEventElapsedTime(&t, r.a, r.b));
+            ++n; ms += t; fl += r.flops;
+        }
+        *count = n; *total_ms = ms; *total_flops = fl;
+    })
+}
+
 // ---- operator-level entry points (stateless; share one lazily allocated zero page per device) ----
 static bf16_t* op_zero_page() {
     static thread_local bf16_t* z = nullptr;
     if (!z) { HIP_CHECK(hipMalloc((void**)&z, 256)); HIP_CHECK(hipMemset(z, 0, 256)); }
     return z;
 }
-#define OP_TRY(body)                                                         \
-    try { body; return RT_OK; }                                              \
+#define OP_TRY(...)                                                          \
+    try { __VA_ARGS__; return RT_OK; }                                              \
     catch (const rt_error& ex) { g_op_error = ex.what(); return ex.code; }   \
     catch (const std::exception& ex) { g_op_error = ex.what(); return RT_E_INVALID; }
 

@@ -65,7 +65,8 @@ _SYMBOLS = [
     "rt_weight_info", "rt_bind_weight", "rt_weights_missing", "rt_arena_info", "rt_arena_mark_bound",
     "rt_set_prompts", "rt_set_masks", "rt_set_fontsize", "rt_set_schedule", "rt_set_latents", "rt_get_latents",
     "rt_region_step", "rt_plain_step", "rt_unet_forward", "rt_op_gemm", "rt_op_attention", "rt_op_groupnorm",
-    "rt_op_layernorm", "rt_op_small_linear", "rt_op_timestep_embed", "rt_op_last_error",
+    "rt_op_layernorm", "rt_op_small_linear", "rt_op_timestep_embed", "rt_op_last_error", "rt_profile_enable",
+    "rt_profile_read",
 ]
 
 
@@ -265,10 +266,19 @@ class Engine:
         self._chk(self.lib.rt_set_latents(self.h, _ptr(l), l.shape[2], l.shape[3]))
         self.synchronize()
 
-    def get_latents(self, with_ref=False):
-        import torch
-        h, w = self._lat_shape
-        raise NotImplementedError
+    # ---- profiling (HIP events around every MFMA kernel launch on the engine stream)
+    PROF_CLASSES = {0: "gemm_kernel<A_DENSE>", 1: "gemm_kernel<A_CONV3*>", 2: "attn_kernel<self>", 3: "attn_kernel<cross>"}
+
+    def profile_enable(self, on=True):
+        self._chk(self.lib.rt_profile_enable(self.h, int(on)))
+
+    def profile_read(self):
+        out = {}
+        for cls, name in self.PROF_CLASSES.items():
+            n, ms, fl = C.c_int(), C.c_double(), C.c_double()
+            self._chk(self.lib.rt_profile_read(self.h, cls, C.byref(n), C.byref(ms), C.byref(fl)))
+            out[name] = dict(launches=n.value, total_ms=ms.value, total_flops=fl.value)
+        return out
 
     def read_latents(self, h, w, with_ref=False):
         import torch

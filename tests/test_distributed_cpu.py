@@ -1,0 +1,49 @@
+"""world_size-2 gloo test of the seed-parallel launcher (the N>1 path of bench.py without GPUs)."""
+import os
+import sys
+
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from rich_text_to_image_amd import launcher
+    r, lr, w = launcher.init_distributed("gloo")
+    assert (r, w) == (rank, world)
+    # "arena": rank 0 holds the packed weights, the others receive them in several chunks
+    arena = torch.arange(10_000, dtype=torch.uint8) if rank == 0 else torch.zeros(10_000, dtype=torch.uint8)
+    nchunks = launcher.broadcast_tensor(arena, src=0, chunk_bytes=4096)
+    ok_bcast = bool(torch.equal(arena, torch.arange(10_000, dtype=torch.uint8))) and nchunks == 3
+    mine = launcher.shard_round_robin(list(range(7)), rank, world)
+    tmax = launcher.max_over_ranks(1.0 + rank)
+    launcher.barrier()
+    q.put((rank, ok_bcast, mine, tmax))
+    torch.distributed.destroy_process_group()
+
+
+def test_seed_parallel_launcher_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] and res[1][1]                                 # broadcast delivered the arena
+    assert res[0][2] == [0, 2, 4, 6] and res[1][2] == [1, 3, 5]    # every request exactly once
+    assert res[0][3] == res[1][3] == 2.0                           # max over ranks
+
+
+def test_single_process_is_a_noop():
+    sys.path.insert(0, ROOT)
+    from rich_text_to_image_amd import launcher
+    assert launcher.shard_round_robin([1, 2, 3], 0, 1) == [1, 2, 3]
+    assert launcher.max_over_ranks(3.5) == 3.5
+    assert launcher.broadcast_tensor(torch.zeros(4, dtype=torch.uint8)) == 0

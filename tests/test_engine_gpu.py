@@ -5,8 +5,9 @@
 Tolerances: the engine multiplies bf16 operands with fp32 accumulation and keeps the residual trunk,
 normalisation statistics, softmax and scheduler state in fp32.  The reference itself measures rel-L2
 1.3e-2 between its own bf16 and fp32 UNet forward, which sets the scale:
-  single UNet forward   rel-L2 <= 2.5e-2
-  full rich-text loop   rel-L2 <= 6e-2 on the final latents (errors compound over steps and through CFG)
+  single UNet forward   rel-L2 <= 1.5e-2   (measured 7.6e-3 .. 8.2e-3 on MI355X, round 1)
+  full rich-text loop   rel-L2 <= 3e-2 on the final latents (measured 4.9e-3 .. 9.7e-3; errors compound over
+                        steps and through CFG)
 """
 import os
 
@@ -69,7 +70,7 @@ def test_unet_forward_matches_reference_golden(which, tiny_xl, tiny_sd):
     ref = g["reference_unet_t481"]
     r = rel_l2(out, ref)
     print(f"{which}: unet fwd vs reference golden rel-L2 {r:.3e} max|err| {(out.cpu() - ref).abs().max():.3e} ref rms {ref.pow(2).mean().sqrt():.3f}")
-    assert r < 2.5e-2
+    assert r < 1.5e-2
 
 
 @pytest.mark.parametrize("which", ["xl", "sd"])
@@ -110,7 +111,7 @@ def test_batched_forward_with_stream_modes_matches_oracle(which, tiny_xl, tiny_s
                            ("region injected", out[3], r3[0])):
         r = rel_l2(got, ref)
         print(f"{which} stream {name}: rel-L2 {r:.3e}")
-        assert r < 2.5e-2, name
+        assert r < 1.5e-2, name
     # the modes must actually change the result (guards against silently ignored mode words)
     plain = eng.unet_forward(x, t, [0, 2, 2, 1])
     assert rel_l2(plain[1], out[1]) > 1e-3 and rel_l2(plain[3], out[3]) > 1e-3
@@ -155,7 +156,7 @@ def test_rich_text_loop_matches_reference_golden(which, tiny_xl, tiny_sd):
     ref = g["reference_final_latents"]
     r = rel_l2(outs[False], ref)
     print(f"{which}: final latents vs reference loop rel-L2 {r:.3e} max|err| {(outs[False] - ref).abs().max():.3e} (ref std {ref.std():.3f})")
-    assert r < 6e-2
+    assert r < 3e-2
     # eliding reference forwards that can no longer influence the output must not change the result
     assert torch.equal(outs[False], outs[True]) or rel_l2(outs[True], outs[False]) < 1e-6
 

@@ -110,7 +110,7 @@ def _ref_attention(q, k, v, heads, fontsize=None):
     qh, kh, vh = h2b(q), h2b(k), h2b(v)
     s = d ** -0.5 * torch.bmm(qh, kh.transpose(1, 2))
     if fontsize is not None:
-        wp, fs = fontsize
+        wp, fs = fontsize[0].to(q.device), fontsize[1].to(q.device)
         e = (s - s.max(-1, True)[0]).exp()
         e[:, :, wp] = e[:, :, wp] * fs.abs()
         p = e / e.sum(-1, True)
