@@ -1,0 +1,128 @@
+"""Drop-in for `models/region_diffusion.py:RegionDiffusion` (SD-v1.5, PNDM/PLMS) with the denoising hot path
+on the HIP engine.  Same method names / argument meaning / attributes as the reference."""
+import torch
+
+from .engine import SD15_CONFIG
+from .schedulers import PNDMTables
+from .unet import HipUNet2DConditionModel
+
+
+class RegionDiffusion:
+    def __init__(self, device=0, unet_state_dict=None, config=None, vae=None, tokenizer=None, text_encoder=None):
+        """The reference downloads runwayml/stable-diffusion-v1-5 (rd.py:26-33); offline the caller passes the
+        UNet `state_dict` (reference key names) and, optionally, VAE / CLIP objects with the diffusers /
+        transformers call surface (`.decode(z).sample`, tokenizer(...), text_encoder(ids)[0])."""
+        self.device_index = device if isinstance(device, int) else (torch.device(device).index or 0)
+        self.device = torch.device(f"cuda:{self.device_index}")
+        self.num_train_timesteps = 1000
+        self.vae, self.tokenizer, self.text_encoder = vae, tokenizer, text_encoder
+        self.unet = HipUNet2DConditionModel(config or SD15_CONFIG, unet_state_dict, self.device_index)
+        self.scheduler = PNDMTables(self.num_train_timesteps)          # rd.py:35-36
+        self.alphas_cumprod = torch.tensor(self.scheduler.alphas_cumprod)
+        self.masks = []
+        self.attention_maps = None
+        self.selfattn_maps = None
+        self.crossattn_maps = None
+        self.n_maps = None
+        self.color_loss = torch.nn.functional.mse_loss
+
+    # rd.py:49-84
+    def get_text_embeds(self, prompt, negative_prompt):
+        if self.tokenizer is None or self.text_encoder is None:
+            raise RuntimeError("RegionDiffusion.get_text_embeds needs a CLIP tokenizer + text encoder (not available offline)")
+        ti = self.tokenizer(prompt, padding="max_length", max_length=self.tokenizer.model_max_length, truncation=True,
+                            return_tensors="pt")
+        with torch.no_grad():
+            te = self.text_encoder(ti.input_ids.to(self.device))[0]
+        ui = self.tokenizer(negative_prompt, padding="max_length", max_length=self.tokenizer.model_max_length, return_tensors="pt")
+        with torch.no_grad():
+            ue = self.text_encoder(ui.input_ids.to(self.device))[0]
+        return torch.cat([ue, te])
+
+    # rd.py:86-174
+    def produce_latents(self, text_embeddings, height=512, width=512, num_inference_steps=50, guidance_scale=7.5,
+                        latents=None, use_guidance=False, text_format_dict={}, inject_selfattn=0, inject_background=0,
+                        elide_dead_forwards=False):
+        if latents is None:
+            latents = torch.randn((1, self.unet.in_channels, height // 8, width // 8), device=self.device)
+        if use_guidance:
+            raise NotImplementedError("colour guidance (rd.py:151-168) needs the VAE decoder gradient: SURVEY 8a row a13, next round")
+        n_styles = text_embeddings.shape[0] - 1
+        assert n_styles == len(self.masks)                                  # rd.py:97
+        h, w = latents.shape[2], latents.shape[3]
+        eng = self.unet.engine(h, w)
+        self.scheduler.set_timesteps(num_inference_steps)
+        eng.set_prompts(text_embeddings.to(self.device))
+        eng.set_masks([m.to(self.device) for m in self.masks])
+        tfd = text_format_dict or {}
+        eng.set_fontsize(tfd.get("word_pos"), tfd.get("font_size"))
+        eng.set_schedule(1, self.scheduler.timesteps.tolist(), self.scheduler.table(), num_inference_steps)
+        eng.set_latents(latents.to(self.device))
+        for i in range(len(self.scheduler.timesteps)):
+            eng.region_step(i, guidance_scale, inject_selfattn, inject_background, xl=False, elide=elide_dead_forwards)
+        return eng.read_latents(h, w)
+
+    def predict_x0(self, x_t, eps_t, t):                                    # rd.py:176-178
+        a = self.alphas_cumprod[int(t)].to(x_t.device)
+        return (x_t - eps_t * torch.sqrt(1 - a)) / torch.sqrt(a)
+
+    # rd.py:180-225 (plain pass; attention-map capture = SURVEY 8a row a10, next)
+    def produce_attn_maps(self, prompts, negative_prompts='', height=512, width=512, num_inference_steps=50,
+                          guidance_scale=7.5, latents=None):
+        if isinstance(prompts, str):
+            prompts = [prompts]
+        if isinstance(negative_prompts, str):
+            negative_prompts = [negative_prompts]
+        emb = self.get_text_embeds(prompts, negative_prompts)
+        lat = self.plain_latents(emb, height, width, num_inference_steps, guidance_scale, latents)
+        return self.latents_to_uint8(lat)
+
+    def plain_latents(self, text_embeddings, height=512, width=512, num_inference_steps=50, guidance_scale=7.5, latents=None):
+        if latents is None:
+            latents = torch.randn((1, self.unet.in_channels, height // 8, width // 8), device=self.device)
+        h, w = latents.shape[2], latents.shape[3]
+        eng = self.unet.engine(h, w)
+        self.scheduler.set_timesteps(num_inference_steps)
+        eng.set_prompts(text_embeddings.to(self.device))
+        eng.set_schedule(1, self.scheduler.timesteps.tolist(), self.scheduler.table(), num_inference_steps)
+        eng.set_latents(latents.to(self.device))
+        for i in range(len(self.scheduler.timesteps)):
+            eng.plain_step(i, guidance_scale)
+        return eng.read_latents(h, w)
+
+    def decode_latents(self, latents):                                      # rd.py:227-236
+        if self.vae is None:
+            raise NotImplementedError("VAE decode is SURVEY 8f row f2 (next); pass a `vae` with .decode(z).sample")
+        latents = 1 / 0.18215 * latents
+        with torch.no_grad():
+            imgs = self.vae.decode(latents).sample
+        return (imgs / 2 + 0.5).clamp(0, 1)
+
+    def latents_to_uint8(self, latents):
+        imgs = self.decode_latents(latents)
+        imgs = imgs.detach().cpu().permute(0, 2, 3, 1).numpy()
+        return (imgs * 255).round().astype('uint8')
+
+    # rd.py:248-273
+    def prompt_to_img(self, prompts, negative_prompts='', height=512, width=512, num_inference_steps=50, guidance_scale=7.5,
+                      latents=None, text_format_dict={}, use_guidance=False, inject_selfattn=0, inject_background=0):
+        if isinstance(prompts, str):
+            prompts = [prompts]
+        if isinstance(negative_prompts, str):
+            negative_prompts = [negative_prompts]
+        text_embeds = self.get_text_embeds(prompts, negative_prompts)
+        latents = self.produce_latents(text_embeds, height=height, width=width, latents=latents,
+                                       num_inference_steps=num_inference_steps, guidance_scale=guidance_scale,
+                                       use_guidance=use_guidance, text_format_dict=text_format_dict,
+                                       inject_selfattn=inject_selfattn, inject_background=inject_background)
+        return self.latents_to_uint8(latents)
+
+    # hook surface of the reference (rd.py:397-443): token-map capture is the "next" row f1
+    def reset_attention_maps(self):
+        self.attention_maps = None
+
+    def register_tokenmap_hooks(self):
+        raise NotImplementedError("attention-map capture (rd.py:397-443) is SURVEY 8f row f1 (next)")
+
+    def remove_tokenmap_hooks(self):
+        self.selfattn_maps = self.crossattn_maps = self.n_maps = None

@@ -1,0 +1,113 @@
+"""Drop-in for `models/region_diffusion_sdxl.py:RegionDiffusionXL` (SDXL, Euler) with the denoising hot path on
+the HIP engine.  `sample()` keeps the reference's signature (xl.py:556-587)."""
+import types
+
+import torch
+
+from .engine import SDXL_CONFIG
+from .schedulers import EulerTables
+from .unet import HipUNet2DConditionModel
+
+
+class StableDiffusionXLPipelineOutput(dict):
+    def __init__(self, images):
+        super().__init__(images=images)
+        self.images = images
+
+
+class RegionDiffusionXL:
+    def __init__(self, load_path=None, device=0, unet_state_dict=None, config=None, vae=None, text_encoders=None,
+                 vae_scaling_factor=0.13025):
+        self.device_index = device if isinstance(device, int) else (torch.device(device).index or 0)
+        self.device = torch.device(f"cuda:{self.device_index}")
+        self.device_type = "cuda"
+        self.unet = HipUNet2DConditionModel(config or SDXL_CONFIG, unet_state_dict, self.device_index)
+        self.vae = vae
+        self.text_encoders = text_encoders
+        self.vae_scaling_factor = vae_scaling_factor
+        self.vae_scale_factor = 8
+        self.default_sample_size = 128
+        self.scheduler = EulerTables()
+        self.masks = []
+        self.selfattn_maps = self.crossattn_maps = self.n_maps = None
+
+    def check_inputs(self, prompt, height, width, prompt_embeds, pooled_prompt_embeds):          # xl.py:462-519
+        if height % 8 != 0 or width % 8 != 0:
+            raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+        if prompt is None and prompt_embeds is None:
+            raise ValueError("Provide either `prompt` or `prompt_embeds`. Cannot leave both `prompt` and `prompt_embeds` undefined.")
+        if prompt_embeds is not None and pooled_prompt_embeds is None:
+            raise ValueError("If `prompt_embeds` are provided, `pooled_prompt_embeds` also have to be passed.")
+
+    def _get_add_time_ids(self, original_size, crops_coords_top_left, target_size):                # xl.py:539-553
+        return torch.tensor([list(original_size + crops_coords_top_left + target_size)], dtype=torch.float32)
+
+    def encode_prompt(self, prompt, negative_prompt):
+        if self.text_encoders is None:
+            raise RuntimeError("RegionDiffusionXL needs CLIP text encoders for string prompts (not available offline); "
+                               "pass prompt_embeds / pooled_prompt_embeds instead")
+        return self.text_encoders(prompt, negative_prompt)
+
+    def sample(self, prompt=None, prompt_2=None, height=None, width=None, num_inference_steps=50, guidance_scale=5.0,
+               negative_prompt=None, negative_prompt_2=None, num_images_per_prompt=1, eta=0.0, generator=None,
+               latents=None, prompt_embeds=None, negative_prompt_embeds=None, pooled_prompt_embeds=None,
+               negative_pooled_prompt_embeds=None, output_type="pil", return_dict=True, callback=None, callback_steps=1,
+               cross_attention_kwargs=None, guidance_rescale=0.0, original_size=None, crops_coords_top_left=(0, 0),
+               target_size=None, use_guidance=False, inject_selfattn=0, inject_background=0, text_format_dict=None,
+               run_rich_text=False, elide_dead_forwards=False):
+        height = height or self.default_sample_size * self.vae_scale_factor
+        width = width or self.default_sample_size * self.vae_scale_factor
+        original_size = original_size or (height, width)
+        target_size = target_size or (height, width)
+        self.check_inputs(prompt, height, width, prompt_embeds, pooled_prompt_embeds)
+        if prompt_embeds is None:
+            prompt_embeds, negative_prompt_embeds, pooled_prompt_embeds, negative_pooled_prompt_embeds = \
+                self.encode_prompt(prompt, negative_prompt)
+        do_cfg = guidance_scale > 1.0
+        if run_rich_text and do_cfg and guidance_rescale > 0.0:
+            raise NotImplementedError                                                              # xl.py:827-830
+        if use_guidance:
+            raise NotImplementedError("colour guidance (xl.py:849-867) needs the VAE decoder gradient: SURVEY 8a row a13, next round")
+        self.scheduler.set_timesteps(num_inference_steps)
+        h, w = height // self.vae_scale_factor, width // self.vae_scale_factor
+        if latents is None:
+            latents = torch.randn((1, 4, h, w), generator=generator, device=self.device if generator is None else generator.device)
+        latents = latents.to(self.device).float() * self.scheduler.init_noise_sigma                # xl.py:533-536
+        add_time_ids = self._get_add_time_ids(tuple(original_size), tuple(crops_coords_top_left), tuple(target_size))
+        embeds = torch.cat([negative_prompt_embeds, prompt_embeds], 0).to(self.device).float()    # xl.py:760
+        pooled = torch.cat([negative_pooled_prompt_embeds, pooled_prompt_embeds], 0).to(self.device).float()
+        eng = self.unet.engine(h, w)
+        eng.set_prompts(embeds, pooled, add_time_ids)
+        eng.set_schedule(0, self.scheduler.timesteps.tolist(), self.scheduler.table(), num_inference_steps)
+        eng.set_latents(latents)
+        n = len(self.scheduler.timesteps)
+        if run_rich_text:
+            n_styles = embeds.shape[0] - 1
+            assert n_styles == len(self.masks), (n_styles, len(self.masks))
+            eng.set_masks([m.to(self.device) for m in self.masks])
+            tfd = text_format_dict or {}
+            eng.set_fontsize(tfd.get("word_pos"), tfd.get("font_size"))
+            for i in range(n):
+                eng.region_step(i, guidance_scale, inject_selfattn, inject_background, xl=True, elide=elide_dead_forwards)
+                if callback is not None and i % callback_steps == 0:
+                    callback(i, self.scheduler.timesteps[i], eng.read_latents(h, w))
+        else:
+            for i in range(n):
+                eng.plain_step(i, guidance_scale)
+        latents = eng.read_latents(h, w)
+        if output_type == "latent":
+            return StableDiffusionXLPipelineOutput(images=latents)
+        if self.vae is None:
+            raise NotImplementedError("VAE decode is SURVEY 8f row f2 (next); pass a `vae` with .decode(z) or use output_type='latent'")
+        image = self.vae.decode(latents / self.vae_scaling_factor)
+        return StableDiffusionXLPipelineOutput(images=image)
+
+    def predict_x0(self, x_t, eps_t, t):                                                           # xl.py:955-957
+        a = torch.tensor(self.scheduler.alphas_cumprod)[int(t)].to(x_t.device)
+        return (x_t - eps_t * torch.sqrt(1 - a)) / torch.sqrt(a)
+
+    def register_tokenmap_hooks(self):
+        raise NotImplementedError("attention-map capture (xl.py:959-1016) is SURVEY 8f row f1 (next)")
+
+    def remove_tokenmap_hooks(self):
+        self.selfattn_maps = self.crossattn_maps = self.n_maps = None

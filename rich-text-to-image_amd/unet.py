@@ -1,0 +1,48 @@
+"""`unet(sample, t, encoder_hidden_states, added_cond_kwargs)['sample']` seam
+(models/unet_2d_condition.py:703-717) backed by the HIP engine."""
+import types
+
+import torch
+
+from .engine import Engine
+
+
+class HipUNet2DConditionModel:
+    """Holds the engine(s) for one set of weights; engines are created lazily per latent size."""
+
+    def __init__(self, config, state_dict=None, device=0, max_streams=8, max_prompts=8):
+        self.config_dict = dict(config)
+        self.config = types.SimpleNamespace(**config)
+        self.in_channels = config["in_channels"]
+        self.device_index = device
+        self.max_streams, self.max_prompts = max_streams, max_prompts
+        self._state_dict = state_dict
+        self._engines = {}
+
+    def load_state_dict(self, sd):
+        self._state_dict = sd
+        for e in self._engines.values():
+            e.load_state_dict(sd)
+
+    def engine(self, h, w):
+        key = (h, w)
+        if key not in self._engines:
+            e = Engine(self.config_dict, h, w, device=self.device_index, max_streams=self.max_streams,
+                       max_prompts=self.max_prompts)
+            if self._state_dict is None:
+                raise RuntimeError("HipUNet2DConditionModel: no weights loaded (call load_state_dict)")
+            e.load_state_dict(self._state_dict)
+            self._engines[key] = e
+        return self._engines[key]
+
+    def __call__(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None, **kw):
+        """Batch of independent samples; every sample uses its own row of `encoder_hidden_states`."""
+        B, _, h, w = sample.shape
+        eng = self.engine(h, w)
+        pooled = tid = None
+        if added_cond_kwargs is not None:
+            pooled, tid = added_cond_kwargs["text_embeds"], added_cond_kwargs["time_ids"][:1]
+        eng.set_prompts(encoder_hidden_states, pooled, tid)
+        eng.set_fontsize(None, None)
+        out = eng.unet_forward(sample, float(timestep), list(range(B)))
+        return {"sample": out}
