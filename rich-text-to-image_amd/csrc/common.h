@@ -73,8 +73,11 @@ struct GemmArgs {
     int lda, ldw, ldo, ldres, temb_ld;
     int rows_per_batch;              // Hout*Wout (conv and temb)
     int Hin, Win, Cin, Hout, Wout;   // conv geometry (Cin padded to a multiple of 8; K = 9*Cin)
+    int debug;                       // ablation probes only (tools/overhead_probe.py): 1 = no DMA in the k loop, 2 = no MFMA
 };
 void launch_gemm(const GemmArgs& a, hipStream_t st);
+void gemm_force_config(int cfg);
+void gemm_set_debug(int d);   // -1 auto-tune, 0..3 fixed tile configuration
 
 // ---------------------------------------------------------------- attention
 #define RT_MAXB 16

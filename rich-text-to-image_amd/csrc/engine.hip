@@ -877,6 +877,12 @@ static bf16_t* op_zero_page() {
     catch (const std::exception& ex) { g_op_error = ex.what(); return RT_E_INVALID; }
 
 const char* rt_op_last_error(void) { return g_op_error.c_str(); }
+int rt_op_gemm_debug(int d) { gemm_set_debug(d); return RT_OK; }
+int rt_op_gemm_force_config(int cfg) {
+    if (cfg < -1 || cfg > 5) return RT_E_INVALID;
+    gemm_force_config(cfg);
+    return RT_OK;
+}
 
 int rt_op_gemm(const void* A, const void* W, const float* bias, void* out, const float* res, const float* temb, int mode,
                int epi, int M, int N, int K, int lda, int ldw, int ldo, int ldres, int temb_ld, int rows_per_batch, int Hin,

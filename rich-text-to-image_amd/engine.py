@@ -66,7 +66,7 @@ _SYMBOLS = [
     "rt_set_prompts", "rt_set_masks", "rt_set_fontsize", "rt_set_schedule", "rt_set_latents", "rt_get_latents",
     "rt_region_step", "rt_plain_step", "rt_unet_forward", "rt_op_gemm", "rt_op_attention", "rt_op_groupnorm",
     "rt_op_layernorm", "rt_op_small_linear", "rt_op_timestep_embed", "rt_op_last_error", "rt_profile_enable",
-    "rt_profile_read",
+    "rt_profile_read", "rt_op_gemm_force_config", "rt_op_gemm_debug",
 ]
 
 

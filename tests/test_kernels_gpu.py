@@ -76,6 +76,44 @@ def test_gemm_temb_epilogue():
     report("gemm_temb", out, ref.reshape(B * HW, N), **BF16_OUT)
 
 
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
+def test_gemm_tile_configurations_are_bit_identical(cfg):
+    """Every tile configuration (incl. the 3-stage counted-vmcnt ring) must give the same bits as cfg 0."""
+    from rich_text_to_image_amd.engine import load_library
+    lib = load_library()
+    try:
+        for (M, N, K) in [(512, 512, 128), (7168, 1280, 1280), (1000, 200, 328), (300, 1280, 64), (2048, 640, 2560), (256, 160, 192), (512, 320, 128), (7168, 1280, 5120)]:
+            A, W = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=K ** -0.5))
+            bias, res = rnd(N, seed=3).to(DEV), rnd(M, N, seed=4).to(DEV)
+            lib.rt_op_gemm_force_config(0)
+            ref = gemm(A, W, bias, epi=1, res=res)
+            lib.rt_op_gemm_force_config(cfg)
+            for rep in range(3):                      # repeated launches: races show up as run-to-run differences
+                out = gemm(A, W, bias, epi=1, res=res)
+                assert torch.equal(out, ref), f"cfg {cfg} differs from cfg 0 at {M}x{N}x{K} (rep {rep}): max {(out - ref).abs().max().item()}"
+            report(f"gemm cfg{cfg} {M}x{N}x{K}", out, A.float() @ W.float().t() + bias + res, **F32_OUT)
+        # conv + geglu through every configuration
+        x = rnd(2, 64, 32, 32, seed=20); w = rnd(96, 64, 3, 3, seed=21, scale=(9 * 64) ** -0.5)
+        ref = F.conv2d(x.to(torch.bfloat16).float(), w.to(torch.bfloat16).float(), None, padding=1)
+        out = gemm(bf(x.permute(0, 2, 3, 1)), bf(_conv_weight_packed(w)), None, epi=1, mode=1, conv=(32, 32))
+        report(f"conv cfg{cfg}", out.reshape(2, 32, 32, 96), ref.permute(0, 2, 3, 1), **F32_OUT)
+    finally:
+        lib.rt_op_gemm_force_config(-1)
+
+
+def test_gemm_autotune_keeps_inplace_residual_intact():
+    M, N, K = 2048, 1280, 640
+    A, W = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=K ** -0.5))
+    h0 = rnd(M, N, seed=4).to(DEV)
+    h = h0.clone()
+    from rich_text_to_image_amd.engine import load_library, _ptr
+    lib = load_library()
+    rc = lib.rt_op_gemm(_ptr(A), _ptr(W), None, _ptr(h), _ptr(h), None, 0, 1, M, N, K, K, K, N, N, 0, 0, 0, 0, 0, 0, 0, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    report("in-place residual through autotune", h, A.float() @ W.float().t() + h0, **F32_OUT)
+
+
 def _conv_weight_packed(w):          # [Cout, Cin, 3, 3] -> [Cout, 9*Cin], K = tap*Cin + c
     return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
 
