@@ -34,88 +34,79 @@
 
 #define BK 64
 
-// ---- epilogue (shared by both main-loop variants).  With swapped operands the 32x32 accumulator tile is
-//      D[n][m]: m = lane&31 (row of C), n = (r&3) + 8*(r>>2) + 4*(lane>>5) (column of C): 4 consecutive columns
-//      per register quad, so the lane moves 16-B / 8-B vectors.
-template <int TM, int TN>
+// ---- epilogue (shared by both main-loop variants), specialised at compile time on the epilogue kind so each
+//      kernel carries only its own store code (a 4-way runtime switch over fully unrolled stores made the
+//      epilogue 85 % of the kernel's instructions and every launch paid for the instruction-cache misses).
+//      With swapped operands the 32x32 accumulator tile is D[n][m]: m = lane&31 (row of C),
+//      n = (r&3) + 8*(r>>2) + 4*(lane>>5) (column of C): 4 consecutive columns per register quad, so the lane
+//      moves 16-B / 8-B vectors.  N % 4 == 0 is required (checked by the launcher).
+template <int EPI, int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[TM][TN], int wrow0, int wcol0, int l31, int hi) {
-    if (p.epi == EPI_GEGLU) {
-        if constexpr (TN % 2 == 0) {
-            // packed weight rows: per 64-column block [32 value | 32 gate] (engine: PACK_ROWS_GEGLU)
-            bf16_t* out = (bf16_t*)p.out;
+    if constexpr (EPI == EPI_GEGLU) {
+        static_assert(TN % 2 == 0, "GEGLU needs value/gate tile pairs in one wave");
+        // packed weight rows: per 64-column block [32 value | 32 gate] (engine: PACK_ROWS_GEGLU)
+        bf16_t* out = (bf16_t*)p.out;
 #pragma unroll
-            for (int j = 0; j < TN; j += 2) {
-                const int cb = wcol0 + j * 32;                  // first value column of this 64-block
-                if (cb + 64 > p.N) continue;
+        for (int j = 0; j < TN; j += 2) {
+            const int cb = wcol0 + j * 32;                  // first value column of this 64-block
+            if (cb + 64 > p.N) continue;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int nl = 8 * g + 4 * hi;
-                    float bv[4] = {0, 0, 0, 0}, bg[4] = {0, 0, 0, 0};
-                    if (p.bias) {
-                        const float4 t0 = *(const float4*)(p.bias + cb + nl), t1 = *(const float4*)(p.bias + cb + 32 + nl);
-                        bv[0] = t0.x; bv[1] = t0.y; bv[2] = t0.z; bv[3] = t0.w; bg[0] = t1.x; bg[1] = t1.y; bg[2] = t1.z; bg[3] = t1.w;
+            for (int g = 0; g < 4; ++g) {
+                const int nl = 8 * g + 4 * hi;
+                float bv[4] = {0, 0, 0, 0}, bg[4] = {0, 0, 0, 0};
+                if (p.bias) {
+                    const float4 t0 = *(const float4*)(p.bias + cb + nl), t1 = *(const float4*)(p.bias + cb + 32 + nl);
+                    bv[0] = t0.x; bv[1] = t0.y; bv[2] = t0.z; bv[3] = t0.w; bg[0] = t1.x; bg[1] = t1.y; bg[2] = t1.z; bg[3] = t1.w;
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int row = wrow0 + i * 32 + l31;
+                    if (row >= p.M) continue;
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = acc[i][j][4 * g + e] + bv[e], gt = acc[i][j + 1][4 * g + e] + bg[e];
+                        o[e] = v * (0.5f * gt * (1.f + erff(gt * 0.70710678118654752440f)));
                     }
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) {
-                        const int row = wrow0 + i * 32 + l31;
-                        if (row >= p.M) continue;
-                        float o[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float v = acc[i][j][4 * g + e] + bv[e], gt = acc[i][j + 1][4 * g + e] + bg[e];
-                            o[e] = v * (0.5f * gt * (1.f + erff(gt * 0.70710678118654752440f)));
-                        }
-                        uint2 w; w.x = pack_bf16x2(o[0], o[1]); w.y = pack_bf16x2(o[2], o[3]);
-                        *(uint2*)(out + (size_t)row * p.ldo + (cb >> 1) + nl) = w;
-                    }
+                    uint2 w; w.x = pack_bf16x2(o[0], o[1]); w.y = pack_bf16x2(o[2], o[3]);
+                    *(uint2*)(out + (size_t)row * p.ldo + (cb >> 1) + nl) = w;
                 }
             }
         }
-        return;
-    }
+    } else {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
+        for (int j = 0; j < TN; ++j) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int col = wcol0 + j * 32 + 8 * g + 4 * hi;
-            if (col >= p.N) continue;
-            const bool full = col + 4 <= p.N;
-            float bv[4] = {0, 0, 0, 0};
-            if (p.bias) {
-                if (full) { const float4 t = *(const float4*)(p.bias + col); bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w; }
-                else for (int e = 0; e < 4; ++e) if (col + e < p.N) bv[e] = p.bias[col + e];
-            }
+            for (int g = 0; g < 4; ++g) {
+                const int col = wcol0 + j * 32 + 8 * g + 4 * hi;
+                if (col >= p.N) continue;
+                float bv[4] = {0, 0, 0, 0};
+                if (p.bias) { const float4 t = *(const float4*)(p.bias + col); bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w; }
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row = wrow0 + i * 32 + l31;
-                if (row >= p.M) continue;
-                float v[4];
+                for (int i = 0; i < TM; ++i) {
+                    const int row = wrow0 + i * 32 + l31;
+                    if (row >= p.M) continue;
+                    float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + bv[e];
-                if (p.epi == EPI_BF16_TEMB) {
-                    const float* tp = p.temb + (size_t)(row / p.rows_per_batch) * p.temb_ld + col;
-                    if (full) { const float4 t = *(const float4*)tp; v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
-                    else for (int e = 0; e < 4; ++e) if (col + e < p.N) v[e] += tp[e];
-                }
-                if (p.epi == EPI_F32) {
-                    float* op = (float*)p.out + (size_t)row * p.ldo + col;
-                    if (full) {
-                        if (p.res) { const float4 t = *(const float4*)(p.res + (size_t)row * p.ldres + col); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
-                        *(float4*)op = make_float4(v[0], v[1], v[2], v[3]);
-                    } else {
-                        for (int e = 0; e < 4; ++e) if (col + e < p.N) op[e] = v[e] + (p.res ? p.res[(size_t)row * p.ldres + col + e] : 0.f);
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + bv[e];
+                    if constexpr (EPI == EPI_BF16_TEMB) {
+                        const float4 t = *(const float4*)(p.temb + (size_t)(row / p.rows_per_batch) * p.temb_ld + col);
+                        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
                     }
-                } else {
-                    bf16_t* op = (bf16_t*)p.out + (size_t)row * p.ldo + col;
-                    if (full) { uint2 w; w.x = pack_bf16x2(v[0], v[1]); w.y = pack_bf16x2(v[2], v[3]); *(uint2*)op = w; }
-                    else for (int e = 0; e < 4; ++e) if (col + e < p.N) op[e] = f32_to_bf16(v[e]);
+                    if constexpr (EPI == EPI_F32) {
+                        if (p.res) { const float4 t = *(const float4*)(p.res + (size_t)row * p.ldres + col); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+                        *(float4*)((float*)p.out + (size_t)row * p.ldo + col) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+                        uint2 w; w.x = pack_bf16x2(v[0], v[1]); w.y = pack_bf16x2(v[2], v[3]);
+                        *(uint2*)((bf16_t*)p.out + (size_t)row * p.ldo + col) = w;
+                    }
                 }
             }
         }
     }
 }
 
-template <int MODE, int BM, int BN, int WM, int WN, int S>
+template <int MODE, int EPI, int BM, int BN, int WM, int WN, int S>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = WM * WN;                    // waves
@@ -291,7 +282,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     for (; kt + S - 1 < nk; ++kt) ktile(kt, std::true_type{}, std::false_type{});
     for (; kt + 1 < nk; ++kt) ktile(kt, std::false_type{}, std::false_type{});
     for (; kt < nk; ++kt) ktile(kt, std::false_type{}, std::true_type{});
-    gemm_epilogue<TM, TN>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), l31, hi);
+    gemm_epilogue<EPI, TM, TN>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), l31, hi);
 }
 
 // ================================================================================================
@@ -306,7 +297,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
 //   compute kt:                                                                     s_barrier ; compute(kt)
 // Ring safety: stage(kt+2) overwrites slot (kt-1)%3, whose last readers (compute(kt-1)) all arrived at
 // barrier kt after their MFMAs consumed the fragments.
-template <int MODE, int BM, int BN, int WM, int WN, int NL>
+template <int MODE, int EPI, int BM, int BN, int WM, int WN, int NL>
 __global__ __launch_bounds__((WM * WN + NL) * 64) void gemm_ws_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NWC = WM * WN;
@@ -435,7 +426,7 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void gemm_ws_kernel(GemmArgs p
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    gemm_epilogue<TM, TN>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), l31, hi);
+    gemm_epilogue<EPI, TM, TN>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), l31, hi);
 }
 
 // ---------------------------------------------------------------------------------------------- launch
@@ -444,52 +435,66 @@ struct TileCfg { int BM, BN, threads, stages, geglu_ok; };
 static const TileCfg kCfg[RT_NCFG] = {{128, 128, 256, 2, 1}, {256, 128, 512, 3, 1}, {256, 160, 512, 3, 0}, {256, 256, 1024, 2, 1},
                                        {256, 160, 768, 3, 0}, {256, 128, 768, 3, 1}};
 
-template <int MODE, int BM, int BN, int WM, int WN, int S>
+template <int MODE, int EPI, int BM, int BN, int WM, int WN, int S>
 static void launch_cfg(const GemmArgs& a, hipStream_t st) {
-    const size_t lds = (size_t)S * (BM + BN) * BK * 2;
-    static bool attr = false;
-    if (!attr) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)gemm_kernel<MODE, BM, BN, WM, WN, S>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
+    if constexpr (EPI == EPI_GEGLU && (BN / WN / 32) % 2 != 0) {
+        throw rt_error(RT_E_INVALID, "gemm: this tile configuration cannot run the GEGLU epilogue");
+    } else {
+        const size_t lds = (size_t)S * (BM + BN) * BK * 2;
+        static bool attr = false;
+        if (!attr) {
+            HIP_CHECK(hipFuncSetAttribute((const void*)gemm_kernel<MODE, EPI, BM, BN, WM, WN, S>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr = true;
+        }
+        dim3 grid(cdiv(a.M, BM) * cdiv(a.N, BN)), block(WM * WN * 64);
+        hipLaunchKernelGGL((gemm_kernel<MODE, EPI, BM, BN, WM, WN, S>), grid, block, lds, st, a);
     }
-    dim3 grid(cdiv(a.M, BM) * cdiv(a.N, BN)), block(WM * WN * 64);
-    hipLaunchKernelGGL((gemm_kernel<MODE, BM, BN, WM, WN, S>), grid, block, lds, st, a);
 }
 
-template <int MODE, int BM, int BN, int WM, int WN, int NL>
+template <int MODE, int EPI, int BM, int BN, int WM, int WN, int NL>
 static void launch_ws(const GemmArgs& a, hipStream_t st) {
-    const size_t lds = (size_t)3 * (BM + BN) * BK * 2;
-    static bool attr = false;
-    if (!attr) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)gemm_ws_kernel<MODE, BM, BN, WM, WN, NL>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
+    if constexpr (EPI == EPI_GEGLU && (BN / WN / 32) % 2 != 0) {
+        throw rt_error(RT_E_INVALID, "gemm: this tile configuration cannot run the GEGLU epilogue");
+    } else {
+        const size_t lds = (size_t)3 * (BM + BN) * BK * 2;
+        static bool attr = false;
+        if (!attr) {
+            HIP_CHECK(hipFuncSetAttribute((const void*)gemm_ws_kernel<MODE, EPI, BM, BN, WM, WN, NL>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr = true;
+        }
+        dim3 grid(cdiv(a.M, BM) * cdiv(a.N, BN)), block((WM * WN + NL) * 64);
+        hipLaunchKernelGGL((gemm_ws_kernel<MODE, EPI, BM, BN, WM, WN, NL>), grid, block, lds, st, a);
     }
-    dim3 grid(cdiv(a.M, BM) * cdiv(a.N, BN)), block((WM * WN + NL) * 64);
-    hipLaunchKernelGGL((gemm_ws_kernel<MODE, BM, BN, WM, WN, NL>), grid, block, lds, st, a);
 }
 
-template <int MODE>
-static void launch_mode(const GemmArgs& a, int cfg, hipStream_t st) {
+template <int MODE, int EPI>
+static void launch_me(const GemmArgs& a, int cfg, hipStream_t st) {
     switch (cfg) {
-        case 0: launch_cfg<MODE, 128, 128, 2, 2, 2>(a, st); break;
-        case 1: launch_cfg<MODE, 256, 128, 4, 2, 3>(a, st); break;
-        case 2: launch_cfg<MODE, 256, 160, 8, 1, 3>(a, st); break;
-        case 3: launch_cfg<MODE, 256, 256, 4, 4, 2>(a, st); break;
-        case 4: launch_ws<MODE, 256, 160, 8, 1, 4>(a, st); break;
-        case 5: launch_ws<MODE, 256, 128, 4, 2, 4>(a, st); break;
+        case 0: launch_cfg<MODE, EPI, 128, 128, 2, 2, 2>(a, st); break;
+        case 1: launch_cfg<MODE, EPI, 256, 128, 4, 2, 3>(a, st); break;
+        case 2: launch_cfg<MODE, EPI, 256, 160, 8, 1, 3>(a, st); break;
+        case 3: launch_cfg<MODE, EPI, 256, 256, 4, 4, 2>(a, st); break;
+        case 4: launch_ws<MODE, EPI, 256, 160, 8, 1, 4>(a, st); break;
+        case 5: launch_ws<MODE, EPI, 256, 128, 4, 2, 4>(a, st); break;
         default: throw rt_error(RT_E_INVALID, "gemm: bad tile configuration");
     }
 }
 
+// (A operand mode, epilogue) combinations that exist on the hot path; anything else is rejected loudly.
 static void launch_with_cfg(const GemmArgs& a, int cfg, hipStream_t st) {
-    switch (a.mode) {
-        case A_DENSE: launch_mode<A_DENSE>(a, cfg, st); break;
-        case A_CONV3: launch_mode<A_CONV3>(a, cfg, st); break;
-        case A_CONV3_S2: launch_mode<A_CONV3_S2>(a, cfg, st); break;
-        case A_CONV3_UP2: launch_mode<A_CONV3_UP2>(a, cfg, st); break;
-        default: throw rt_error(RT_E_INVALID, "gemm: bad mode");
+    const int key = a.mode * 4 + a.epi;
+    switch (key) {
+        case A_DENSE * 4 + EPI_BF16: launch_me<A_DENSE, EPI_BF16>(a, cfg, st); break;
+        case A_DENSE * 4 + EPI_F32: launch_me<A_DENSE, EPI_F32>(a, cfg, st); break;
+        case A_DENSE * 4 + EPI_BF16_TEMB: launch_me<A_DENSE, EPI_BF16_TEMB>(a, cfg, st); break;
+        case A_DENSE * 4 + EPI_GEGLU: launch_me<A_DENSE, EPI_GEGLU>(a, cfg, st); break;
+        case A_CONV3 * 4 + EPI_F32: launch_me<A_CONV3, EPI_F32>(a, cfg, st); break;
+        case A_CONV3 * 4 + EPI_BF16_TEMB: launch_me<A_CONV3, EPI_BF16_TEMB>(a, cfg, st); break;
+        case A_CONV3_S2 * 4 + EPI_F32: launch_me<A_CONV3_S2, EPI_F32>(a, cfg, st); break;
+        case A_CONV3_UP2 * 4 + EPI_F32: launch_me<A_CONV3_UP2, EPI_F32>(a, cfg, st); break;
+        default: throw rt_error(RT_E_UNSUPPORTED, "gemm: (operand mode, epilogue) combination not built");
     }
     HIP_CHECK(hipGetLastError());
 }
@@ -557,6 +562,7 @@ void launch_gemm(const GemmArgs& a, hipStream_t st) {
         RT_REQUIRE((long)(a.M / a.rows_per_batch + 1) * a.Hin * a.Win * a.Cin < (1L << 31), "conv: input too large for 32-bit offsets");
     }
     if (a.epi == EPI_GEGLU) RT_REQUIRE(a.N % 64 == 0, "geglu: N must be a multiple of 64");
+    RT_REQUIRE(a.N % 4 == 0, "gemm: N must be a multiple of 4");
     RT_REQUIRE(a.ldo % 4 == 0 && ((uintptr_t)a.out & 15) == 0, "gemm: output must be 16-B aligned with ldo % 4 == 0");
     if (a.res) RT_REQUIRE(a.ldres % 4 == 0 && ((uintptr_t)a.res & 15) == 0, "gemm: residual must be 16-B aligned");
     if (a.bias) RT_REQUIRE(((uintptr_t)a.bias & 15) == 0, "gemm: bias must be 16-B aligned");

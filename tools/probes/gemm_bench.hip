@@ -3,7 +3,7 @@
 #include <vector>
 #include <algorithm>
 int main(int argc, char** argv) {
-    struct Shape { int M, N, K; } shapes[] = {{7168, 1280, 1280}, {7168, 1280, 5120}, {7168, 10240, 1280}, {7168, 2560, 1280}, {28672, 640, 2560}, {8192, 8192, 8192}};
+    struct Shape { int M, N, K; } shapes[] = {{256, 160, 64}, {7168, 1280, 64}, {7168, 1280, 128}, {7168, 1280, 320}, {7168, 1280, 640}, {7168, 1280, 1280}, {7168, 1280, 5120}, {7168, 10240, 1280}, {7168, 2560, 1280}, {28672, 640, 2560}, {8192, 8192, 8192}};
     bf16_t *A, *W, *out, *zero;
     hipMalloc(&A, (size_t)28672 * 8192 * 2); hipMalloc(&W, (size_t)10240 * 8192 * 2); hipMalloc(&out, (size_t)28672 * 10240 * 2); hipMalloc(&zero, 256);
     // pseudo-random bf16 fill (values ~ +-1): data-dependent power/clock effects matter (guide 5.4 rule 25)
@@ -19,7 +19,7 @@ int main(int argc, char** argv) {
             g.M = sh.M; g.N = sh.N; g.K = sh.K; g.lda = sh.K; g.ldw = sh.K; g.ldo = sh.N;
             for (int r = 0; r < 3; ++r) launch_with_cfg(g, cfg, 0);
             hipEventRecord(e0, 0);
-            const int it = 20;
+            const int it = 50;
             for (int r = 0; r < it; ++r) launch_with_cfg(g, cfg, 0);
             hipEventRecord(e1, 0); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
