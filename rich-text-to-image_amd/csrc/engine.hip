@@ -468,7 +468,11 @@ struct rt_engine {
                 bf16_t* qk = ws.b16((size_t)M * 2 * HD);
                 bf16_t* vt = ws.b16((size_t)HD * M);
                 bf16_t* o = ws.b16((size_t)M * HD);
-                gemm(n, C, k.qk1, M, qk, 2 * HD, EPI_BF16);
+                // Q,K are only needed for streams that some stream attends with (injected region streams use the
+                // text_ref stream's Q,K: attention_processor.py:522-524 discards their own scores)
+                int nqk = 0;
+                for (int b = 0; b < B; ++b) nqk = std::max(nqk, in.qk_src[b] + 1);
+                gemm(n, C, k.qk1, nqk * HW, qk, 2 * HD, EPI_BF16);
                 gemm_vt(k.v1, n, C, M, vt, M);
                 if (!dry()) {
                     AttnArgs a{}; a.Q = qk; a.ldq = 2 * HD; a.K = qk + HD; a.ldk = 2 * HD; a.VT = vt; a.ldvt = M; a.O = o; a.ldo = HD;
