@@ -97,6 +97,18 @@ int rt_region_step(rt_engine* e, int step_index, float guidance_scale, float inj
 /* one iteration of the plain-text loop (rd.py:200-214 / xl.py:880-905): batch-2 forward, CFG, step */
 int rt_plain_step(rt_engine* e, int step_index, float guidance_scale);
 
+/* token-map attention store (hooks rd.py:397-443, xl.py:959-1016): head-averaged softmax(QK^T) of the
+ * CONDITIONAL stream of rt_plain_step, recorded for the named attention modules (reference module names such as
+ * "down_blocks.1.attentions.0.transformer_blocks.0.attn1").  mode 1: accumulate over calls after the module's 10th
+ * call (n_maps[name] > 10); mode 2: overwrite after the 10th call (the SD-v1.5 self-attention quirk, rd.py:423);
+ * mode 0: off.  Self-attention maps are limited to 32x32 tokens (the only ones get_token_maps consumes). */
+int rt_attn_store_enable(rt_engine* e, const char* module_name, int mode);
+int rt_attn_store_reset(rt_engine* e);
+int rt_attn_store_read(rt_engine* e, const char* module_name, float* dst_dev /* [rows, cols] f32 or NULL */, int* n_calls,
+                       int* rows, int* cols);
+int rt_attn_module_count(rt_engine* e);
+int rt_attn_module_info(rt_engine* e, int idx, char* name, int name_cap, int* max_tokens, int* heads);
+
 /* per-launch HIP-event timing of the MFMA kernels on the engine's stream (bench.py roofline leg).
  * Algorithmic FLOPs are counted per launch (2*M*N*K for GEMM/conv, 4*B*H*N*NK*d for attention; padded
  * head dims / keys are not counted). */

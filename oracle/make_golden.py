@@ -171,5 +171,89 @@ def main():
     print("wrote", sorted(os.listdir(OUT)))
 
 
+def tokenmap_goldens():
+    """Reference token-map hooks (rd.py:397-443 / xl.py:959-1016) + the reference get_token_maps
+    (utils/attention_utils.py:233-341) on a plain pass of the tiny UNets."""
+    import tempfile
+    import matplotlib
+    matplotlib.use("Agg")
+    mods = load_reference()
+    import importlib
+    au = importlib.import_module("utils.attention_utils")
+    au.plot_attention_maps = lambda *a, **k: None              # figures are out of scope (SURVEY section 2 #11)
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self              # get_token_maps ends with .cuda() (attention_utils.py:337)
+    U = mods["unet_2d_condition"].UNet2DConditionModel
+    try:
+        for name, cfg, xl, hw, steps in (("tokenmaps_sd", TINY_SD_CONFIG, False, 64, 13), ("tokenmaps_xl", TINY_XL_CONFIG, True, 128, 12)):
+            sd = random_state_dict(cfg, seed=11)
+            ref = U(**reference_kwargs(cfg)); ref.load_state_dict(sd); ref.eval()
+            g = torch.Generator().manual_seed(9)
+            lat = torch.randn(1, 4, hw, hw, generator=g)
+            emb = torch.randn(2, 77, cfg["cross_attention_dim"], generator=g) * 2.0
+            pooled = torch.randn(2, 32, generator=g) if xl else None
+            tid = torch.tensor([[hw * 8.0, hw * 8.0, 0, 0, hw * 8.0, hw * 8.0]] * 2) if xl else None
+            if xl:
+                XL = mods["region_diffusion_sdxl"].RegionDiffusionXL
+                m = XL.__new__(XL)
+                # the XL hook reads the module-global list; point it at modules that exist in the tiny UNet
+                xl_cross = ['down_blocks.2.attentions.1.transformer_blocks.1.attn2', 'mid_block.attentions.0.transformer_blocks.0.attn2',
+                            'mid_block.attentions.0.transformer_blocks.1.attn2', 'up_blocks.0.attentions.0.transformer_blocks.1.attn2',
+                            'up_blocks.1.attentions.0.transformer_blocks.0.attn2']
+                mods["region_diffusion_sdxl"].CrossAttentionLayers_XL[:] = xl_cross
+                sched = OracleEuler()
+            else:
+                RD = mods["region_diffusion"].RegionDiffusion
+                m = RD.__new__(RD)
+                torch.nn.Module.__init__(m)
+                xl_cross = None
+                sched = OraclePNDM()
+            m.unet = ref
+            m.register_tokenmap_hooks()
+            sched.set_timesteps(steps)
+            x = lat * sched.init_noise_sigma if xl else lat.clone()
+            gs = 7.5
+            for t in sched.timesteps:
+                inp = torch.cat([x] * 2)
+                if xl:
+                    inp = sched.scale_model_input(inp, t)
+                with torch.no_grad():
+                    eps = ref(inp, t, encoder_hidden_states=emb,
+                              added_cond_kwargs={"text_embeds": pooled, "time_ids": tid} if xl else None)["sample"]
+                eu, et = eps.chunk(2)
+                x = sched.step(eu + gs * (et - eu), t, x)["prev_sample"]
+            selfm = {k: v for k, v in m.selfattn_maps.items() if v.shape[1] == 1024}
+            crossm = dict(m.crossattn_maps)
+            obj_tokens = [torch.tensor([2, 3]), torch.tensor([6])]
+            with tempfile.TemporaryDirectory() as td:
+                masks = au.get_token_maps(selfm, crossm, m.n_maps, td, hw, hw, obj_tokens, seed=3, segment_threshold=0.3, num_segments=5)
+            print(name, "self maps", len(selfm), "cross maps", len(crossm), "n_maps", set(m.n_maps.values()), "masks", len(masks))
+            torch.save({
+                "xl": xl, "steps": steps, "guidance_scale": gs, "weight_seed": 11, "latents": lat, "embeds": emb, "pooled": pooled,
+                "time_ids": tid[:1] if xl else None, "xl_cross_layers": xl_cross, "final_latents": x,
+                "self_names": sorted(selfm), "cross_names": sorted(crossm),
+                "self_maps_rows": {k: v[0, ::16].clone().half() for k, v in selfm.items()},      # every 16th query row (fixture size)
+                "self_maps_rowsum": {k: v[0].sum(-1) for k, v in selfm.items()},
+                "cross_maps": {k: v[0].clone() for k, v in crossm.items()},
+                "n_maps_values": sorted(set(int(v) for v in m.n_maps.values())), "obj_tokens": obj_tokens,
+                "masks": torch.cat(masks)[:, 0].clone().half(),
+            }, os.path.join(OUT, name + ".pt"))
+        # the reference get_token_maps on deterministic synthetic maps (pins the port; inputs are regenerated from the seed)
+        from .synth import synthetic_attention_maps
+        port = {}
+        for seed, nseg, thr in ((0, 5, 0.3), (1, 7, 0.25)):
+            selfm, crossm = synthetic_attention_maps(seed)
+            with tempfile.TemporaryDirectory() as td:
+                masks = au.get_token_maps(selfm, crossm, {}, td, 64, 64, [torch.tensor([2, 3]), torch.tensor([6])], seed=4,
+                                          segment_threshold=thr, num_segments=nseg)
+            port[(seed, nseg, thr)] = torch.cat(masks)[:, 0].clone()
+        torch.save(port, os.path.join(OUT, "token_maps_port.pt"))
+    finally:
+        torch.Tensor.cuda = orig_cuda
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "tokenmaps":
+        tokenmap_goldens()
+    else:
+        main()

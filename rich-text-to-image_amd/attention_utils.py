@@ -1,0 +1,102 @@
+"""Token-map producer: drop-in for `utils/attention_utils.py:get_token_maps`.
+
+Same arguments and return value as the reference (list of [1,4,h,w] region masks on the GPU); the seaborn /
+matplotlib figures the reference writes on every call (attention_utils.py:266-270,334-335) are not produced.
+The numerical steps follow attention_utils.py:233-341 line by line: 32x32 self-attention affinity ->
+SpectralClustering(n_init=100, kmeans) -> clusters labelled by min-max-normalised cross-attention score against
+`segment_threshold` -> bicubic(antialias) resize, clamp, normalise.  The clustering itself stays on the CPU
+(scikit-learn, seeded like the reference: `seed_everything(seed)` before `fit_predict`)."""
+import random
+
+import numpy as np
+import torch
+
+# module-name lists of the reference (attention_utils.py:12-67): data, not code
+SelfAttentionLayers = [
+    'down_blocks.0.attentions.0.transformer_blocks.0.attn1', 'down_blocks.0.attentions.1.transformer_blocks.0.attn1',
+    'down_blocks.1.attentions.0.transformer_blocks.0.attn1', 'down_blocks.1.attentions.1.transformer_blocks.0.attn1',
+    'down_blocks.2.attentions.0.transformer_blocks.0.attn1', 'down_blocks.2.attentions.1.transformer_blocks.0.attn1',
+    'mid_block.attentions.0.transformer_blocks.0.attn1',
+    'up_blocks.1.attentions.0.transformer_blocks.0.attn1', 'up_blocks.1.attentions.1.transformer_blocks.0.attn1',
+    'up_blocks.1.attentions.2.transformer_blocks.0.attn1', 'up_blocks.2.attentions.0.transformer_blocks.0.attn1',
+    'up_blocks.2.attentions.1.transformer_blocks.0.attn1', 'up_blocks.2.attentions.2.transformer_blocks.0.attn1',
+    'up_blocks.3.attentions.0.transformer_blocks.0.attn1', 'up_blocks.3.attentions.1.transformer_blocks.0.attn1',
+    'up_blocks.3.attentions.2.transformer_blocks.0.attn1',
+]
+CrossAttentionLayers = [
+    'down_blocks.1.attentions.0.transformer_blocks.0.attn2', 'down_blocks.2.attentions.0.transformer_blocks.0.attn2',
+    'down_blocks.2.attentions.1.transformer_blocks.0.attn2', 'mid_block.attentions.0.transformer_blocks.0.attn2',
+    'up_blocks.1.attentions.0.transformer_blocks.0.attn2', 'up_blocks.1.attentions.1.transformer_blocks.0.attn2',
+    'up_blocks.1.attentions.2.transformer_blocks.0.attn2', 'up_blocks.2.attentions.1.transformer_blocks.0.attn2',
+]
+CrossAttentionLayers_XL = [
+    'down_blocks.2.attentions.1.transformer_blocks.3.attn2', 'down_blocks.2.attentions.1.transformer_blocks.4.attn2',
+    'mid_block.attentions.0.transformer_blocks.0.attn2', 'mid_block.attentions.0.transformer_blocks.1.attn2',
+    'mid_block.attentions.0.transformer_blocks.2.attn2', 'mid_block.attentions.0.transformer_blocks.3.attn2',
+    'up_blocks.0.attentions.0.transformer_blocks.1.attn2', 'up_blocks.0.attentions.0.transformer_blocks.2.attn2',
+    'up_blocks.0.attentions.0.transformer_blocks.3.attn2', 'up_blocks.0.attentions.0.transformer_blocks.4.attn2',
+    'up_blocks.0.attentions.0.transformer_blocks.5.attn2', 'up_blocks.0.attentions.0.transformer_blocks.6.attn2',
+    'up_blocks.0.attentions.0.transformer_blocks.7.attn2', 'up_blocks.1.attentions.0.transformer_blocks.0.attn2',
+]
+
+
+def seed_everything(seed):                         # utils/richtext_utils.py:22-27
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+def get_token_maps(selfattn_maps, crossattn_maps, n_maps, save_dir, width, height, obj_tokens, seed=0, tokens_vis=None,
+                   preprocess=False, segment_threshold=0.3, num_segments=5, return_vis=False, save_attn=False, device=None):
+    from sklearn.cluster import SpectralClustering
+    resolution = 32
+    maps32 = []
+    for attn_map in selfattn_maps.values():
+        res_map = int(np.sqrt(attn_map.shape[1]))
+        if res_map != resolution:
+            continue
+        a = attn_map.reshape(1, res_map, res_map, res_map ** 2).permute([3, 0, 1, 2]).float().cpu()
+        a = torch.nn.functional.interpolate(a, (resolution, resolution), mode='bicubic', antialias=True)
+        maps32.append(a.permute([1, 2, 3, 0]).reshape(1, resolution ** 2, res_map ** 2))
+    affinity = torch.cat(maps32).mean(0).cpu().numpy()
+    seed_everything(seed)
+    sc = SpectralClustering(num_segments, affinity='precomputed', n_init=100, assign_labels='kmeans')
+    clusters = sc.fit_predict(affinity).reshape(resolution, resolution)
+
+    cross = []
+    for attn_map in crossattn_maps.values():
+        res_map = int(np.sqrt(attn_map.shape[1]))
+        a = attn_map.reshape(1, res_map, res_map, -1).permute([0, 3, 1, 2]).float().cpu()
+        a = torch.nn.functional.interpolate(a, (resolution, resolution), mode='bicubic', antialias=True)
+        cross.append(a.permute([0, 2, 3, 1]))
+    cross = torch.cat(cross).mean(0).cpu().numpy()
+    normalized_span_maps = []
+    for token_ids in obj_tokens:
+        span = cross[:, :, token_ids.numpy()]
+        nm = np.zeros_like(span)
+        for i in range(span.shape[-1]):
+            cur = span[:, :, i]
+            nm[:, :, i] = (cur - np.abs(cur.min())) / (cur.max() - cur.min())
+        normalized_span_maps.append(nm)
+    foreground = [np.zeros([clusters.shape[0], clusters.shape[1]]).squeeze() for _ in normalized_span_maps]
+    background = np.zeros([clusters.shape[0], clusters.shape[1]]).squeeze()
+    for c in range(num_segments):
+        cluster_mask = np.zeros_like(clusters)
+        cluster_mask[clusters == c] = 1.
+        is_fg = False
+        for nm, fg, token_ids in zip(normalized_span_maps, foreground, obj_tokens):
+            scores = [(cluster_mask * nm[:, :, i]).sum() / cluster_mask.sum() for i in range(len(token_ids))]
+            if max(scores) > segment_threshold:
+                fg += cluster_mask
+                is_fg = True
+        if not is_fg:
+            background += cluster_mask
+    foreground.append(background)
+    resized = torch.cat([torch.nn.functional.interpolate(torch.from_numpy(m).unsqueeze(0).unsqueeze(0), (height, width),
+                                                         mode='bicubic', antialias=True)[0] for m in foreground]).clamp(0, 1)
+    resized = resized / (resized.sum(0, True) + 1e-8)
+    dev = device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu")
+    dtype = next(iter(crossattn_maps.values())).dtype
+    return [m.unsqueeze(0).unsqueeze(1).repeat([1, 4, 1, 1]).to(dtype).to(dev) for m in resized]

@@ -97,6 +97,16 @@ struct AttnArgs {
 };
 void launch_attention(const AttnArgs& a, hipStream_t st);
 
+// head-averaged probabilities of one stream, accumulated over calls (token-map producer)
+struct AttnStoreArgs {
+    const bf16_t* Q; int ldq; long q_row0;     // query rows q_row0 + [0, N), head h at column h*DP (pre-scaled like AttnArgs.Q)
+    const bf16_t* K; int ldk; long k_row0;     // key rows k_row0 + [0, NKrows)
+    float* out;                                // [N, NK] fp32 accumulator
+    int H, N, NK, NKpad, NKrows, DP;
+    int overwrite;                             // 1: out = avg(P); 0: out += avg(P)
+};
+void launch_attn_store(const AttnStoreArgs& a, hipStream_t st);
+
 // ---------------------------------------------------------------- norms / elementwise
 struct GroupNormArgs {
     const void* x1; const void* x2;   // x2 may be null; virtual concat along channels [C1 | C2]

@@ -76,10 +76,17 @@ struct TBlockP {
     MatW qk1, v1, out1, q2, k2, v2, out2, ff1, ff2;
     bf16_t* kcache = nullptr;    // [maxP*96, H*DP]
     bf16_t* vtcache = nullptr;   // [H*DP, maxP*96]
+    // token-map attention store: index 0 = attn1, 1 = attn2
+    std::string mod_name[2];
+    float* store[2] = {nullptr, nullptr};
+    int store_mode[2] = {0, 0};            // 0 off, 1 accumulate after the 10th call, 2 overwrite after the 10th call
+    int store_calls[2] = {0, 0};
+    int store_rows[2] = {0, 0}, store_cols[2] = {0, 0};
+    size_t store_cap[2] = {0, 0};
 };
 struct TransformerP {
     std::string name;
-    int C = 0, heads = 0, d = 0, DP = 0;
+    int C = 0, heads = 0, d = 0, DP = 0, level = 0;
     NormW gn;
     MatW pin, pout;
     std::vector<TBlockP> blocks;
@@ -111,6 +118,7 @@ struct FwdIn {
     float t = 0;
     int prompt[RT_MAXB], fontsize[RT_MAXB], qk_src[RT_MAXB], res_src[RT_MAXB];
     float* eps_out = nullptr;    // [B, HW, 4] fp32
+    int store_stream = -1;       // stream whose head-averaged attention maps are recorded (plain pass: the conditional one)
 };
 
 // step epilogue kernels (defined in step.hip)
@@ -255,8 +263,8 @@ struct rt_engine {
         add_slot(name + ".bias", {C}, pk_vec(m.b, C));
         return m;
     }
-    TransformerP mk_transformer(const std::string& name, int C, int heads, int nlayers) {
-        TransformerP t; t.name = name; t.C = C; t.heads = heads; t.d = C / heads; t.DP = pad_head_dim(t.d);
+    TransformerP mk_transformer(const std::string& name, int C, int heads, int nlayers, int level) {
+        TransformerP t; t.name = name; t.C = C; t.heads = heads; t.d = C / heads; t.DP = pad_head_dim(t.d); t.level = level;
         RT_REQUIRE(C % heads == 0, "channels not divisible by heads");
         const int HD = heads * t.DP, D = cfg.cross_attention_dim;
         const float qscale = (float)(std::pow((double)t.d, -0.5) * 1.4426950408889634);   // d^-1/2 * log2(e)
@@ -265,6 +273,7 @@ struct rt_engine {
         for (int li = 0; li < nlayers; ++li) {
             const std::string b = name + ".transformer_blocks." + std::to_string(li);
             TBlockP k;
+            k.mod_name[0] = b + ".attn1"; k.mod_name[1] = b + ".attn2";
             k.ln1 = mk_norm(b + ".norm1", C);
             bf16_t* qk = (bf16_t*)arena.alloc((size_t)2 * HD * C * 2);
             k.qk1 = mk_headproj(b + ".attn1.to_q", C, heads, t.d, t.DP, qscale, qk, C);
@@ -318,13 +327,13 @@ struct rt_engine {
             const std::string pre = "down_blocks." + std::to_string(i);
             for (int j = 0; j < cfg.layers_per_block[i]; ++j) {
                 d.res.push_back(mk_resnet(pre + ".resnets." + std::to_string(j), j == 0 ? in_c : out_c, out_c));
-                if (d.has_attn) d.attn.push_back(mk_transformer(pre + ".attentions." + std::to_string(j), out_c, cfg.heads[i], cfg.transformer_layers[i]));
+                if (d.has_attn) d.attn.push_back(mk_transformer(pre + ".attentions." + std::to_string(j), out_c, cfg.heads[i], cfg.transformer_layers[i], i));
             }
             if (d.has_down) d.down = mk_conv3(pre + ".downsamplers.0.conv", out_c, out_c);
             down.push_back(d);
         }
         mid_r0 = mk_resnet("mid_block.resnets.0", boc[L - 1], boc[L - 1]);
-        mid_t = mk_transformer("mid_block.attentions.0", boc[L - 1], cfg.heads[L - 1], cfg.transformer_layers[L - 1]);
+        mid_t = mk_transformer("mid_block.attentions.0", boc[L - 1], cfg.heads[L - 1], cfg.transformer_layers[L - 1], L - 1);
         mid_r1 = mk_resnet("mid_block.resnets.1", boc[L - 1], boc[L - 1]);
         out_c = boc[L - 1];
         for (int i = 0; i < L; ++i) {
@@ -337,7 +346,7 @@ struct rt_engine {
                 const int skip_c = j == nl - 1 ? in_c : out_c;
                 const int res_in = j == 0 ? prev : out_c;
                 u.res.push_back(mk_resnet(pre + ".resnets." + std::to_string(j), res_in + skip_c, out_c));
-                if (u.has_attn) u.attn.push_back(mk_transformer(pre + ".attentions." + std::to_string(j), out_c, cfg.heads[L - 1 - i], cfg.transformer_layers[L - 1 - i]));
+                if (u.has_attn) u.attn.push_back(mk_transformer(pre + ".attentions." + std::to_string(j), out_c, cfg.heads[L - 1 - i], cfg.transformer_layers[L - 1 - i], L - 1 - i));
             }
             if (u.has_up) u.up = mk_conv3(pre + ".upsamplers.0.conv", out_c, out_c);
             up.push_back(u);
@@ -446,7 +455,7 @@ struct rt_engine {
     }
 
     // Transformer2DModel.forward (models/transformer_2d.py:270-310) + BasicTransformerBlock (attention.py:131-206)
-    Tensor transformer(const TransformerP& t, const FwdIn& in, int HW, Tensor x) {
+    Tensor transformer(TransformerP& t, const FwdIn& in, int HW, Tensor x) {
         const int B = in.B, M = B * HW, C = t.C, HD = t.heads * t.DP;
         RT_REQUIRE(x.C == C, "transformer: channel mismatch");
         RT_REQUIRE(HW % 64 == 0, "transformer: token count must be a multiple of 64");
@@ -460,7 +469,7 @@ struct rt_engine {
                 groupnorm(x.p, nullptr, false, C, 0, B, HW, t.gn, 1e-6f, false, g, nullptr);
                 gemm(g, C, t.pin, M, hcur, C, EPI_F32);
             }
-            for (const TBlockP& k : t.blocks) {
+            for (TBlockP& k : t.blocks) {
                 Scope s2(ws);
                 bf16_t* n = ws.b16((size_t)M * C);
                 // --- attn1 (self; attention_processor.py:476-545)
@@ -481,6 +490,15 @@ struct rt_engine {
                     prof_begin(RT_PROF_ATTN_SELF, 4.0 * B * t.heads * (double)HW * HW * t.d);
                     launch_attention(a, stream);
                     prof_end();
+                    if (in.store_stream >= 0 && k.store_mode[0] && ++k.store_calls[0] > 10) {      // n_maps[name] > 10 (rd.py:422, xl.py:988)
+                        RT_REQUIRE((size_t)HW * HW <= k.store_cap[0], "attention store: map larger than the enabled buffer");
+                        AttnStoreArgs sa{}; sa.Q = qk; sa.ldq = 2 * HD; sa.q_row0 = (long)in.store_stream * HW;
+                        sa.K = qk + HD; sa.ldk = 2 * HD; sa.k_row0 = (long)in.store_stream * HW;
+                        sa.out = k.store[0]; sa.H = t.heads; sa.N = HW; sa.NK = HW; sa.NKpad = HW; sa.NKrows = HW; sa.DP = t.DP;
+                        sa.overwrite = k.store_mode[0] == 2;
+                        launch_attn_store(sa, stream);
+                        k.store_rows[0] = HW; k.store_cols[0] = HW;
+                    }
                 }
                 gemm(o, HD, k.out1, M, hcur, C, EPI_F32, hcur, C);
                 // --- attn2 (cross, K/V from the per-prompt cache; font-size softmax on flagged streams)
@@ -495,6 +513,15 @@ struct rt_engine {
                     prof_begin(RT_PROF_ATTN_CROSS, 4.0 * B * t.heads * (double)HW * 77 * t.d);
                     launch_attention(a, stream);
                     prof_end();
+                    if (in.store_stream >= 0 && k.store_mode[1] && ++k.store_calls[1] > 10) {
+                        RT_REQUIRE((size_t)HW * 77 <= k.store_cap[1], "attention store: map larger than the enabled buffer");
+                        AttnStoreArgs sa{}; sa.Q = qk; sa.ldq = HD; sa.q_row0 = (long)in.store_stream * HW;
+                        sa.K = k.kcache; sa.ldk = HD; sa.k_row0 = (long)in.prompt[in.store_stream] * 96;
+                        sa.out = k.store[1]; sa.H = t.heads; sa.N = HW; sa.NK = 77; sa.NKpad = 96; sa.NKrows = 96; sa.DP = t.DP;
+                        sa.overwrite = k.store_mode[1] == 2;
+                        launch_attn_store(sa, stream);
+                        k.store_rows[1] = HW; k.store_cols[1] = 77;
+                    }
                 }
                 gemm(o, HD, k.out2, M, hcur, C, EPI_F32, hcur, C);
                 // --- GEGLU feed-forward (attention.py:209-304)
@@ -548,7 +575,7 @@ struct rt_engine {
         skips.push_back(x);
         int ch = Hh, cw = Ww;
         for (size_t i = 0; i < down.size(); ++i) {
-            const DownP& d = down[i];
+            DownP& d = down[i];
             for (size_t j = 0; j < d.res.size(); ++j) {
                 x = resnet(d.res[j], in, ch * cw, ch, cw, x, nullptr, emb, false);
                 if (d.has_attn) x = transformer(d.attn[j], in, ch * cw, x);
@@ -572,7 +599,7 @@ struct rt_engine {
         x = transformer(mid_t, in, ch * cw, x);
         x = resnet(mid_r1, in, ch * cw, ch, cw, x, nullptr, emb, false);
         for (size_t i = 0; i < up.size(); ++i) {
-            const UpP& u = up[i];
+            UpP& u = up[i];
             for (size_t j = 0; j < u.res.size(); ++j) {
                 Tensor sk = skips.back(); skips.pop_back();
                 const bool inject_here = (i == 1 && j == 1);        // 'up_blocks.1.resnets.1' (rd.py:350, xl.py:1101)
@@ -657,6 +684,42 @@ struct rt_engine {
         HIP_CHECK(hipStreamSynchronize(stream));
     }
 
+    template <typename F> void for_each_tblock(F f) {
+        for (auto& d : down) for (auto& t : d.attn) for (auto& k : t.blocks) f(t, k);
+        for (auto& k : mid_t.blocks) f(mid_t, k);
+        for (auto& u : up) for (auto& t : u.attn) for (auto& k : t.blocks) f(t, k);
+    }
+    bool any_store() { bool any = false; for_each_tblock([&](TransformerP&, TBlockP& k) { any |= k.store_mode[0] || k.store_mode[1]; }); return any; }
+    void attn_store_enable(const std::string& name, int mode) {
+        bool found = false;
+        for_each_tblock([&](TransformerP& t, TBlockP& k) {
+            for (int w = 0; w < 2; ++w) {
+                if (k.mod_name[w] != name) continue;
+                found = true;
+                const size_t N = (size_t)(cfg.latent_h >> t.level) * (cfg.latent_w >> t.level);
+                const size_t cols = w == 0 ? N : 77;
+                if (mode != 0 && w == 0 && N > 1024)
+                    throw rt_error(RT_E_UNSUPPORTED, "attention store: self-attention maps above 32x32 are not recorded (never consumed: attention_utils.py:243-248)");
+                if (mode != 0 && k.store_cap[w] < N * cols) {
+                    if (k.store[w]) HIP_CHECK(hipFree(k.store[w]));
+                    HIP_CHECK(hipMalloc((void**)&k.store[w], N * cols * 4));
+                    k.store_cap[w] = N * cols;
+                }
+                k.store_mode[w] = mode; k.store_calls[w] = 0; k.store_rows[w] = k.store_cols[w] = 0;
+                if (mode != 0) HIP_CHECK(hipMemsetAsync(k.store[w], 0, k.store_cap[w] * 4, stream));
+            }
+        });
+        if (!found) throw rt_error(RT_E_INVALID, "attention store: unknown attention module " + name);
+    }
+    void attn_store_reset() {
+        for_each_tblock([&](TransformerP&, TBlockP& k) {
+            for (int w = 0; w < 2; ++w) {
+                k.store_calls[w] = 0; k.store_rows[w] = k.store_cols[w] = 0;
+                if (k.store[w]) HIP_CHECK(hipMemsetAsync(k.store[w], 0, k.store_cap[w] * 4, stream));
+            }
+        });
+    }
+
     void require_bound() {
         for (auto& s : slots) if (!s.bound) throw rt_error(RT_E_MISSING_WEIGHT, "weight not bound: " + s.name);
     }
@@ -722,6 +785,7 @@ int rt_create(const rt_config* cfg, int device, rt_engine** out) {
             HIP_CHECK(hipMalloc((void**)&e->ws.base, peak));
             e->ws.cap = peak;
         }
+        e->set_fontsize(nullptr, nullptr, 0);      // multiplier set 0/1 = plain softmax until rt_set_fontsize is called
         *out = e;
         return RT_OK;
     } catch (const std::exception& ex) {
@@ -845,6 +909,45 @@ int rt_unet_forward(rt_engine* e, const float* x, int B, int h, int w, float t, 
         }
         e->unet_forward(in);
         launch_nhwc4_to_nchw(e->eps, out, B, h * w, e->stream);
+    })
+}
+
+int rt_attn_store_enable(rt_engine* e, const char* name, int mode) {
+    RT_TRY(e, { need_device(e); RT_REQUIRE(mode >= 0 && mode <= 2, "rt_attn_store_enable: mode"); e->attn_store_enable(name, mode); })
+}
+int rt_attn_store_reset(rt_engine* e) { RT_TRY(e, { need_device(e); e->attn_store_reset(); }) }
+int rt_attn_store_read(rt_engine* e, const char* name, float* dst, int* n_calls, int* rows, int* cols) {
+    RT_TRY(e, {
+        need_device(e);
+        bool found = false;
+        e->for_each_tblock([&](TransformerP&, TBlockP& k) {
+            for (int w = 0; w < 2; ++w) {
+                if (k.mod_name[w] != name) continue;
+                found = true;
+                *n_calls = k.store_calls[w]; *rows = k.store_rows[w]; *cols = k.store_cols[w];
+                if (dst && k.store[w] && k.store_rows[w] > 0)
+                    HIP_CHECK(hipMemcpyAsync(dst, k.store[w], (size_t)k.store_rows[w] * k.store_cols[w] * 4, hipMemcpyDeviceToDevice, e->stream));
+            }
+        });
+        if (!found) throw rt_error(RT_E_INVALID, std::string("attention store: unknown attention module ") + name);
+        HIP_CHECK(hipStreamSynchronize(e->stream));
+    })
+}
+int rt_attn_module_count(rt_engine* e) { int n = 0; e->for_each_tblock([&](TransformerP&, TBlockP&) { n += 2; }); return n; }
+int rt_attn_module_info(rt_engine* e, int idx, char* name, int cap, int* max_tokens, int* heads) {
+    RT_TRY(e, {
+        int i = 0; bool found = false;
+        e->for_each_tblock([&](TransformerP& t, TBlockP& k) {
+            for (int w = 0; w < 2; ++w, ++i) {
+                if (i != idx) continue;
+                found = true;
+                RT_REQUIRE((int)k.mod_name[w].size() < cap, "rt_attn_module_info: name buffer too small");
+                std::strcpy(name, k.mod_name[w].c_str());
+                *max_tokens = (e->cfg.latent_h >> t.level) * (e->cfg.latent_w >> t.level);
+                *heads = t.heads;
+            }
+        });
+        RT_REQUIRE(found, "rt_attn_module_info: index");
     })
 }
 

@@ -96,6 +96,7 @@ void rt_engine::plain_step(int i, float g) {
     FwdIn in{}; in.h = lat_h; in.w = lat_w; in.t = timesteps[i]; in.eps_out = eps; in.B = 2;
     const float scale = xl ? 1.f / std::sqrt(table[i] * table[i] + 1.f) : 1.f;
     for (int b = 0; b < 2; ++b) { in.x[b] = lat; in.scale[b] = scale; in.prompt[b] = b; in.fontsize[b] = 0; in.qk_src[b] = b; in.res_src[b] = -1; }
+    if (any_store()) in.store_stream = 1;     // hooks keep the conditional half: out[1][0][1:2] (rd.py:417,425 / xl.py:980,991)
     unet_forward(in);
     StepArgs a{};
     a.eps = eps; a.masks = masks; a.lat = lat; a.lat_ref = lat_ref; a.HW = lat_h * lat_w; a.R = 0; a.g = g; a.plain = 1;

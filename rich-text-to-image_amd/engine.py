@@ -66,7 +66,8 @@ _SYMBOLS = [
     "rt_set_prompts", "rt_set_masks", "rt_set_fontsize", "rt_set_schedule", "rt_set_latents", "rt_get_latents",
     "rt_region_step", "rt_plain_step", "rt_unet_forward", "rt_op_gemm", "rt_op_attention", "rt_op_groupnorm",
     "rt_op_layernorm", "rt_op_small_linear", "rt_op_timestep_embed", "rt_op_last_error", "rt_profile_enable",
-    "rt_profile_read", "rt_op_gemm_force_config", "rt_op_gemm_debug",
+    "rt_profile_read", "rt_op_gemm_force_config", "rt_op_gemm_debug", "rt_attn_store_enable", "rt_attn_store_reset",
+    "rt_attn_store_read", "rt_attn_module_count", "rt_attn_module_info",
 ]
 
 
@@ -265,6 +266,34 @@ class Engine:
         assert l.shape[0] == 1 and l.shape[1] == 4
         self._chk(self.lib.rt_set_latents(self.h, _ptr(l), l.shape[2], l.shape[3]))
         self.synchronize()
+
+    # ---- token-map attention store
+    def attn_modules(self):
+        n = self.lib.rt_attn_module_count(self.h)
+        name = C.create_string_buffer(256)
+        mt, hd = C.c_int(), C.c_int()
+        out = []
+        for i in range(n):
+            self._chk(self.lib.rt_attn_module_info(self.h, i, name, 256, C.byref(mt), C.byref(hd)))
+            out.append((name.value.decode(), mt.value, hd.value))
+        return out
+
+    def attn_store_enable(self, name, mode=1):
+        self._chk(self.lib.rt_attn_store_enable(self.h, name.encode(), int(mode)))
+
+    def attn_store_reset(self):
+        self._chk(self.lib.rt_attn_store_reset(self.h))
+
+    def attn_store_read(self, name):
+        """-> (n_calls, map [1, rows, cols] on the GPU or None if nothing was recorded yet)"""
+        import torch
+        n, r, c = C.c_int(), C.c_int(), C.c_int()
+        self._chk(self.lib.rt_attn_store_read(self.h, name.encode(), None, C.byref(n), C.byref(r), C.byref(c)))
+        if r.value == 0:
+            return n.value, None
+        out = torch.empty(1, r.value, c.value, device=f"cuda:{self.device}")
+        self._chk(self.lib.rt_attn_store_read(self.h, name.encode(), _ptr(out), C.byref(n), C.byref(r), C.byref(c)))
+        return n.value, out
 
     # ---- profiling (HIP events around every MFMA kernel launch on the engine stream)
     PROF_CLASSES = {0: "gemm_kernel<A_DENSE>", 1: "gemm_kernel<A_CONV3*>", 2: "attn_kernel<self>", 3: "attn_kernel<cross>"}

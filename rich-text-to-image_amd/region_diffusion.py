@@ -86,8 +86,13 @@ class RegionDiffusion:
         eng.set_prompts(text_embeddings.to(self.device))
         eng.set_schedule(1, self.scheduler.timesteps.tolist(), self.scheduler.table(), num_inference_steps)
         eng.set_latents(latents.to(self.device))
+        hooks = getattr(self, "_tokenmap_hooks", False)
+        if hooks:
+            self._store_begin(eng)
         for i in range(len(self.scheduler.timesteps)):
             eng.plain_step(i, guidance_scale)
+        if hooks:
+            self._store_end(eng, len(self.scheduler.timesteps))
         return eng.read_latents(h, w)
 
     def decode_latents(self, latents):                                      # rd.py:227-236
@@ -122,7 +127,42 @@ class RegionDiffusion:
         self.attention_maps = None
 
     def register_tokenmap_hooks(self):
-        raise NotImplementedError("attention-map capture (rd.py:397-443) is SURVEY 8f row f1 (next)")
+        """rd.py:397-443: record head-averaged maps of the conditional half during produce_attn_maps / plain_latents.
+        Recording happens on the GPU (rt_attn_store_*); the dicts are filled after each plain pass."""
+        import collections
+        self._tokenmap_hooks = True
+        self.selfattn_maps = collections.defaultdict(list)
+        self.crossattn_maps = collections.defaultdict(list)
+        self.n_maps = collections.defaultdict(list)
 
     def remove_tokenmap_hooks(self):
+        self._tokenmap_hooks = False
         self.selfattn_maps = self.crossattn_maps = self.n_maps = None
+
+    def _store_begin(self, eng):
+        from .attention_utils import CrossAttentionLayers, SelfAttentionLayers
+        self._recorded = []
+        for name, max_tokens, _ in eng.attn_modules():
+            if name in SelfAttentionLayers and max_tokens <= 1024:
+                eng.attn_store_enable(name, 2)       # rd.py:423: tests `name in crossattn_maps` => overwritten each step
+                self._recorded.append(name)
+            elif name in CrossAttentionLayers:
+                eng.attn_store_enable(name, 1)
+                self._recorded.append(name)
+            else:
+                eng.attn_store_enable(name, 0)
+        eng.attn_store_reset()
+
+    def _store_end(self, eng, n_calls):
+        for name, _, _ in eng.attn_modules():
+            self.n_maps[name] = (self.n_maps[name] if name in self.n_maps else 0) + n_calls
+        for name in self._recorded:
+            n, m = eng.attn_store_read(name)
+            if m is None:
+                continue
+            tgt = self.crossattn_maps if name.endswith("attn2") else self.selfattn_maps
+            if name.endswith("attn2") and name in tgt and not isinstance(tgt[name], list):
+                tgt[name] = tgt[name] + m.cpu()
+            else:
+                tgt[name] = m.cpu()
+            eng.attn_store_enable(name, 0)

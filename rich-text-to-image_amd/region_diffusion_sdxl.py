@@ -92,8 +92,13 @@ class RegionDiffusionXL:
                 if callback is not None and i % callback_steps == 0:
                     callback(i, self.scheduler.timesteps[i], eng.read_latents(h, w))
         else:
+            hooks = getattr(self, "_tokenmap_hooks", False)
+            if hooks:
+                self._store_begin(eng)
             for i in range(n):
                 eng.plain_step(i, guidance_scale)
+            if hooks:
+                self._store_end(eng, n)
         latents = eng.read_latents(h, w)
         if output_type == "latent":
             return StableDiffusionXLPipelineOutput(images=latents)
@@ -106,8 +111,43 @@ class RegionDiffusionXL:
         a = torch.tensor(self.scheduler.alphas_cumprod)[int(t)].to(x_t.device)
         return (x_t - eps_t * torch.sqrt(1 - a)) / torch.sqrt(a)
 
+    cross_attention_layers = None      # defaults to attention_utils.CrossAttentionLayers_XL
+
     def register_tokenmap_hooks(self):
-        raise NotImplementedError("attention-map capture (xl.py:959-1016) is SURVEY 8f row f1 (next)")
+        """xl.py:959-1016: every attn1 map is accumulated by the reference; only the 32x32 ones are consumed
+        (attention_utils.py:243-248), so only those are recorded here (GPU side, rt_attn_store_*)."""
+        import collections
+        self._tokenmap_hooks = True
+        self.selfattn_maps = collections.defaultdict(list)
+        self.crossattn_maps = collections.defaultdict(list)
+        self.n_maps = collections.defaultdict(list)
 
     def remove_tokenmap_hooks(self):
+        self._tokenmap_hooks = False
         self.selfattn_maps = self.crossattn_maps = self.n_maps = None
+
+    def _store_begin(self, eng):
+        from .attention_utils import CrossAttentionLayers_XL
+        cross = self.cross_attention_layers or CrossAttentionLayers_XL
+        self._recorded = []
+        for name, max_tokens, _ in eng.attn_modules():
+            if name.endswith("attn1") and max_tokens <= 1024:
+                eng.attn_store_enable(name, 1)
+                self._recorded.append(name)
+            elif name in cross:
+                eng.attn_store_enable(name, 1)
+                self._recorded.append(name)
+            else:
+                eng.attn_store_enable(name, 0)
+        eng.attn_store_reset()
+
+    def _store_end(self, eng, n_calls):
+        for name, _, _ in eng.attn_modules():
+            self.n_maps[name] = (self.n_maps[name] if name in self.n_maps else 0) + n_calls
+        for name in self._recorded:
+            n, m = eng.attn_store_read(name)
+            if m is None:
+                continue
+            tgt = self.crossattn_maps if name.endswith("attn2") else self.selfattn_maps
+            tgt[name] = (tgt[name] + m.cpu()) if (name in tgt and not isinstance(tgt[name], list)) else m.cpu()
+            eng.attn_store_enable(name, 0)
