@@ -123,14 +123,25 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
                 mx = fmaxf(mx, s[j][r]);
             }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float alpha = exp2f(m - mx);
-        m = mx;
+        // Deferred rescale (guide T13): keep the old running max while it grew by <= 8 (log2 domain): P is then bounded
+        // by 2^8 instead of 1, which bf16 P / fp32 accumulation absorb, and the O / l rescale (32 accumulator
+        // read-modify-writes per tile) is skipped for almost every tile.  The decision is taken before this tile's P
+        // is exponentiated and after the previous tile's P.V completed, so everything at the old scale is scaled once.
+        if (!__all(mx - m <= 8.f)) {
+            const float alpha = __builtin_amdgcn_exp2f(m - mx);
+            m = mx;
+            l *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        }
         float rs = 0.f;
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float pv = exp2f(s[j][r] - mx);
+                float pv = __builtin_amdgcn_exp2f(s[j][r] - m);      // v_exp_f32: argument <= 8, underflow flushes to 0
                 if (CROSS) {
                     const int kl = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                     pv *= wl[kl];
@@ -141,11 +152,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
                 }
                 s[j][r] = pv;
             }
-        l = l * alpha + rs;
-#pragma unroll
-        for (int dt = 0; dt < ND; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        l += rs;
 
         // ---- O^T += V^T P^T
 #pragma unroll

@@ -34,72 +34,92 @@
 
 #define BK 64
 
-// ---- epilogue (shared by both main-loop variants), specialised at compile time on the epilogue kind so each
-//      kernel carries only its own store code (a 4-way runtime switch over fully unrolled stores made the
-//      epilogue 85 % of the kernel's instructions and every launch paid for the instruction-cache misses).
-//      With swapped operands the 32x32 accumulator tile is D[n][m]: m = lane&31 (row of C),
-//      n = (r&3) + 8*(r>>2) + 4*(lane>>5) (column of C): 4 consecutive columns per register quad, so the lane
-//      moves 16-B / 8-B vectors.  N % 4 == 0 is required (checked by the launcher).
-template <int EPI, int TM, int TN>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[TM][TN], int wrow0, int wcol0, int l31, int hi) {
-    if constexpr (EPI == EPI_GEGLU) {
-        static_assert(TN % 2 == 0, "GEGLU needs value/gate tile pairs in one wave");
-        // packed weight rows: per 64-column block [32 value | 32 gate] (engine: PACK_ROWS_GEGLU)
-        bf16_t* out = (bf16_t*)p.out;
+// ---- epilogue (shared by both main-loop variants), specialised at compile time on the epilogue kind.
+// With swapped operands the 32x32 accumulator tile is D[n][m]: m = lane&31 (row of C), n = (r&3) + 8*(r>>2) +
+// 4*(lane>>5) (column of C), i.e. a lane owns ONE output row and 4 consecutive columns per register quad.
+// Storing straight from that layout makes every store instruction touch 32 different rows with 16-32 B each
+// (measured: 7-9 us of the 12 us fixed cost of a launch).  Instead every wave transposes its 32-row slab through
+// its private slice of the (now idle) LDS ring and writes / reads HBM in row-contiguous 16-B chunks, so stores
+// (and the fp32 residual reads) move whole cache lines.  N % 4 == 0 (fp32) / N % 8 == 0 (bf16) is required.
+template <int EPI, int TM, int TN, int NWC, int LDS_BYTES>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[TM][TN], int wrow0, int wcol0, int lane, int wave_c,
+                                              char* smem) {
+    constexpr bool F32 = EPI == EPI_F32;
+    constexpr int ES = F32 ? 4 : 2;
+    constexpr int TO = EPI == EPI_GEGLU ? TN / 2 : TN;                 // 32-column output tiles per wave
+    static_assert(EPI != EPI_GEGLU || TN % 2 == 0, "GEGLU needs value/gate tile pairs in one wave");
+    constexpr int MAXROW = LDS_BYTES / NWC / 32;                        // bytes per slab row this wave may use
+    constexpr int TS_RAW = (MAXROW - 16) / (32 * ES);
+    constexpr int TS = TS_RAW >= TO ? TO : TS_RAW;                      // output tiles staged per pass
+    static_assert(TS >= 1, "LDS ring too small for the epilogue slab");
+    constexpr int RS = TS * 32 * ES + 16;                               // slab row stride (16-B pad)
+    constexpr int CPR = TS * 32 * ES / 16;                              // 16-B chunks per slab row
+    const int l31 = lane & 31, hi = lane >> 5;
+    char* slab = smem + (size_t)wave_c * 32 * RS;
+    const int ocol0 = EPI == EPI_GEGLU ? (wcol0 >> 1) : wcol0;         // first output column of this wave
+    const int NO = EPI == EPI_GEGLU ? (p.N >> 1) : p.N;                 // output columns
 #pragma unroll
-        for (int j = 0; j < TN; j += 2) {
-            const int cb = wcol0 + j * 32;                  // first value column of this 64-block
-            if (cb + 64 > p.N) continue;
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int nl = 8 * g + 4 * hi;
-                float bv[4] = {0, 0, 0, 0}, bg[4] = {0, 0, 0, 0};
-                if (p.bias) {
-                    const float4 t0 = *(const float4*)(p.bias + cb + nl), t1 = *(const float4*)(p.bias + cb + 32 + nl);
-                    bv[0] = t0.x; bv[1] = t0.y; bv[2] = t0.z; bv[3] = t0.w; bg[0] = t1.x; bg[1] = t1.y; bg[2] = t1.z; bg[3] = t1.w;
-                }
+        for (int t0 = 0; t0 < TO; t0 += TS) {
+            // ---- registers -> slab (this wave's 32 rows x up to TS*32 columns)
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int row = wrow0 + i * 32 + l31;
-                    if (row >= p.M) continue;
-                    float o[4];
+            for (int tt = 0; tt < TS; ++tt) {
+                const int t = t0 + tt;
+                if (t >= TO) break;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float v = acc[i][j][4 * g + e] + bv[e], gt = acc[i][j + 1][4 * g + e] + bg[e];
-                        o[e] = v * (0.5f * gt * (1.f + erff(gt * 0.70710678118654752440f)));
+                for (int g = 0; g < 4; ++g) {
+                    const int cl = 8 * g + 4 * hi;                      // column inside the 32-wide tile
+                    float v[4];
+                    if constexpr (EPI == EPI_GEGLU) {
+                        const int cb = wcol0 + 2 * t * 32;              // packed rows: per 64-block [32 value | 32 gate]
+                        float bv[4] = {0, 0, 0, 0}, bg[4] = {0, 0, 0, 0};
+                        if (p.bias && cb + 64 <= p.N) {
+                            const float4 b0 = *(const float4*)(p.bias + cb + cl), b1 = *(const float4*)(p.bias + cb + 32 + cl);
+                            bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bg[0] = b1.x; bg[1] = b1.y; bg[2] = b1.z; bg[3] = b1.w;
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float val = acc[i][2 * t][4 * g + e] + bv[e], gt = acc[i][2 * t + 1][4 * g + e] + bg[e];
+                            v[e] = val * (0.5f * gt * (1.f + erff(gt * 0.70710678118654752440f)));
+                        }
+                    } else {
+                        const int col = wcol0 + t * 32 + cl;
+                        float bv[4] = {0, 0, 0, 0};
+                        if (p.bias && col < p.N) { const float4 b0 = *(const float4*)(p.bias + col); bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[i][t][4 * g + e] + bv[e];
+                        if constexpr (EPI == EPI_BF16_TEMB) {
+                            int row = wrow0 + i * 32 + l31; if (row >= p.M) row = p.M - 1;
+                            if (col < p.N) {
+                                const float4 tv = *(const float4*)(p.temb + (size_t)(row / p.rows_per_batch) * p.temb_ld + col);
+                                v[0] += tv.x; v[1] += tv.y; v[2] += tv.z; v[3] += tv.w;
+                            }
+                        }
                     }
-                    uint2 w; w.x = pack_bf16x2(o[0], o[1]); w.y = pack_bf16x2(o[2], o[3]);
-                    *(uint2*)(out + (size_t)row * p.ldo + (cb >> 1) + nl) = w;
+                    char* dst = slab + l31 * RS + (tt * 32 + cl) * ES;
+                    if constexpr (F32) *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+                    else { uint2 w; w.x = pack_bf16x2(v[0], v[1]); w.y = pack_bf16x2(v[2], v[3]); *(uint2*)dst = w; }
                 }
             }
-        }
-    } else {
+            // ---- slab -> HBM, row-contiguous 16-B chunks (LDS operations of one wave execute in order)
+            const int ncol_pass = (TO - t0 < TS ? TO - t0 : TS) * 32;   // columns staged in this pass
+            const int cpr_pass = ncol_pass * ES / 16;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int col = wcol0 + j * 32 + 8 * g + 4 * hi;
-                if (col >= p.N) continue;
-                float bv[4] = {0, 0, 0, 0};
-                if (p.bias) { const float4 t = *(const float4*)(p.bias + col); bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w; }
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int row = wrow0 + i * 32 + l31;
-                    if (row >= p.M) continue;
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + bv[e];
-                    if constexpr (EPI == EPI_BF16_TEMB) {
-                        const float4 t = *(const float4*)(p.temb + (size_t)(row / p.rows_per_batch) * p.temb_ld + col);
-                        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-                    }
-                    if constexpr (EPI == EPI_F32) {
-                        if (p.res) { const float4 t = *(const float4*)(p.res + (size_t)row * p.ldres + col); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
-                        *(float4*)((float*)p.out + (size_t)row * p.ldo + col) = make_float4(v[0], v[1], v[2], v[3]);
-                    } else {
-                        uint2 w; w.x = pack_bf16x2(v[0], v[1]); w.y = pack_bf16x2(v[2], v[3]);
-                        *(uint2*)((bf16_t*)p.out + (size_t)row * p.ldo + col) = w;
-                    }
+            for (int idx0 = 0; idx0 < 32 * CPR; idx0 += 64) {
+                const int idx = idx0 + lane;
+                const int r = idx / cpr_pass, ch = idx - r * cpr_pass;
+                if (r >= 32) continue;
+                const int row = wrow0 + i * 32 + r;
+                const int col = ocol0 + t0 * 32 + ch * (16 / ES);
+                if (row >= p.M || col >= NO) continue;
+                const uint4 q = *(const uint4*)(slab + r * RS + ch * 16);
+                if constexpr (F32) {
+                    float4 o = make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w));
+                    if (p.res) { const float4 rv = *(const float4*)(p.res + (size_t)row * p.ldres + col); o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w; }
+                    *(float4*)((float*)p.out + (size_t)row * p.ldo + col) = o;
+                } else {
+                    *(uint4*)((bf16_t*)p.out + (size_t)row * p.ldo + col) = q;
                 }
             }
         }
@@ -282,7 +302,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     for (; kt + S - 1 < nk; ++kt) ktile(kt, std::true_type{}, std::false_type{});
     for (; kt + 1 < nk; ++kt) ktile(kt, std::false_type{}, std::false_type{});
     for (; kt < nk; ++kt) ktile(kt, std::false_type{}, std::true_type{});
-    gemm_epilogue<EPI, TM, TN>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), l31, hi);
+    __syncthreads();      // every wave is done with the LDS ring: it becomes the epilogue's transpose slabs
+    gemm_epilogue<EPI, TM, TN, NW, S * STAGE>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane, wave, smem);
 }
 
 // ================================================================================================
@@ -381,6 +402,7 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void gemm_ws_kernel(GemmArgs p
             __builtin_amdgcn_s_barrier();
             if (kt + 2 < nk) stage((kt + 2) % 3, KMAPW(kt + 2));
         }
+        __builtin_amdgcn_s_barrier();      // pairs with the compute waves' barrier in front of their epilogue
         return;
     }
     // ---------------------------------------------------------------------- compute wave
@@ -426,7 +448,8 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void gemm_ws_kernel(GemmArgs p
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    gemm_epilogue<EPI, TM, TN>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), l31, hi);
+    __builtin_amdgcn_s_barrier();          // all compute waves left the ring (the loaders arrive here too)
+    gemm_epilogue<EPI, TM, TN, NWC, 3 * STAGE>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane, wave, smem);
 }
 
 // ---------------------------------------------------------------------------------------------- launch
@@ -563,6 +586,8 @@ void launch_gemm(const GemmArgs& a, hipStream_t st) {
     }
     if (a.epi == EPI_GEGLU) RT_REQUIRE(a.N % 64 == 0, "geglu: N must be a multiple of 64");
     RT_REQUIRE(a.N % 4 == 0, "gemm: N must be a multiple of 4");
+    if (a.epi == EPI_BF16 || a.epi == EPI_BF16_TEMB) RT_REQUIRE(a.N % 8 == 0 && a.ldo % 8 == 0, "gemm: bf16 output needs N % 8 == 0");
+    if (a.epi == EPI_GEGLU) RT_REQUIRE(a.N % 16 == 0 && a.ldo % 8 == 0, "gemm: GEGLU output needs N % 16 == 0");
     RT_REQUIRE(a.ldo % 4 == 0 && ((uintptr_t)a.out & 15) == 0, "gemm: output must be 16-B aligned with ldo % 4 == 0");
     if (a.res) RT_REQUIRE(a.ldres % 4 == 0 && ((uintptr_t)a.res & 15) == 0, "gemm: residual must be 16-B aligned");
     if (a.bias) RT_REQUIRE(((uintptr_t)a.bias & 15) == 0, "gemm: bias must be 16-B aligned");
