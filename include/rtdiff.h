@@ -93,7 +93,10 @@ int rt_get_latents(rt_engine* e, float* latents_out, float* latents_ref_out /* m
 /* one iteration of the rich-text loop (rd.py:99-173 / xl.py:779-872 without colour guidance):
  * all R+1 / R+3 UNet forwards batched, mask combine, CFG, scheduler step, background blend */
 int rt_region_step(rt_engine* e, int step_index, float guidance_scale, float inject_selfattn, float inject_background,
-                   int xl_semantics, int elide_dead_forwards);
+                   int xl_semantics, int flags /* bit 0: elide reference forwards that cannot influence the output;
+                                                  bit 1: defer the background blend to rt_background_blend() */);
+/* the deferred blend of the last step (colour guidance sits between the scheduler step and the blend: rd.py:151-173) */
+int rt_background_blend(rt_engine* e);
 /* one iteration of the plain-text loop (rd.py:200-214 / xl.py:880-905): batch-2 forward, CFG, step */
 int rt_plain_step(rt_engine* e, int step_index, float guidance_scale);
 
@@ -143,6 +146,39 @@ const char* rt_op_last_error(void);
  * All configurations give bit-identical results. */
 int rt_op_gemm_force_config(int cfg);
 int rt_op_gemm_debug(int flags);   /* ablation probes (results are WRONG when non-zero): 1 no DMA in k loop, 2 no MFMA */
+
+/* ---- VAE decoder: colour guidance (rd.py:151-168, xl.py:849-867) and plain decode (rd.py:227-236) ----
+ * AutoencoderKL.decoder + post_quant_conv (diffusers 0.18.2, third party: architecture restated in oracle/vae.py).
+ * Weight names are the AutoencoderKL state_dict keys ("decoder.conv_in.weight", "post_quant_conv.bias", ...). */
+typedef struct rt_vae_config {
+    int n_blocks;                         /* len(block_out_channels) */
+    int block_out_channels[RT_MAX_LEVELS];
+    int layers_per_block;                 /* decoder uses layers_per_block + 1 resnets per up block */
+    int norm_groups;
+    float scaling_factor;                 /* 0.18215 (SD) / 0.13025 (SDXL) */
+    int latent_h, latent_w;               /* largest latent the workspace is sized for */
+} rt_vae_config;
+typedef struct rt_vae rt_vae;
+int rt_vae_create(const rt_vae_config* cfg, int device, rt_vae** out);
+int rt_vae_destroy(rt_vae* v);
+const char* rt_vae_last_error(rt_vae* v);
+int rt_vae_weight_count(rt_vae* v);
+int rt_vae_weight_info(rt_vae* v, int idx, char* name, int name_cap, int64_t* shape4, int* ndim);
+int rt_vae_bind_weight(rt_vae* v, const char* name, const void* dev_ptr, int dtype, const int64_t* shape, int ndim);
+int rt_vae_synchronize(rt_vae* v);
+/* img_out [3, 8h, 8w] f32 in [-1,1] = decode(latents [4,h,w] / scaling_factor if divide_by_scaling) */
+int rt_vae_decode(rt_vae* v, const float* latents, int h, int w, int divide_by_scaling, float* img_out);
+/* one guidance update, in place on `latents` [4,h,w]:
+ *   x0 = (latents - noise_pred*sqrt(1-alpha_t))/sqrt(alpha_t); img = clamp(decode(x0/scaling)/2+.5, 0, 1)
+ *   L = sum_k 100 * mse(sum(img*m_k)/sum(m_k), target_k);  latents -= dL/dlatents * weight * mask_all
+ * masks_img [n, 8h*8w] (channel 0 of text_format_dict['color_obj_atten']), target_rgb_host [n*3],
+ * mask_all [4,h,w] (text_format_dict['color_obj_atten_all']); grad_out [4,h,w] / loss_out_host optional. */
+int rt_vae_color_guidance(rt_vae* v, float* latents, const float* noise_pred, float alpha_t, int h, int w, const float* masks_img,
+                          const float* target_rgb_host, int n_regions, float weight, const float* mask_all, float* grad_out,
+                          float* loss_out_host);
+/* engine sampler state pointers for the guidance step: latents [4,h,w] and the CFG-combined noise prediction of the
+ * last rt_region_step (noise_pred in rd.py:131-132 / xl.py:824-825) */
+int rt_get_state_ptrs(rt_engine* e, float** latents, float** noise_pred);
 
 #ifdef __cplusplus
 }

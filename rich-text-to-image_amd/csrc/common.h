@@ -146,6 +146,7 @@ struct PackArgs {
     int c_inner, ci_valid;
     long s_r, s_co, s_ci;
     float scale;
+    long s_base;                      // constant source offset (flipped conv taps for the backward-data weights)
 };
 void launch_pack(const PackArgs& a, hipStream_t st);
 
@@ -156,3 +157,43 @@ struct PrepArgs {
     bf16_t* dst; int B, HW;
 };
 void launch_prep_latents(const PrepArgs& a, hipStream_t st);
+
+// ---------------------------------------------------------------- VAE decoder forward / backward-data helpers (a13)
+// GroupNorm(+SiLU) backward wrt the input: dx = rstd * (dxh - mean_g(dxh) - xh * mean_g(dxh * xh)),
+// dxh = dA * silu'(y) * gamma, y = xh*gamma + beta, xh = (x - mean) * rstd; statistics are recomputed from the
+// forward pass' partial sums.  `add` (fp32, may be null) is accumulated into the result (residual gradients).
+struct GroupNormBwdArgs {
+    const void* x; int x_bf16;         // forward input [B, HW, C]
+    const bf16_t* dA;                  // gradient wrt the (activated) output [B, HW, C]
+    const float* fwd_partial;          // forward statistics partials [B, nchunk, G, 2]
+    float* bwd_partial;                // workspace [B, nchunk, G, 2]
+    const float* gamma; const float* beta; float eps;
+    int silu, C, G, B, HW, nchunk, rows_per_chunk;
+    const float* add;                  // optional fp32 [B, HW, C]
+    float* out;                        // fp32 [B, HW, C] (may be null)
+    bf16_t* out_bf16;                  // optional bf16 copy (operand of the next backward conv)
+};
+void launch_groupnorm_bwd(const GroupNormBwdArgs& a, hipStream_t st);
+void launch_transpose_bf16(const bf16_t* in, bf16_t* out, int R, int C, hipStream_t st);        // [R,C] -> [C,R]
+void launch_softmax_rows(const float* s, bf16_t* p, int rows, int cols, float scale, hipStream_t st);
+// dS = scale * P o (dP - rowsum(dP o P))   (bf16 out)
+void launch_softmax_bwd(const bf16_t* p, const float* dp, bf16_t* ds, int rows, int cols, float scale, hipStream_t st);
+void launch_sumpool2x2(const float* in, float* out, int B, int H, int W, int C, hipStream_t st);   // [B,2H,2W,C] -> [B,H,W,C]
+void launch_add_f32(const float* a, const float* b, float* out, size_t n, hipStream_t st);
+// per pixel: out[pix][0..7] = bf16(W[4x4] * (in[c][pix] * scale) + b), channels 4..7 zero  (post_quant_conv 1x1)
+void launch_pq_conv_fwd(const float* lat_nchw, const float* eps_nchw, float c_lat, float c_eps, const float* W, const float* b,
+                        bf16_t* out, int HW, hipStream_t st);
+// dlat[c][pix] = sum_o W[o][c] * dz[pix][o] * gscale ;  lat -= dlat * weight * mask_all
+void launch_pq_conv_bwd_update(const float* dz, int ldz, const float* W, float gscale, float weight, const float* mask_all,
+                               float* lat_nchw, float* grad_out /* optional [4,HW] */, int HW, hipStream_t st);
+struct ColorLossArgs {
+    const float* img; int ldi;         // decoder output [HWi, ldi] fp32 (3 valid channels), range [-1, 1]
+    const float* masks;                // [n, HWi]
+    const float* target;               // [n, 3] device
+    int n, HWi;
+    float* partial;                    // [nblk, n, 4] workspace
+    int nblk;
+    bf16_t* dimg;                      // [HWi, 8] bf16 gradient wrt the decoder output
+    float* loss_out;                   // [1] optional
+};
+void launch_color_loss_grad(const ColorLossArgs& a, hipStream_t st);

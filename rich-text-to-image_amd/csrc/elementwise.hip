@@ -34,7 +34,7 @@ __global__ void pack_kernel(PackArgs p) {
         ok = ok && ci < p.ci_valid;
         float v = 0.f;
         if (ok) {
-            const long off = srow * p.s_r + co * p.s_co + ci * p.s_ci;
+            const long off = p.s_base + srow * p.s_r + co * p.s_co + ci * p.s_ci;
             if (p.src_dtype == 0) v = ((const float*)p.src)[off];
             else if (p.src_dtype == 1) v = __half2float(((const __half*)p.src)[off]);
             else v = bf16_to_f32(((const bf16_t*)p.src)[off]);

@@ -128,6 +128,7 @@ void launch_gather_add_rows(const float* base, const float* table, const int* /*
 void launch_inject_add(float* out, const float* sc, const float* hres, const int* /*host*/ src, int B, size_t per_batch, hipStream_t st);
 void launch_nhwc4_to_nchw(const float* in, float* out, int B, int HW, hipStream_t st);
 void launch_pad_ctx(const float* ctx, bf16_t* out, int P, int D, hipStream_t st);
+void launch_background_blend(float* lat, const float* lat_ref, const float* mask_last, int n, hipStream_t st);
 
 #include "step.h"
 
@@ -166,6 +167,7 @@ struct rt_engine {
     int n_regions = 0, mask_hw = 0;
     float* lat = nullptr;            // [4, HW]
     float* lat_ref = nullptr;
+    float* noise_pred = nullptr;     // [4, HW] CFG-combined prediction of the last step (guidance input)
     float* eps = nullptr;            // [maxB, HW, 4]
     float* ets = nullptr;            // PNDM history [4][2][4*HW]
     float* cur_sample = nullptr;     // PNDM [2][4*HW]
@@ -358,7 +360,7 @@ struct rt_engine {
         aug_emb = (float*)sarena.alloc((size_t)cfg.max_prompts * temb_dim * 4);
         wabs = (float*)sarena.alloc(2 * 96 * 4); wsgn = (float*)sarena.alloc(2 * 96 * 4);
         masks = (float*)sarena.alloc((size_t)RT_MAXB * 4 * HW * 4);
-        lat = (float*)sarena.alloc(4 * HW * 4); lat_ref = (float*)sarena.alloc(4 * HW * 4);
+        lat = (float*)sarena.alloc(4 * HW * 4); lat_ref = (float*)sarena.alloc(4 * HW * 4); noise_pred = (float*)sarena.alloc(4 * HW * 4);
         eps = (float*)sarena.alloc((size_t)cfg.max_streams * HW * 4 * 4);
         ets = (float*)sarena.alloc((size_t)4 * 2 * 4 * HW * 4);
         cur_sample = (float*)sarena.alloc((size_t)2 * 4 * HW * 4);
@@ -725,7 +727,8 @@ struct rt_engine {
     }
 
     // ---------------------------------------------------------------------------- step drivers
-    void region_step(int i, float g, float inject_selfattn, float inject_background, bool xl, bool elide);
+    void region_step(int i, float g, float inject_selfattn, float inject_background, bool xl, bool elide, bool defer_blend);
+    bool pending_blend = false;
     void plain_step(int i, float g);
 };
 
@@ -888,8 +891,17 @@ int rt_get_latents(rt_engine* e, float* out, float* out_ref) {
         if (out_ref) HIP_CHECK(hipMemcpyAsync(out_ref, e->lat_ref, n, hipMemcpyDeviceToDevice, e->stream));
     })
 }
+int rt_get_state_ptrs(rt_engine* e, float** latents, float** noise_pred) {
+    RT_TRY(e, { need_device(e); HIP_CHECK(hipStreamSynchronize(e->stream)); *latents = e->lat; *noise_pred = e->noise_pred; })
+}
 int rt_region_step(rt_engine* e, int i, float g, float isa, float ibg, int xl, int elide) {
-    RT_TRY(e, { need_device(e); e->region_step(i, g, isa, ibg, xl != 0, elide != 0); })
+    RT_TRY(e, { need_device(e); e->region_step(i, g, isa, ibg, xl != 0, (elide & 1) != 0, (elide & 2) != 0); })
+}
+int rt_background_blend(rt_engine* e) {
+    RT_TRY(e, {
+        need_device(e);
+        if (e->pending_blend) { launch_background_blend(e->lat, e->lat_ref, e->masks + (size_t)(e->n_regions - 1) * 4 * e->mask_hw, 4 * e->mask_hw, e->stream); e->pending_blend = false; }
+    })
 }
 int rt_plain_step(rt_engine* e, int i, float g) { RT_TRY(e, { need_device(e); e->plain_step(i, g); }) }
 

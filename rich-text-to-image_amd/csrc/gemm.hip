@@ -513,6 +513,7 @@ static void launch_with_cfg(const GemmArgs& a, int cfg, hipStream_t st) {
         case A_DENSE * 4 + EPI_F32: launch_me<A_DENSE, EPI_F32>(a, cfg, st); break;
         case A_DENSE * 4 + EPI_BF16_TEMB: launch_me<A_DENSE, EPI_BF16_TEMB>(a, cfg, st); break;
         case A_DENSE * 4 + EPI_GEGLU: launch_me<A_DENSE, EPI_GEGLU>(a, cfg, st); break;
+        case A_CONV3 * 4 + EPI_BF16: launch_me<A_CONV3, EPI_BF16>(a, cfg, st); break;     // VAE decoder convs (no time embedding) and backward-data
         case A_CONV3 * 4 + EPI_F32: launch_me<A_CONV3, EPI_F32>(a, cfg, st); break;
         case A_CONV3 * 4 + EPI_BF16_TEMB: launch_me<A_CONV3, EPI_BF16_TEMB>(a, cfg, st); break;
         case A_CONV3_S2 * 4 + EPI_F32: launch_me<A_CONV3_S2, EPI_F32>(a, cfg, st); break;

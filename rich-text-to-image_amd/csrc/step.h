@@ -21,6 +21,7 @@ struct StepArgs {
     float* cur_sample;     // PNDM: [2][4*HW]
     int push;
     int blend;             // lat = lat_ref * M[R-1] + lat * (1 - M[R-1]) after the update
+    float* noise_pred;     // optional [4, HW]: CFG-combined prediction of the main stream (input of the guidance step)
 };
 
 struct IdxList { int v[RT_MAXB]; };

@@ -35,6 +35,10 @@ __global__ void step_epilogue_kernel(StepArgs p) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) e[c] = nu[c] + p.g * (nt[c] - nu[c]);
     }
+    if (p.noise_pred) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) p.noise_pred[(size_t)c * p.HW + pix] = e[c];
+    }
     const bool has_ref = p.s_uref >= 0 && p.step_ref;
     if (has_ref) {
         const float4 a = ld4(p.s_uref), b = ld4(p.s_tref);
@@ -142,5 +146,15 @@ __global__ void pad_ctx_kernel(const float* ctx, bf16_t* out, int P, int D) {
 }
 void launch_pad_ctx(const float* ctx, bf16_t* out, int P, int D, hipStream_t st) {
     hipLaunchKernelGGL(pad_ctx_kernel, dim3(cdiv(P * 96 * D, 256)), dim3(256), 0, st, ctx, out, P, D);
+    HIP_CHECK(hipGetLastError());
+}
+
+// lat = lat_ref * M + lat * (1 - M)   (rd.py:171-173, xl.py:870-872) as a separate launch when colour guidance has to run
+// between the scheduler step and the blend
+__global__ void background_blend_kernel(float* lat, const float* lat_ref, const float* m, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) lat[i] = lat_ref[i] * m[i] + lat[i] * (1.f - m[i]);
+}
+void launch_background_blend(float* lat, const float* lat_ref, const float* mask_last, int n, hipStream_t st) {
+    hipLaunchKernelGGL(background_blend_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, lat, lat_ref, mask_last, n);
     HIP_CHECK(hipGetLastError());
 }

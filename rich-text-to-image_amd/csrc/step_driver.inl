@@ -32,7 +32,7 @@ static void pndm_coeffs(rt_engine* e, int i, StepArgs& a) {
     e->pndm_counter++;
 }
 
-void rt_engine::region_step(int i, float g, float isa, float ibg, bool xl, bool elide) {
+void rt_engine::region_step(int i, float g, float isa, float ibg, bool xl, bool elide, bool defer_blend) {
     require_bound();
     const int n = (int)timesteps.size(), R = n_regions;
     RT_REQUIRE(i >= 0 && i < n, "region_step: step index out of range");
@@ -80,7 +80,9 @@ void rt_engine::region_step(int i, float g, float isa, float ibg, bool xl, bool 
     unet_forward(in);
 
     a.eps = eps; a.masks = masks; a.lat = lat; a.lat_ref = lat_ref; a.HW = lat_h * lat_w; a.R = R; a.g = g; a.plain = 0;
-    a.sched = sched_kind; a.step_ref = step_ref ? 1 : 0; a.blend = blend ? 1 : 0;
+    a.noise_pred = noise_pred;
+    a.sched = sched_kind; a.step_ref = step_ref ? 1 : 0; a.blend = (blend && !defer_blend) ? 1 : 0;
+    pending_blend = blend && defer_blend;
     if (sched_kind == RT_SCHED_EULER) a.dsigma = table[i + 1] - table[i];
     else pndm_coeffs(this, i, a);
     launch_step_epilogue(a, stream);

@@ -1,0 +1,464 @@
+// VAE decoder forward + input-gradient (backward-data only) for the colour-guidance step, and plain decode.
+//
+// Replaces `self.vae.decode(...)` + `loss_total.backward()` of the reference's guidance block
+// (models/region_diffusion.py:151-168, models/region_diffusion_sdxl.py:849-867) and the final decode
+// (rd.py:227-236, xl.py:916-944).  AutoencoderKL itself is third-party (diffusers 0.18.2, not on disk): the graph
+// below follows the oracle restatement oracle/vae.py (parity unpinned against diffusers, pinned against the oracle
+// incl. its torch-autograd gradient).  Only d(loss)/d(latents) is needed: no weight gradients, and the UNet is not
+// differentiated (noise_pred is a constant in predict_x0).
+// All contractions (3x3 convs, their backward-data = 3x3 conv with flipped/transposed weights, linears, attention
+// score/PV GEMMs and their adjoints) run on the MFMA GEMM of gemm.hip with bf16 operands and fp32 accumulation.
+#include "common.h"
+#include "../../include/rtdiff.h"
+#include "vae.h"
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+struct Arena2 {
+    char* base = nullptr; size_t off = 0, cap = 0;
+    void* alloc(size_t bytes) {
+        off = (off + 255) & ~(size_t)255;
+        void* p = base ? base + off : (void*)(uintptr_t)(off + 256);
+        off += bytes;
+        if (base && off > cap) throw rt_error(RT_E_STATE, "vae: arena overflow");
+        return p;
+    }
+};
+struct NormW { float* g = nullptr; float* b = nullptr; int C = 0; };
+struct MatW { bf16_t* w = nullptr; float* b = nullptr; int N = 0, K = 0; };
+struct VConv { MatW f, b; int cin = 0, cout = 0, cinP = 0, coutP = 0; };
+struct VLin { MatW f, b; };
+struct VRes { std::string name; NormW n1, n2; VConv c1, c2; bool has_sc = false; VLin sc; int cin = 0, cout = 0; };
+struct VAttn { NormW gn; VLin q, k, v, o; int C = 0; };
+struct Slot { std::string name; std::vector<int64_t> shape; std::vector<PackArgs> packs; bool bound = false; };
+
+struct ResSaved { const float* x; float* part1; bf16_t* h2; float* part2; int H, W; };
+struct AttnSaved { const float* x; float* part; bf16_t *q, *k, *v, *P; int N; };
+}  // namespace
+
+struct rt_vae {
+    rt_vae_config cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    Arena2 arena;
+    char* arena_base = nullptr; size_t arena_bytes = 0;
+    char* ws_base = nullptr; size_t ws_cap = 0, ws_off = 0, ws_peak = 0;
+    bool dry = false;
+    bf16_t* zero = nullptr;
+    std::vector<Slot> slots;
+    std::map<std::string, int> slot_index;
+    // plan
+    float* pq_w = nullptr; float* pq_b = nullptr;
+    VConv conv_in, conv_out;
+    VRes mid0, mid1;
+    VAttn attn;
+    std::vector<std::vector<VRes>> up_res;
+    std::vector<VConv> up_conv;      // size n-1
+    NormW norm_out;
+    int G = 32;
+
+    // ---------------------------------------------------------------- memory
+    void* walloc(size_t bytes) {
+        ws_off = (ws_off + 255) & ~(size_t)255;
+        void* p = ws_base ? ws_base + ws_off : (void*)(uintptr_t)(ws_off + 256);
+        ws_off += bytes;
+        if (ws_off > ws_peak) ws_peak = ws_off;
+        if (!dry && ws_off > ws_cap) throw rt_error(RT_E_STATE, "vae: workspace overflow");
+        return p;
+    }
+    float* f32(size_t n) { return (float*)walloc(n * 4); }
+    bf16_t* b16(size_t n) { return (bf16_t*)walloc(n * 2); }
+
+    // ---------------------------------------------------------------- plan
+    void add_slot(const std::string& name, std::vector<int64_t> shape, std::vector<PackArgs> packs) {
+        Slot s; s.name = name; s.shape = std::move(shape); s.packs = std::move(packs);
+        slot_index[name] = (int)slots.size(); slots.push_back(s);
+    }
+    static PackArgs pk_vec(void* dst, int n) {
+        PackArgs p{}; p.dst = dst; p.dst_f32 = 1; p.rows = n; p.cols = 1; p.ld_dst = 1; p.row_map = PACK_ROWS_ID; p.c_inner = 1; p.ci_valid = 1;
+        p.s_r = 1; p.scale = 1.f; return p;
+    }
+    NormW mk_norm(const std::string& n, int C) {
+        NormW w; w.C = C; w.g = (float*)arena.alloc((size_t)C * 4); w.b = (float*)arena.alloc((size_t)C * 4);
+        add_slot(n + ".weight", {C}, {pk_vec(w.g, C)}); add_slot(n + ".bias", {C}, {pk_vec(w.b, C)});
+        return w;
+    }
+    // 3x3 conv: forward [CoutN][tap][CinP] and backward-data [CinN][flipped tap][CoutP]
+    VConv mk_conv3(const std::string& n, int Cin, int Cout) {
+        VConv c; c.cin = Cin; c.cout = Cout; c.cinP = (Cin + 7) & ~7; c.coutP = (Cout + 7) & ~7;
+        const int CoutN = (Cout + 3) & ~3, CinN = (Cin + 3) & ~3;      // GEMM N must be a multiple of 4
+        c.f.N = CoutN; c.f.K = 9 * c.cinP; c.f.w = (bf16_t*)arena.alloc((size_t)CoutN * c.f.K * 2);
+        c.f.b = (float*)arena.alloc((size_t)CoutN * 4);
+        c.b.N = CinN; c.b.K = 9 * c.coutP; c.b.w = (bf16_t*)arena.alloc((size_t)CinN * c.b.K * 2);
+        PackArgs pf{}; pf.dst = c.f.w; pf.rows = Cout; pf.cols = c.f.K; pf.ld_dst = c.f.K; pf.row_map = PACK_ROWS_ID; pf.c_inner = c.cinP;
+        pf.ci_valid = Cin; pf.s_r = (long)Cin * 9; pf.s_co = 1; pf.s_ci = 9; pf.scale = 1.f;
+        PackArgs pb{}; pb.dst = c.b.w; pb.rows = Cin; pb.cols = c.b.K; pb.ld_dst = c.b.K; pb.row_map = PACK_ROWS_ID; pb.c_inner = c.coutP;
+        pb.ci_valid = Cout; pb.s_r = 9; pb.s_co = -1; pb.s_ci = (long)Cin * 9; pb.s_base = 8; pb.scale = 1.f;
+        add_slot(n + ".weight", {Cout, Cin, 3, 3}, {pf, pb});
+        add_slot(n + ".bias", {Cout}, {pk_vec(c.f.b, Cout)});
+        return c;
+    }
+    // Linear / 1x1 conv [N, K]: forward as is, backward-data transposed [K, N]
+    VLin mk_lin(const std::string& n, int K, int N, bool conv1x1, bool bias = true) {
+        VLin l; l.f.N = N; l.f.K = K; l.f.w = (bf16_t*)arena.alloc((size_t)N * K * 2);
+        l.b.N = K; l.b.K = N; l.b.w = (bf16_t*)arena.alloc((size_t)N * K * 2);
+        PackArgs pf{}; pf.dst = l.f.w; pf.rows = N; pf.cols = K; pf.ld_dst = K; pf.row_map = PACK_ROWS_ID; pf.c_inner = K; pf.ci_valid = K;
+        pf.s_r = K; pf.s_ci = 1; pf.scale = 1.f;
+        PackArgs pb{}; pb.dst = l.b.w; pb.rows = K; pb.cols = N; pb.ld_dst = N; pb.row_map = PACK_ROWS_ID; pb.c_inner = N; pb.ci_valid = N;
+        pb.s_r = 1; pb.s_ci = K; pb.scale = 1.f;
+        std::vector<int64_t> shp = conv1x1 ? std::vector<int64_t>{N, K, 1, 1} : std::vector<int64_t>{N, K};
+        add_slot(n + ".weight", shp, {pf, pb});
+        if (bias) { l.f.b = (float*)arena.alloc((size_t)N * 4); add_slot(n + ".bias", {N}, {pk_vec(l.f.b, N)}); }
+        return l;
+    }
+    VRes mk_res(const std::string& n, int cin, int cout) {
+        RT_REQUIRE(cin % 8 == 0 && cout % 8 == 0, "vae: channel counts must be multiples of 8");
+        VRes r; r.name = n; r.cin = cin; r.cout = cout;
+        r.n1 = mk_norm(n + ".norm1", cin); r.c1 = mk_conv3(n + ".conv1", cin, cout);
+        r.n2 = mk_norm(n + ".norm2", cout); r.c2 = mk_conv3(n + ".conv2", cout, cout);
+        r.has_sc = cin != cout;
+        if (r.has_sc) r.sc = mk_lin(n + ".conv_shortcut", cin, cout, true);
+        return r;
+    }
+    void build_plan() {
+        slots.clear(); slot_index.clear(); up_res.clear(); up_conv.clear();
+        G = cfg.norm_groups;
+        const int n = cfg.n_blocks;
+        zero = (bf16_t*)arena.alloc(256);
+        pq_w = (float*)arena.alloc(16 * 4); pq_b = (float*)arena.alloc(4 * 4);
+        { PackArgs p{}; p.dst = pq_w; p.dst_f32 = 1; p.rows = 4; p.cols = 4; p.ld_dst = 4; p.row_map = PACK_ROWS_ID; p.c_inner = 4; p.ci_valid = 4;
+          p.s_r = 4; p.s_ci = 1; p.scale = 1.f; add_slot("post_quant_conv.weight", {4, 4, 1, 1}, {p}); }
+        add_slot("post_quant_conv.bias", {4}, {pk_vec(pq_b, 4)});
+        const int top = cfg.block_out_channels[n - 1];
+        conv_in = mk_conv3("decoder.conv_in", 4, top);
+        mid0 = mk_res("decoder.mid_block.resnets.0", top, top);
+        const std::string a = "decoder.mid_block.attentions.0";
+        attn.C = top;
+        attn.gn = mk_norm(a + ".group_norm", top);
+        attn.q = mk_lin(a + ".to_q", top, top, false); attn.k = mk_lin(a + ".to_k", top, top, false);
+        attn.v = mk_lin(a + ".to_v", top, top, false); attn.o = mk_lin(a + ".to_out.0", top, top, false);
+        mid1 = mk_res("decoder.mid_block.resnets.1", top, top);
+        int out_c = top;
+        for (int i = 0; i < n; ++i) {
+            const int prev = out_c; out_c = cfg.block_out_channels[n - 1 - i];
+            std::vector<VRes> rs;
+            for (int j = 0; j < cfg.layers_per_block + 1; ++j)
+                rs.push_back(mk_res("decoder.up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), j == 0 ? prev : out_c, out_c));
+            up_res.push_back(rs);
+            if (i != n - 1) up_conv.push_back(mk_conv3("decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv", out_c, out_c));
+        }
+        norm_out = mk_norm("decoder.conv_norm_out", cfg.block_out_channels[0]);
+        conv_out = mk_conv3("decoder.conv_out", cfg.block_out_channels[0], 3);
+    }
+    void require_bound() { for (auto& s : slots) if (!s.bound) throw rt_error(RT_E_MISSING_WEIGHT, "vae weight not bound: " + s.name); }
+
+    // ---------------------------------------------------------------- launch helpers
+    void gemm(const bf16_t* A, int lda, const MatW& W, int M, void* out, int ldo, int epi, const float* res = nullptr, int ldres = 0, bool bias = true) {
+        if (dry) return;
+        GemmArgs g{}; g.A = A; g.W = W.w; g.bias = bias ? W.b : nullptr; g.out = out; g.res = res; g.zero = zero; g.mode = A_DENSE; g.epi = epi;
+        g.M = M; g.N = W.N; g.K = W.K; g.lda = lda; g.ldw = W.K; g.ldo = ldo; g.ldres = ldres;
+        launch_gemm(g, stream);
+    }
+    // raw operands (attention score / PV GEMMs)
+    void gemm_raw(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, int N, int K, void* out, int ldo, int epi) {
+        if (dry) return;
+        GemmArgs g{}; g.A = A; g.W = W; g.out = out; g.zero = zero; g.mode = A_DENSE; g.epi = epi; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldo = ldo;
+        launch_gemm(g, stream);
+    }
+    void conv3(const bf16_t* in, int mode, const MatW& W, int H, int Wd, int CinP, void* out, int epi, const float* res = nullptr, bool bias = true) {
+        if (dry) return;
+        int Ho = H, Wo = Wd;
+        if (mode == A_CONV3_UP2) { Ho = 2 * H; Wo = 2 * Wd; }
+        GemmArgs g{}; g.A = in; g.W = W.w; g.bias = bias ? W.b : nullptr; g.out = out; g.res = res; g.zero = zero; g.mode = mode; g.epi = epi;
+        g.M = Ho * Wo; g.N = W.N; g.K = W.K; g.ldw = W.K; g.ldo = W.N; g.ldres = W.N; g.rows_per_batch = Ho * Wo; g.Hin = H; g.Win = Wd; g.Cin = CinP;
+        g.Hout = Ho; g.Wout = Wo;
+        RT_REQUIRE(W.K == 9 * CinP, "vae conv: weight/input channel mismatch");
+        launch_gemm(g, stream);
+    }
+    float* gn_fwd(const void* x, bool x_bf16, int C, int HW, const NormW& n, bool silu, bf16_t* out, bf16_t* raw) {
+        const int nchunk = groupnorm_nchunk(HW);
+        float* part = f32((size_t)nchunk * G * 2);
+        if (dry) return part;
+        GroupNormArgs a{}; a.x1 = x; a.in_bf16 = x_bf16; a.C1 = C; a.C2 = 0; a.G = G; a.B = 1; a.HW = HW; a.gamma = n.g; a.beta = n.b; a.eps = 1e-6f;
+        a.silu = silu; a.out = out; a.raw_out = raw; a.partial = part; a.nchunk = nchunk; a.rows_per_chunk = groupnorm_rows_per_chunk(HW);
+        launch_groupnorm(a, stream);
+        return part;
+    }
+    void gn_bwd(const void* x, bool x_bf16, const bf16_t* dA, const float* fwd_part, int C, int HW, const NormW& n, bool silu, const float* add,
+                float* out, bf16_t* out_b) {
+        const int nchunk = groupnorm_nchunk(HW);
+        float* bp = f32((size_t)nchunk * G * 2);
+        if (dry) return;
+        GroupNormBwdArgs a{}; a.x = x; a.x_bf16 = x_bf16; a.dA = dA; a.fwd_partial = fwd_part; a.bwd_partial = bp; a.gamma = n.g; a.beta = n.b; a.eps = 1e-6f;
+        a.silu = silu; a.C = C; a.G = G; a.B = 1; a.HW = HW; a.nchunk = nchunk; a.rows_per_chunk = groupnorm_rows_per_chunk(HW); a.add = add; a.out = out;
+        a.out_bf16 = out_b;
+        launch_groupnorm_bwd(a, stream);
+    }
+    bf16_t* cast(const float* x, size_t n) { bf16_t* o = b16(n); if (!dry) launch_cast_f32_bf16(x, o, n, stream); return o; }
+
+    // ---------------------------------------------------------------- blocks
+    float* res_fwd(const VRes& r, const float* x, int H, int W, ResSaved* sv) {
+        const size_t HW = (size_t)H * W;
+        bf16_t* h1 = b16(HW * r.cin);
+        bf16_t* raw = r.has_sc ? b16(HW * r.cin) : nullptr;
+        float* p1 = gn_fwd(x, false, r.cin, (int)HW, r.n1, true, h1, raw);
+        bf16_t* h2 = b16(HW * r.cout);
+        conv3(h1, A_CONV3, r.c1.f, H, W, r.cin, h2, EPI_BF16);
+        bf16_t* h3 = b16(HW * r.cout);
+        float* p2 = gn_fwd(h2, true, r.cout, (int)HW, r.n2, true, h3, nullptr);
+        float* out = f32(HW * r.cout);
+        const float* resid = x;
+        if (r.has_sc) { gemm(raw, r.cin, r.sc.f, (int)HW, out, r.cout, EPI_F32); resid = out; }
+        conv3(h3, A_CONV3, r.c2.f, H, W, r.cout, out, EPI_F32, resid);
+        if (sv) { sv->x = x; sv->part1 = p1; sv->h2 = h2; sv->part2 = p2; sv->H = H; sv->W = W; }
+        return out;
+    }
+    float* res_bwd(const VRes& r, const ResSaved& sv, const float* dOut) {
+        const int H = sv.H, W = sv.W; const size_t HW = (size_t)H * W;
+        bf16_t* dOb = cast(dOut, HW * r.cout);
+        bf16_t* dH3 = b16(HW * r.cout);
+        conv3(dOb, A_CONV3, r.c2.b, H, W, r.cout, dH3, EPI_BF16, nullptr, false);
+        bf16_t* dH2 = b16(HW * r.cout);
+        gn_bwd(sv.h2, true, dH3, sv.part2, r.cout, (int)HW, r.n2, true, nullptr, nullptr, dH2);
+        bf16_t* dH1 = b16(HW * r.cin);
+        conv3(dH2, A_CONV3, r.c1.b, H, W, r.cout, dH1, EPI_BF16, nullptr, false);
+        const float* skip = dOut;
+        if (r.has_sc) { float* s = f32(HW * r.cin); gemm(dOb, r.cout, r.sc.b, (int)HW, s, r.cin, EPI_F32, nullptr, 0, false); skip = s; }
+        float* dX = f32(HW * r.cin);
+        gn_bwd(sv.x, false, dH1, sv.part1, r.cin, (int)HW, r.n1, true, skip, dX, nullptr);
+        return dX;
+    }
+    float* attn_fwd(const float* x, int N, AttnSaved* sv) {
+        const int C = attn.C;
+        bf16_t* g = b16((size_t)N * C);
+        float* part = gn_fwd(x, false, C, N, attn.gn, false, g, nullptr);
+        bf16_t* q = b16((size_t)N * C); bf16_t* k = b16((size_t)N * C); bf16_t* v = b16((size_t)N * C);
+        gemm(g, C, attn.q.f, N, q, C, EPI_BF16); gemm(g, C, attn.k.f, N, k, C, EPI_BF16); gemm(g, C, attn.v.f, N, v, C, EPI_BF16);
+        bf16_t* vT = b16((size_t)N * C);
+        if (!dry) launch_transpose_bf16(v, vT, N, C, stream);
+        float* S = f32((size_t)N * N);
+        gemm_raw(q, C, k, C, N, N, C, S, N, EPI_F32);
+        bf16_t* P = b16((size_t)N * N);
+        if (!dry) launch_softmax_rows(S, P, N, N, 1.f / std::sqrt((float)C), stream);
+        bf16_t* O = b16((size_t)N * C);
+        gemm_raw(P, N, vT, N, N, C, N, O, C, EPI_BF16);
+        float* out = f32((size_t)N * C);
+        gemm(O, C, attn.o.f, N, out, C, EPI_F32, x, C);
+        if (sv) { sv->x = x; sv->part = part; sv->q = q; sv->k = k; sv->v = v; sv->P = P; sv->N = N; }
+        return out;
+    }
+    float* attn_bwd(const AttnSaved& sv, const float* dOut) {
+        const int C = attn.C, N = sv.N;
+        bf16_t* dOb = cast(dOut, (size_t)N * C);
+        bf16_t* dO = b16((size_t)N * C);
+        gemm(dOb, C, attn.o.b, N, dO, C, EPI_BF16, nullptr, 0, false);
+        // dV = P^T dO
+        bf16_t* PT = b16((size_t)N * N); bf16_t* dOT = b16((size_t)N * C);
+        if (!dry) { launch_transpose_bf16(sv.P, PT, N, N, stream); launch_transpose_bf16(dO, dOT, N, C, stream); }
+        bf16_t* dV = b16((size_t)N * C);
+        gemm_raw(PT, N, dOT, N, N, C, N, dV, C, EPI_BF16);
+        // dP = dO V^T ; dS = scale * P o (dP - rowsum(dP o P))
+        float* dP = f32((size_t)N * N);
+        gemm_raw(dO, C, sv.v, C, N, N, C, dP, N, EPI_F32);
+        bf16_t* dS = PT;                                          // P^T is dead: reuse
+        if (!dry) launch_softmax_bwd(sv.P, dP, dS, N, N, 1.f / std::sqrt((float)C), stream);
+        // dQ = dS K ; dK = dS^T Q
+        bf16_t* kT = b16((size_t)N * C); bf16_t* qT = b16((size_t)N * C); bf16_t* dST = b16((size_t)N * N);
+        if (!dry) { launch_transpose_bf16(sv.k, kT, N, C, stream); launch_transpose_bf16(sv.q, qT, N, C, stream); launch_transpose_bf16(dS, dST, N, N, stream); }
+        bf16_t* dQ = b16((size_t)N * C); bf16_t* dK = b16((size_t)N * C);
+        gemm_raw(dS, N, kT, N, N, C, N, dQ, C, EPI_BF16);
+        gemm_raw(dST, N, qT, N, N, C, N, dK, C, EPI_BF16);
+        float* dg = f32((size_t)N * C);
+        gemm(dQ, C, attn.q.b, N, dg, C, EPI_F32, nullptr, 0, false);
+        gemm(dK, C, attn.k.b, N, dg, C, EPI_F32, dg, C, false);
+        gemm(dV, C, attn.v.b, N, dg, C, EPI_F32, dg, C, false);
+        bf16_t* dgb = cast(dg, (size_t)N * C);
+        float* dX = f32((size_t)N * C);
+        gn_bwd(sv.x, false, dgb, sv.part, C, N, attn.gn, false, dOut, dX, nullptr);
+        return dX;
+    }
+
+    // ---------------------------------------------------------------- decoder forward (+ tape)
+    struct Tape { std::vector<ResSaved> res; AttnSaved attn; std::vector<std::pair<int, int>> up_hw; const float* last_x; float* part_out; int Hi, Wi; };
+    float* forward(const float* lat, const float* eps, float c_lat, float c_eps, int h, int w, Tape* tp) {
+        RT_REQUIRE(h <= cfg.latent_h && w <= cfg.latent_w, "vae: latent larger than configured");
+        const size_t hw = (size_t)h * w;
+        bf16_t* z8 = b16(hw * 8);
+        if (!dry) launch_pq_conv_fwd(lat, eps, c_lat, c_eps, pq_w, pq_b, z8, (int)hw, stream);
+        float* x = f32(hw * conv_in.f.N);
+        conv3(z8, A_CONV3, conv_in.f, h, w, 8, x, EPI_F32);
+        ResSaved rs; AttnSaved as;
+        x = res_fwd(mid0, x, h, w, &rs); if (tp) tp->res.push_back(rs);
+        x = attn_fwd(x, (int)hw, &as); if (tp) tp->attn = as;
+        x = res_fwd(mid1, x, h, w, &rs); if (tp) tp->res.push_back(rs);
+        int H = h, W = w;
+        for (size_t i = 0; i < up_res.size(); ++i) {
+            for (auto& r : up_res[i]) { x = res_fwd(r, x, H, W, &rs); if (tp) tp->res.push_back(rs); }
+            if (i + 1 < up_res.size()) {
+                const int C = up_conv[i].cin;
+                bf16_t* xb = cast(x, (size_t)H * W * C);
+                float* y = f32((size_t)4 * H * W * C);
+                conv3(xb, A_CONV3_UP2, up_conv[i].f, H, W, C, y, EPI_F32);
+                if (tp) tp->up_hw.push_back({H, W});
+                H *= 2; W *= 2; x = y;
+            }
+        }
+        const int C0 = cfg.block_out_channels[0];
+        bf16_t* hn = b16((size_t)H * W * C0);
+        float* part = gn_fwd(x, false, C0, H * W, norm_out, true, hn, nullptr);
+        float* img = f32((size_t)H * W * conv_out.f.N);          // [HWi, 4], channel 3 is padding
+        conv3(hn, A_CONV3, conv_out.f, H, W, C0, img, EPI_F32);
+        if (tp) { tp->last_x = x; tp->part_out = part; tp->Hi = H; tp->Wi = W; }
+        return img;
+    }
+    // d(loss)/d(z1) where z1 = post_quant_conv output, given dimg (bf16 [HWi, 8])
+    float* backward(const Tape& tp, const bf16_t* dimg, int h, int w) {
+        int H = tp.Hi, W = tp.Wi;
+        const int C0 = cfg.block_out_channels[0];
+        bf16_t* dHn = b16((size_t)H * W * C0);
+        conv3(dimg, A_CONV3, conv_out.b, H, W, 8, dHn, EPI_BF16, nullptr, false);
+        float* dX = f32((size_t)H * W * C0);
+        gn_bwd(tp.last_x, false, dHn, tp.part_out, C0, H * W, norm_out, true, nullptr, dX, nullptr);
+        int ri = (int)tp.res.size() - 1;
+        for (int i = (int)up_res.size() - 1; i >= 0; --i) {
+            if (i + 1 < (int)up_res.size()) {
+                const int C = up_conv[i].cin;
+                bf16_t* dYb = cast(dX, (size_t)H * W * C);
+                float* dUp = f32((size_t)H * W * C);
+                conv3(dYb, A_CONV3, up_conv[i].b, H, W, C, dUp, EPI_F32, nullptr, false);
+                H /= 2; W /= 2;
+                float* d = f32((size_t)H * W * C);
+                if (!dry) launch_sumpool2x2(dUp, d, 1, H, W, C, stream);
+                dX = d;
+            }
+            for (int j = (int)up_res[i].size() - 1; j >= 0; --j) dX = res_bwd(up_res[i][j], tp.res[ri--], dX);
+        }
+        dX = res_bwd(mid1, tp.res[ri--], dX);
+        dX = attn_bwd(tp.attn, dX);
+        dX = res_bwd(mid0, tp.res[ri--], dX);
+        bf16_t* dXb = cast(dX, (size_t)h * w * conv_in.cout);
+        float* dz = f32((size_t)h * w * 4);
+        conv3(dXb, A_CONV3, conv_in.b, h, w, conv_in.coutP, dz, EPI_F32, nullptr, false);
+        return dz;
+    }
+};
+
+// ================================================================================================ C ABI
+static thread_local std::string g_vae_create_error;
+#define VAE_TRY(v, ...)                                                          \
+    try { __VA_ARGS__; return RT_OK; }                                          \
+    catch (const rt_error& ex) { (v)->err = ex.what(); return ex.code; }        \
+    catch (const std::exception& ex) { (v)->err = ex.what(); return RT_E_INVALID; }
+
+static void vae_need_device(rt_vae* v) { if (!v->arena_base) throw rt_error(RT_E_STATE, "vae engine has no device (weight-table-only)"); }
+
+// workspace estimate by a dry run of decode + guidance at the largest latent
+static size_t vae_measure(rt_vae* v) {
+    v->dry = true; v->ws_off = 0; v->ws_peak = 0;
+    rt_vae::Tape tp;
+    float* img = v->forward(nullptr, nullptr, 1.f, 0.f, v->cfg.latent_h, v->cfg.latent_w, &tp);
+    (void)img;
+    v->b16((size_t)tp.Hi * tp.Wi * 8); v->f32(4096 * 16 * 4 + 64);
+    v->backward(tp, nullptr, v->cfg.latent_h, v->cfg.latent_w);
+    v->dry = false;
+    const size_t peak = v->ws_peak; v->ws_off = 0;
+    return peak + (1 << 20);
+}
+
+extern "C" {
+int rt_vae_create(const rt_vae_config* cfg, int device, rt_vae** out) {
+    rt_vae* v = nullptr;
+    try {
+        RT_REQUIRE(cfg && out, "rt_vae_create: null argument");
+        RT_REQUIRE(cfg->n_blocks >= 2 && cfg->n_blocks <= 4 && cfg->layers_per_block >= 1, "rt_vae_create: bad config");
+        v = new rt_vae(); v->cfg = *cfg; v->device = device;
+        v->arena = Arena2(); v->build_plan();
+        v->arena_bytes = v->arena.off + 256;
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0 || device < 0) { *out = v; return RT_OK; }
+        HIP_CHECK(hipSetDevice(device));
+        HIP_CHECK(hipStreamCreate(&v->stream));
+        HIP_CHECK(hipMalloc((void**)&v->arena_base, v->arena_bytes));
+        HIP_CHECK(hipMemset(v->arena_base, 0, v->arena_bytes));
+        v->arena = Arena2(); v->arena.base = v->arena_base; v->arena.cap = v->arena_bytes; v->build_plan();
+        v->ws_cap = vae_measure(v);
+        HIP_CHECK(hipMalloc((void**)&v->ws_base, v->ws_cap));
+        *out = v; return RT_OK;
+    } catch (const std::exception& ex) { g_vae_create_error = ex.what(); delete v; return RT_E_INVALID; }
+}
+int rt_vae_destroy(rt_vae* v) {
+    if (!v) return RT_OK;
+    if (v->arena_base) { (void)hipSetDevice(v->device); (void)hipStreamSynchronize(v->stream); (void)hipFree(v->arena_base); (void)hipFree(v->ws_base); (void)hipStreamDestroy(v->stream); }
+    delete v; return RT_OK;
+}
+const char* rt_vae_last_error(rt_vae* v) { return v ? v->err.c_str() : g_vae_create_error.c_str(); }
+int rt_vae_weight_count(rt_vae* v) { return (int)v->slots.size(); }
+int rt_vae_weight_info(rt_vae* v, int idx, char* name, int cap, int64_t* shape4, int* ndim) {
+    VAE_TRY(v, {
+        RT_REQUIRE(idx >= 0 && idx < (int)v->slots.size(), "rt_vae_weight_info: index");
+        const Slot& s = v->slots[idx];
+        RT_REQUIRE((int)s.name.size() < cap, "rt_vae_weight_info: name buffer too small");
+        std::strcpy(name, s.name.c_str()); *ndim = (int)s.shape.size();
+        for (size_t i = 0; i < s.shape.size(); ++i) shape4[i] = s.shape[i];
+    })
+}
+int rt_vae_bind_weight(rt_vae* v, const char* name, const void* ptr, int dtype, const int64_t* shape, int ndim) {
+    VAE_TRY(v, {
+        vae_need_device(v);
+        std::string nm = name;
+        // pre-0.18 AttentionBlock names of older checkpoints
+        const char* alias[4][2] = {{".query.", ".to_q."}, {".key.", ".to_k."}, {".value.", ".to_v."}, {".proj_attn.", ".to_out.0."}};
+        for (auto& a : alias) { const size_t p = nm.find(a[0]); if (p != std::string::npos) nm.replace(p, std::strlen(a[0]), a[1]); }
+        auto it = v->slot_index.find(nm);
+        if (it == v->slot_index.end()) throw rt_error(RT_E_INVALID, std::string("unknown vae weight: ") + name);
+        Slot& s = v->slots[it->second];
+        long n_in = 1, n_exp = 1;
+        for (int i = 0; i < ndim; ++i) n_in *= shape[i];
+        for (auto d : s.shape) n_exp *= d;
+        RT_REQUIRE(n_in == n_exp, "rt_vae_bind_weight: element count mismatch");
+        RT_REQUIRE(dtype >= 0 && dtype <= 2, "rt_vae_bind_weight: dtype");
+        for (PackArgs p : s.packs) { p.src = ptr; p.src_dtype = dtype; launch_pack(p, v->stream); }
+        s.bound = true;
+    })
+}
+int rt_vae_synchronize(rt_vae* v) { VAE_TRY(v, { vae_need_device(v); HIP_CHECK(hipStreamSynchronize(v->stream)); }) }
+
+int rt_vae_decode(rt_vae* v, const float* latents, int h, int w, int divide_by_scaling, float* img_out) {
+    VAE_TRY(v, {
+        vae_need_device(v); v->require_bound();
+        v->ws_off = 0;
+        const float c = divide_by_scaling ? 1.f / v->cfg.scaling_factor : 1.f;
+        float* img = v->forward(latents, nullptr, c, 0.f, h, w, nullptr);
+        launch_nhwc4_to_nchw3(img, img_out, 8 * h * 8 * w, v->stream);
+        HIP_CHECK(hipStreamSynchronize(v->stream));
+    })
+}
+
+int rt_vae_color_guidance(rt_vae* v, float* latents, const float* noise_pred, float alpha_t, int h, int w, const float* masks_img,
+                          const float* target_rgb_host, int n_regions, float weight, const float* mask_all, float* grad_out, float* loss_out_host) {
+    VAE_TRY(v, {
+        vae_need_device(v); v->require_bound();
+        RT_REQUIRE(alpha_t > 0.f && alpha_t < 1.f, "rt_vae_color_guidance: alpha_t");
+        v->ws_off = 0;
+        // x0 = (lat - eps*sqrt(1-a))/sqrt(a); z0 = x0 / scaling   (predict_x0: rd.py:176-178, xl.py:955-957)
+        const float sa = std::sqrt(alpha_t), s1 = std::sqrt(1.f - alpha_t), sc = v->cfg.scaling_factor;
+        rt_vae::Tape tp;
+        float* img = v->forward(latents, noise_pred, 1.f / (sa * sc), -s1 / (sa * sc), h, w, &tp);
+        const int HWi = tp.Hi * tp.Wi;
+        float* tgt = v->f32((size_t)n_regions * 3 + 4);
+        HIP_CHECK(hipMemcpyAsync(tgt, target_rgb_host, (size_t)n_regions * 12, hipMemcpyHostToDevice, v->stream));
+        ColorLossArgs c{}; c.img = img; c.ldi = v->conv_out.f.N; c.masks = masks_img; c.target = tgt; c.n = n_regions; c.HWi = HWi;
+        c.nblk = 1024; c.partial = v->f32((size_t)c.nblk * n_regions * 4); c.dimg = v->b16((size_t)HWi * 8); c.loss_out = v->f32(4);
+        launch_color_loss_grad(c, v->stream);
+        float* dz = v->backward(tp, c.dimg, h, w);
+        launch_pq_conv_bwd_update(dz, 4, v->pq_w, 1.f / (sa * sc), weight, mask_all, latents, grad_out, h * w, v->stream);
+        if (loss_out_host) HIP_CHECK(hipMemcpyAsync(loss_out_host, c.loss_out, 4, hipMemcpyDeviceToHost, v->stream));
+        HIP_CHECK(hipStreamSynchronize(v->stream));
+    })
+}
+}  // extern "C"

@@ -67,7 +67,9 @@ _SYMBOLS = [
     "rt_region_step", "rt_plain_step", "rt_unet_forward", "rt_op_gemm", "rt_op_attention", "rt_op_groupnorm",
     "rt_op_layernorm", "rt_op_small_linear", "rt_op_timestep_embed", "rt_op_last_error", "rt_profile_enable",
     "rt_profile_read", "rt_op_gemm_force_config", "rt_op_gemm_debug", "rt_attn_store_enable", "rt_attn_store_reset",
-    "rt_attn_store_read", "rt_attn_module_count", "rt_attn_module_info",
+    "rt_attn_store_read", "rt_attn_module_count", "rt_attn_module_info", "rt_get_state_ptrs", "rt_background_blend", "rt_vae_create", "rt_vae_destroy",
+    "rt_vae_last_error", "rt_vae_weight_count", "rt_vae_weight_info", "rt_vae_bind_weight", "rt_vae_synchronize", "rt_vae_decode",
+    "rt_vae_color_guidance",
 ]
 
 
@@ -86,8 +88,10 @@ def load_library(path=None):
     lib.rt_last_error.restype = C.c_char_p
     lib.rt_op_last_error.restype = C.c_char_p
     lib.rt_last_error.argtypes = [C.c_void_p]
+    lib.rt_vae_last_error.restype = C.c_char_p
+    lib.rt_vae_last_error.argtypes = [C.c_void_p]
     for name in _SYMBOLS:
-        if name not in ("rt_last_error", "rt_op_last_error"):
+        if name not in ("rt_last_error", "rt_op_last_error", "rt_vae_last_error"):
             getattr(lib, name).restype = C.c_int
     if path is None:
         _lib = lib
@@ -295,6 +299,12 @@ class Engine:
         self._chk(self.lib.rt_attn_store_read(self.h, name.encode(), _ptr(out), C.byref(n), C.byref(r), C.byref(c)))
         return n.value, out
 
+    def state_ptrs(self):
+        """Device pointers of the sampler state: (latents [4,h,w], CFG-combined noise_pred of the last rich step)."""
+        a, b = C.c_void_p(), C.c_void_p()
+        self._chk(self.lib.rt_get_state_ptrs(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     # ---- profiling (HIP events around every MFMA kernel launch on the engine stream)
     PROF_CLASSES = {0: "gemm_kernel<A_DENSE>", 1: "gemm_kernel<A_CONV3*>", 2: "attn_kernel<self>", 3: "attn_kernel<cross>"}
 
@@ -318,9 +328,12 @@ class Engine:
         return (out, ref) if with_ref else out
 
     # ---- hot path
-    def region_step(self, i, guidance_scale, inject_selfattn=0.0, inject_background=0.0, xl=True, elide=False):
+    def region_step(self, i, guidance_scale, inject_selfattn=0.0, inject_background=0.0, xl=True, elide=False, defer_blend=False):
         self._chk(self.lib.rt_region_step(self.h, i, C.c_float(guidance_scale), C.c_float(inject_selfattn),
-                                          C.c_float(inject_background), int(xl), int(elide)))
+                                          C.c_float(inject_background), int(xl), int(bool(elide)) | (2 if defer_blend else 0)))
+
+    def background_blend(self):
+        self._chk(self.lib.rt_background_blend(self.h))
 
     def plain_step(self, i, guidance_scale):
         self._chk(self.lib.rt_plain_step(self.h, i, C.c_float(guidance_scale)))
@@ -338,3 +351,98 @@ class Engine:
                                            iarr(fontsize), iarr(qk_src), iarr(res_src), _ptr(out)))
         self.synchronize()
         return out
+
+
+# ------------------------------------------------------------------------------------------------ VAE decoder
+SD_VAE_CONFIG = dict(block_out_channels=(128, 256, 512, 512), layers_per_block=2, norm_num_groups=32, scaling_factor=0.18215)
+SDXL_VAE_CONFIG = dict(block_out_channels=(128, 256, 512, 512), layers_per_block=2, norm_num_groups=32, scaling_factor=0.13025)
+
+
+class RtVaeConfig(C.Structure):
+    _fields_ = [("n_blocks", C.c_int), ("block_out_channels", C.c_int * RT_MAX_LEVELS), ("layers_per_block", C.c_int),
+                ("norm_groups", C.c_int), ("scaling_factor", C.c_float), ("latent_h", C.c_int), ("latent_w", C.c_int)]
+
+
+class VaeDecoder:
+    """AutoencoderKL decoder on the engine: `.decode(z)` (same call surface as diffusers' `vae.decode(z).sample`) and
+    the colour-guidance update of the rich-text loop (rd.py:151-168 / xl.py:849-867)."""
+
+    def __init__(self, cfg, latent_h, latent_w, device=0, state_dict=None):
+        self.lib = load_library()
+        c = RtVaeConfig()
+        boc = tuple(cfg["block_out_channels"])
+        c.n_blocks = len(boc)
+        for i, v in enumerate(boc):
+            c.block_out_channels[i] = v
+        c.layers_per_block = cfg["layers_per_block"]
+        c.norm_groups = cfg["norm_num_groups"]
+        c.scaling_factor = cfg["scaling_factor"]
+        c.latent_h, c.latent_w = latent_h, latent_w
+        self.cfg, self.cfg_dict, self.device = c, dict(cfg), device
+        self.scaling_factor = cfg["scaling_factor"]
+        self.h = C.c_void_p()
+        rc = self.lib.rt_vae_create(C.byref(c), device, C.byref(self.h))
+        if rc != 0:
+            raise RtError(rc, self.lib.rt_vae_last_error(None).decode())
+        if state_dict is not None:
+            self.load_state_dict(state_dict)
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise RtError(rc, self.lib.rt_vae_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.rt_vae_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def weight_table(self):
+        n = self.lib.rt_vae_weight_count(self.h)
+        name = C.create_string_buffer(256)
+        shape, nd = (C.c_int64 * 4)(), C.c_int()
+        out = []
+        for i in range(n):
+            self._chk(self.lib.rt_vae_weight_info(self.h, i, name, 256, shape, C.byref(nd)))
+            out.append((name.value.decode(), tuple(shape[k] for k in range(nd.value))))
+        return out
+
+    def load_state_dict(self, sd):
+        import torch
+        dev = f"cuda:{self.device}"
+        for name, _ in self.weight_table():
+            t = sd[name].to(dev).contiguous()
+            dt = {torch.float32: DTYPE_F32, torch.float16: DTYPE_F16, torch.bfloat16: DTYPE_BF16}[t.dtype]
+            shape = (C.c_int64 * max(1, t.dim()))(*t.shape)
+            self._chk(self.lib.rt_vae_bind_weight(self.h, name.encode(), _ptr(t), dt, shape, t.dim()))
+        self._chk(self.lib.rt_vae_synchronize(self.h))
+
+    def decode(self, z, divide_by_scaling=False):
+        """z [1,4,h,w] -> image [1,3,8h,8w] in [-1,1]"""
+        import torch
+        z = z.contiguous().float()
+        _, _, h, w = z.shape
+        out = torch.empty(1, 3, 8 * h, 8 * w, device=z.device)
+        self._chk(self.lib.rt_vae_decode(self.h, _ptr(z), h, w, int(divide_by_scaling), _ptr(out)))
+        return out
+
+    def color_guidance(self, latents_ptr_or_tensor, noise_pred, alpha_t, h, w, color_obj_atten, target_rgb, weight, color_obj_atten_all,
+                       want_grad=False):
+        """In-place update of `latents` (tensor [1,4,h,w] or raw device pointer) exactly as rd.py:151-168."""
+        import torch
+        masks = torch.cat([m[:, 0].reshape(1, -1) for m in color_obj_atten]).contiguous().float().to(f"cuda:{self.device}")
+        tgt = [float(v) for t in target_rgb for v in t.flatten().tolist()]
+        mall = color_obj_atten_all.contiguous().float().to(f"cuda:{self.device}")
+        grad = torch.empty(1, 4, h, w, device=f"cuda:{self.device}") if want_grad else None
+        loss = C.c_float()
+        lp = latents_ptr_or_tensor if isinstance(latents_ptr_or_tensor, int) else latents_ptr_or_tensor.data_ptr()
+        npp = noise_pred if isinstance(noise_pred, int) else noise_pred.data_ptr()
+        self._chk(self.lib.rt_vae_color_guidance(self.h, C.c_void_p(lp), C.c_void_p(npp), C.c_float(float(alpha_t)), h, w, _ptr(masks),
+                                                 (C.c_float * len(tgt))(*tgt), len(color_obj_atten), C.c_float(float(weight)), _ptr(mall),
+                                                 _ptr(grad), C.byref(loss)))
+        return loss.value, grad

@@ -45,8 +45,8 @@ class RegionDiffusion:
                         elide_dead_forwards=False):
         if latents is None:
             latents = torch.randn((1, self.unet.in_channels, height // 8, width // 8), device=self.device)
-        if use_guidance:
-            raise NotImplementedError("colour guidance (rd.py:151-168) needs the VAE decoder gradient: SURVEY 8a row a13, next round")
+        if use_guidance and not hasattr(self.vae, "color_guidance"):
+            raise RuntimeError("use_guidance=True needs a rich_text_to_image_amd.engine.VaeDecoder as `vae` (rd.py:151-168)")
         n_styles = text_embeddings.shape[0] - 1
         assert n_styles == len(self.masks)                                  # rd.py:97
         h, w = latents.shape[2], latents.shape[3]
@@ -58,8 +58,15 @@ class RegionDiffusion:
         eng.set_fontsize(tfd.get("word_pos"), tfd.get("font_size"))
         eng.set_schedule(1, self.scheduler.timesteps.tolist(), self.scheduler.table(), num_inference_steps)
         eng.set_latents(latents.to(self.device))
-        for i in range(len(self.scheduler.timesteps)):
-            eng.region_step(i, guidance_scale, inject_selfattn, inject_background, xl=False, elide=elide_dead_forwards)
+        for i, t in enumerate(self.scheduler.timesteps):
+            eng.region_step(i, guidance_scale, inject_selfattn, inject_background, xl=False, elide=elide_dead_forwards,
+                            defer_blend=use_guidance)
+            if use_guidance:
+                if t < tfd['guidance_start_step']:                           # rd.py:151
+                    lat_ptr, eps_ptr = eng.state_ptrs()
+                    self.vae.color_guidance(lat_ptr, eps_ptr, float(self.scheduler.alphas_cumprod[int(t)]), h, w, tfd['color_obj_atten'],
+                                            tfd['target_RGB'], tfd['color_guidance_weight'], tfd['color_obj_atten_all'])
+                eng.background_blend()
         return eng.read_latents(h, w)
 
     def predict_x0(self, x_t, eps_t, t):                                    # rd.py:176-178
@@ -100,7 +107,8 @@ class RegionDiffusion:
             raise NotImplementedError("VAE decode is SURVEY 8f row f2 (next); pass a `vae` with .decode(z).sample")
         latents = 1 / 0.18215 * latents
         with torch.no_grad():
-            imgs = self.vae.decode(latents).sample
+            imgs = self.vae.decode(latents)
+            imgs = getattr(imgs, "sample", imgs)               # diffusers-style object or the engine's VaeDecoder tensor
         return (imgs / 2 + 0.5).clamp(0, 1)
 
     def latents_to_uint8(self, latents):

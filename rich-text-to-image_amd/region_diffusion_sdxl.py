@@ -66,8 +66,8 @@ class RegionDiffusionXL:
         do_cfg = guidance_scale > 1.0
         if run_rich_text and do_cfg and guidance_rescale > 0.0:
             raise NotImplementedError                                                              # xl.py:827-830
-        if use_guidance:
-            raise NotImplementedError("colour guidance (xl.py:849-867) needs the VAE decoder gradient: SURVEY 8a row a13, next round")
+        if use_guidance and not hasattr(self.vae, "color_guidance"):
+            raise RuntimeError("use_guidance=True needs a rich_text_to_image_amd.engine.VaeDecoder as `vae` (xl.py:849-867)")
         self.scheduler.set_timesteps(num_inference_steps)
         h, w = height // self.vae_scale_factor, width // self.vae_scale_factor
         if latents is None:
@@ -88,7 +88,15 @@ class RegionDiffusionXL:
             tfd = text_format_dict or {}
             eng.set_fontsize(tfd.get("word_pos"), tfd.get("font_size"))
             for i in range(n):
-                eng.region_step(i, guidance_scale, inject_selfattn, inject_background, xl=True, elide=elide_dead_forwards)
+                eng.region_step(i, guidance_scale, inject_selfattn, inject_background, xl=True, elide=elide_dead_forwards,
+                                defer_blend=use_guidance)
+                if use_guidance:
+                    t = float(self.scheduler.timesteps[i])
+                    if t < tfd['guidance_start_step']:                   # xl.py:849; predict_x0 on the unscaled Euler latents (quirk 4)
+                        lat_ptr, eps_ptr = eng.state_ptrs()
+                        self.vae.color_guidance(lat_ptr, eps_ptr, float(self.scheduler.alphas_cumprod[int(t)]), h, w, tfd['color_obj_atten'],
+                                                tfd['target_RGB'], tfd['color_guidance_weight'], tfd['color_obj_atten_all'])
+                    eng.background_blend()
                 if callback is not None and i % callback_steps == 0:
                     callback(i, self.scheduler.timesteps[i], eng.read_latents(h, w))
         else:
@@ -105,7 +113,14 @@ class RegionDiffusionXL:
         if self.vae is None:
             raise NotImplementedError("VAE decode is SURVEY 8f row f2 (next); pass a `vae` with .decode(z) or use output_type='latent'")
         image = self.vae.decode(latents / self.vae_scaling_factor)
-        return StableDiffusionXLPipelineOutput(images=image)
+        image = getattr(image, "sample", image)
+        if output_type == "pt":
+            return StableDiffusionXLPipelineOutput(images=image)
+        arr = ((image / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).cpu().numpy() * 255).round().astype("uint8")    # VaeImageProcessor.postprocess
+        if output_type == "np":
+            return StableDiffusionXLPipelineOutput(images=arr)
+        from PIL import Image
+        return StableDiffusionXLPipelineOutput(images=[Image.fromarray(a) for a in arr])
 
     def predict_x0(self, x_t, eps_t, t):                                                           # xl.py:955-957
         a = torch.tensor(self.scheduler.alphas_cumprod)[int(t)].to(x_t.device)

@@ -69,3 +69,12 @@ def test_invalid_config_is_rejected():
     bad = dict(TINY_XL_CONFIG, down_block_types=("AttnDownBlock2D",) * 3)
     with pytest.raises(ValueError):
         Engine(bad, 32, 32, device=-1)
+
+
+def test_vae_weight_table_matches_autoencoderkl_decoder_layout():
+    from oracle.vae import SD_VAE_CONFIG, TINY_VAE_CONFIG, vae_decoder_shapes
+    from rich_text_to_image_amd.engine import VaeDecoder
+    for cfg in (SD_VAE_CONFIG, TINY_VAE_CONFIG):
+        v = VaeDecoder(cfg, 64, 64, device=-1)                 # weight-table-only (no GPU)
+        assert {n: tuple(s) for n, s in v.weight_table()} == {k: tuple(s) for k, s in vae_decoder_shapes(cfg).items()}
+        v.close()
