@@ -1,0 +1,117 @@
+"""Checkpoint / text-side plumbing around the engine: diffusers-layout directory -> façade objects.
+
+Replaces `StableDiffusionPipeline / AutoencoderKL / CLIPTextModel.from_pretrained` at rd.py:26-33 and xl.py:95-130.
+The UNet and VAE decoder go to the HIP engine; the CLIP text encoders run ONCE per prompt set, off the hot path, in
+torch through `transformers` (their output is the engine's `rt_set_prompts` input).  No checkpoint exists offline,
+so only the prompt-encoding logic is unit-tested (tiny random CLIP).
+"""
+import glob
+import json
+import os
+
+import torch
+
+from .clip_tokenizer import ClipBPETokenizer
+
+
+def load_state_dict_dir(path, prefer=("diffusion_pytorch_model.safetensors", "diffusion_pytorch_model.fp16.safetensors", "model.safetensors",
+                                      "model.fp16.safetensors")):
+    """All tensors of the (possibly sharded) safetensors / .bin weights in one component directory."""
+    from safetensors.torch import load_file
+    for name in prefer:
+        f = os.path.join(path, name)
+        if os.path.exists(f):
+            return load_file(f)
+    shards = sorted(glob.glob(os.path.join(path, "*.safetensors")))
+    if shards:
+        sd = {}
+        for f in shards:
+            sd.update(load_file(f))
+        return sd
+    bins = sorted(glob.glob(os.path.join(path, "*.bin")))
+    if bins:
+        sd = {}
+        for f in bins:
+            sd.update(torch.load(f, map_location="cpu", weights_only=True))
+        return sd
+    raise FileNotFoundError(f"no weights under {path}")
+
+
+def _component_config(path):
+    f = os.path.join(path, "config.json")
+    return json.load(open(f)) if os.path.exists(f) else {}
+
+
+class ClipEncoderSD:
+    """rd.py:49-84: `text_encoder(ids)[0]` = last hidden state (with final layer norm)."""
+
+    def __init__(self, text_encoder, device):
+        self.enc = text_encoder.to(device).eval()
+        self.device = device
+
+    def __call__(self, input_ids):
+        with torch.no_grad():
+            return (self.enc(input_ids.to(self.device))[0].float(),)
+
+
+class ClipEncodersXL:
+    """xl.py:318-440 for the cases the rich-text flow uses (num_images_per_prompt=1, CFG on, no LoRA / textual inversion):
+    penultimate hidden states of both encoders concatenated on channels; pooled = projected embedding of encoder 2;
+    negative prompt `None` + force_zeros_for_empty_prompt => zeros, otherwise encoded at the same max_length."""
+
+    def __init__(self, tokenizers, text_encoders, device, force_zeros_for_empty_prompt=True):
+        self.tokenizers = tokenizers
+        self.encoders = [e.to(device).eval() for e in text_encoders]
+        self.device = device
+        self.force_zeros = force_zeros_for_empty_prompt
+
+    def _encode(self, texts, max_length=None):
+        hidden, pooled = [], None
+        for tok, enc in zip(self.tokenizers, self.encoders):
+            ids = tok(texts, padding="max_length", max_length=max_length or tok.model_max_length, truncation=True, return_tensors="pt").input_ids
+            with torch.no_grad():
+                out = enc(ids.to(self.device), output_hidden_states=True)
+            pooled = out[0]                                     # the LAST encoder's wins (xl.py:353)
+            hidden.append(out.hidden_states[-2])
+        return torch.cat(hidden, dim=-1).float(), pooled.float()
+
+    def __call__(self, prompt, negative_prompt):
+        prompt = [prompt] if isinstance(prompt, str) else list(prompt)
+        pe, pp = self._encode(prompt)
+        if negative_prompt is None and self.force_zeros:
+            return pe, torch.zeros_like(pe), pp, torch.zeros_like(pp)
+        neg = negative_prompt or ""
+        neg = [neg] if isinstance(neg, str) else list(neg)
+        ne, npool = self._encode(neg, max_length=pe.shape[1])
+        return pe, ne, pp, npool
+
+
+def load_pipeline(load_path, kind="SD", device=0, latent_hw=None):
+    """kind 'SD' -> RegionDiffusion, 'SDXL' -> RegionDiffusionXL, from a diffusers-layout directory
+    (unet/, vae/, tokenizer[_2]/, text_encoder[_2]/).  `latent_hw` sizes the VAE plan (default: the model's native size)."""
+    from transformers import CLIPTextModel, CLIPTextModelWithProjection
+    from .engine import SD_VAE_CONFIG, SDXL_VAE_CONFIG, VaeDecoder
+    dev = torch.device(f"cuda:{device}")
+    unet_sd = load_state_dict_dir(os.path.join(load_path, "unet"))
+    vae_sd = load_state_dict_dir(os.path.join(load_path, "vae"))
+    vae_cfg = dict(SD_VAE_CONFIG if kind == "SD" else SDXL_VAE_CONFIG)
+    sf = _component_config(os.path.join(load_path, "vae")).get("scaling_factor")
+    if sf:
+        vae_cfg["scaling_factor"] = sf
+    hw = latent_hw or ((64, 64) if kind == "SD" else (128, 128))
+    vae = VaeDecoder(vae_cfg, hw[0], hw[1], device=device, state_dict=vae_sd)
+    tok = ClipBPETokenizer.from_pretrained(load_path, "tokenizer")
+    if kind == "SD":
+        from .region_diffusion import RegionDiffusion
+        enc = CLIPTextModel.from_pretrained(os.path.join(load_path, "text_encoder"))
+        return RegionDiffusion(device, unet_state_dict=unet_sd, vae=vae, tokenizer=tok, text_encoder=ClipEncoderSD(enc, dev))
+    from .region_diffusion_sdxl import RegionDiffusionXL
+    tok2 = ClipBPETokenizer.from_pretrained(load_path, "tokenizer_2")
+    enc1 = CLIPTextModel.from_pretrained(os.path.join(load_path, "text_encoder"))
+    enc2 = CLIPTextModelWithProjection.from_pretrained(os.path.join(load_path, "text_encoder_2"))
+    fz = True
+    mi = os.path.join(load_path, "model_index.json")
+    if os.path.exists(mi):
+        fz = json.load(open(mi)).get("force_zeros_for_empty_prompt", True)
+    return RegionDiffusionXL(load_path, device, unet_state_dict=unet_sd, vae=vae, tokenizer=tok, vae_scaling_factor=vae_cfg["scaling_factor"],
+                             text_encoders=ClipEncodersXL([tok, tok2], [enc1, enc2], dev, fz))

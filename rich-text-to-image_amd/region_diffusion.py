@@ -104,7 +104,7 @@ class RegionDiffusion:
 
     def decode_latents(self, latents):                                      # rd.py:227-236
         if self.vae is None:
-            raise NotImplementedError("VAE decode is SURVEY 8f row f2 (next); pass a `vae` with .decode(z).sample")
+            raise RuntimeError("no VAE bound: pass `vae=` (engine.VaeDecoder or an object with .decode(z).sample)")
         latents = 1 / 0.18215 * latents
         with torch.no_grad():
             imgs = self.vae.decode(latents)
@@ -131,8 +131,10 @@ class RegionDiffusion:
         return self.latents_to_uint8(latents)
 
     # hook surface of the reference (rd.py:397-443): token-map capture is the "next" row f1
-    def reset_attention_maps(self):
-        self.attention_maps = None
+    def reset_attention_maps(self):                                         # rd.py:275-283
+        for maps in (self.selfattn_maps, self.crossattn_maps):
+            for key in (maps or {}):
+                maps[key] = []
 
     def register_tokenmap_hooks(self):
         """rd.py:397-443: record head-averaged maps of the conditional half during produce_attn_maps / plain_latents.

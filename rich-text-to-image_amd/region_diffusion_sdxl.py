@@ -17,7 +17,7 @@ class StableDiffusionXLPipelineOutput(dict):
 
 class RegionDiffusionXL:
     def __init__(self, load_path=None, device=0, unet_state_dict=None, config=None, vae=None, text_encoders=None,
-                 vae_scaling_factor=0.13025):
+                 vae_scaling_factor=0.13025, tokenizer=None):
         self.device_index = device if isinstance(device, int) else (torch.device(device).index or 0)
         self.device = torch.device(f"cuda:{self.device_index}")
         self.device_type = "cuda"
@@ -30,6 +30,13 @@ class RegionDiffusionXL:
         self.scheduler = EulerTables()
         self.masks = []
         self.selfattn_maps = self.crossattn_maps = self.n_maps = None
+        self.attention_maps = None                                   # xl.py:132 (only the evaluation hooks ever set it)
+        self.tokenizer = tokenizer                                   # richtext_utils needs `model.tokenizer._tokenize`
+
+    def reset_attention_maps(self):
+        for maps in (self.selfattn_maps, self.crossattn_maps):
+            for key in (maps or {}):
+                maps[key] = []
 
     def check_inputs(self, prompt, height, width, prompt_embeds, pooled_prompt_embeds):          # xl.py:462-519
         if height % 8 != 0 or width % 8 != 0:
@@ -111,7 +118,7 @@ class RegionDiffusionXL:
         if output_type == "latent":
             return StableDiffusionXLPipelineOutput(images=latents)
         if self.vae is None:
-            raise NotImplementedError("VAE decode is SURVEY 8f row f2 (next); pass a `vae` with .decode(z) or use output_type='latent'")
+            raise RuntimeError("no VAE bound: pass `vae=` (engine.VaeDecoder or an object with .decode(z)) or use output_type='latent'")
         image = self.vae.decode(latents / self.vae_scaling_factor)
         image = getattr(image, "sample", image)
         if output_type == "pt":
