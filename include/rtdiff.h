@@ -142,10 +142,10 @@ int rt_op_small_linear(const float* a, int lda, const void* W_bf16, int ldw, con
                        int B, int N, int K, int silu_in, int accumulate, void* stream);
 int rt_op_timestep_embed(const float* t, int n, int dim, float* out, int ldo, void* stream);
 const char* rt_op_last_error(void);
-/* GEMM tile configuration: -1 = auto-tune per shape (default); 0..3 force one (tests / micro-benchmarks).
+/* GEMM tile configuration: -1 = auto-tune per shape (default); 0..6 force one (tests / micro-benchmarks).
  * All configurations give bit-identical results. */
 int rt_op_gemm_force_config(int cfg);
-int rt_op_gemm_debug(int flags);   /* ablation probes (results are WRONG when non-zero): 1 no DMA in k loop, 2 no MFMA */
+int rt_op_gemm_debug(int flags);   /* retired ablation hook: no-op (ablations are compile-time in tools/probes/gemm_bench.hip) */
 
 /* ---- VAE decoder: colour guidance (rd.py:151-168, xl.py:849-867) and plain decode (rd.py:227-236) ----
  * AutoencoderKL.decoder + post_quant_conv (diffusers 0.18.2, third party: architecture restated in oracle/vae.py).

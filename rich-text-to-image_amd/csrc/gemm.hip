@@ -19,6 +19,7 @@
 //     cfg 3: 256x256, 16 waves (4x4), 2 stages, 1 block/CU    wide N
 //     cfg 4: 256x160, 8 compute waves (8x1) + 4 LOADER waves, 3-slot ring (gemm_ws_kernel)
 //     cfg 5: 256x128, 8 compute waves (4x2) + 4 loader waves
+//     cfg 6: 256x160, 8 waves in two groups one barrier apart (gemm_pp_kernel): long-K problems
 // (A ping-pong variant with two wave groups half an iteration apart was measured and dropped: 3.2k cycles per
 //  K tile against 2.2k here, because the ~1.0k cycles of LDS-DMA issue sit in one of the two phases.)
 // All configurations accumulate every output element in the same k order with the same MFMA shape, so the
@@ -33,6 +34,9 @@
 
 
 #define BK 64
+#ifndef RT_ABLATE
+#define RT_ABLATE 0
+#endif
 
 // ---- epilogue (shared by both main-loop variants), specialised at compile time on the epilogue kind.
 // With swapped operands the 32x32 accumulator tile is D[n][m]: m = lane&31 (row of C), n = (r&3) + 8*(r>>2) +
@@ -287,14 +291,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) fb[nxt][j] = *(const bf16x8*)(sbase + fb_off[j] + ((((ks + 1) * 2 + hi) ^ fb_key[j]) << 4));
             }
+#if RT_ABLATE != 1          // (probe builds only: 1 = no staging in the loop, 2 = no MFMA; tools/probes/gemm_bench.hip)
             if (MORE) stage(ns, nk0, ks);
+#endif
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     // operands swapped (D^T = W A^T): the lane then owns ONE output row m and 4 consecutive
                     // output columns per register quad, so the epilogue moves 16-B / 8-B vectors
+#if RT_ABLATE == 2
+                    asm volatile("" ::"v"(fb[cur][j]), "v"(fa[cur][i]));
+#else
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cur][j], fa[cur][i], acc[i][j], 0, 0, 0);
+#endif
             __builtin_amdgcn_sched_barrier(0);   // keep the (reads ks+1 | DMA issue | MFMA ks) grouping
         }
     };
@@ -303,6 +313,233 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     for (; kt + 1 < nk; ++kt) ktile(kt, std::false_type{}, std::false_type{});
     for (; kt < nk; ++kt) ktile(kt, std::false_type{}, std::true_type{});
     __syncthreads();      // every wave is done with the LDS ring: it becomes the epilogue's transpose slabs
+    gemm_epilogue<EPI, TM, TN, NW, S * STAGE>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane, wave, smem);
+}
+
+// ================================================================================================
+// Ping-pong variant: the 8 waves form two groups of 4 (one wave of each group per SIMD) that run ONE BARRIER apart,
+// so while a group executes a pure-MFMA section the other group issues its ds_reads and LDS-DMA copies
+// (guide T3/T4/T5: wave role split, counted vmcnt, setprio).  Motivation (tools/probes/gemm_bench ablation,
+// MI355X): with all waves in lock-step the kernel above spends ~2.8k cycles per K tile at 256x160 where the MFMA
+// work is 1.3k, the loads alone 1.7k and the MFMA+ds_read loop alone 2.1k - every wave queues on the CU's single
+// texture-address path at the same time and nobody feeds the matrix pipe meanwhile.
+//   phase = 2 k-steps (BK/32 phases per K tile), each phase  L: LDS-DMA part (+ counted vmcnt)                    ; s_barrier
+//                                                            M: setprio 1 ; 2*TM*TN MFMA | ds_read next phase  ; s_barrier
+//   group 1 executes one extra s_barrier first, so its L overlaps group 0's M and vice versa.
+// Ring (3 slots, K tile kt in slot kt % 3), per wave, tile kt:
+//   L(kt,0): stage the A part of tile kt+2 (slot of tile kt-1) ; s_waitcnt vmcnt(NA) => this wave's share of tile kt+1 landed
+//   M(kt,0): MFMA k-steps 0,1 | read k-steps 2,3 of tile kt          ; lgkmcnt(0)
+//   L(kt,1): stage the B part of tile kt+2
+//   M(kt,1): MFMA k-steps 2,3 | read k-steps 0,1 of tile kt+1        ; lgkmcnt(0)
+// RAW: every wave has passed its L(kt,0) wait at the barrier closing group 1's L(kt,0); the first reads of tile kt+1 are
+//      in M(kt,1), which starts after that barrier for both groups.
+// WAR: a slot's last reads (M(kt-1,0)) are retired by the lgkmcnt(0) before the barrier closing that section; the DMA
+//      into the slot is issued in L(kt,0) / L(kt,1), which start after that barrier for both groups.
+// Same k order and MFMA shape as gemm_kernel => bit-identical results.
+#ifdef RT_PP_TIMING
+__device__ long long g_pp_times[8 * 8];
+#define PP_T(i) { const long long now_ = __builtin_readcyclecounter(); tacc[i] += now_ - tlast; tlast = now_; }
+#else
+#define PP_T(i)
+#endif
+template <int MODE, int EPI, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_pp_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int S = 3;
+    constexpr int NW = WM * WN;
+    constexpr int STAGE = (BM + BN) * BK * 2;
+    constexpr int GA = BM / 8, GB = BN / 8;
+    constexpr int NA = (GA + NW - 1) / NW, NB = (GB + NW - 1) / NW;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    static_assert(NW == 8 && BK == 64, "two groups of four waves, two phases per K tile");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool grp1 = wave >= NW / 2;
+
+    const int ntn = (p.N + BN - 1) / BN;
+    const int ntm = (p.M + BM - 1) / BM;
+    const int nwg = ntm * ntn;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    constexpr int GRP = 4;
+    const int gsz = GRP * ntn;
+    const int first_m = (bid / gsz) * GRP;
+    const int gm = (ntm - first_m) < GRP ? (ntm - first_m) : GRP;
+    const int tm = first_m + (bid % gsz) % gm, tn = (bid % gsz) / gm;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int lrow = lane >> 3, pslot = lane & 7;
+    int a_off[NA], a_g[NA];
+    short cy[NA], cx[NA];
+    int b_off[NB], b_g[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        int g = i * NW + wave; if (g > GA - 1) g = GA - 1;
+        a_g[i] = g;
+        int row = m0 + g * 8 + lrow;
+        if (row >= p.M) row = p.M - 1;
+        if (MODE == A_DENSE) {
+            a_off[i] = row * p.lda; cy[i] = cx[i] = 0;
+        } else {
+            const int b = row / p.rows_per_batch;
+            const int pix = row - b * p.rows_per_batch;
+            const int y = pix / p.Wout, x = pix - y * p.Wout;
+            a_off[i] = b * p.Hin * p.Win * p.Cin;
+            cy[i] = (short)y; cx[i] = (short)x;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        int g = i * NW + wave; if (g > GB - 1) g = GB - 1;
+        b_g[i] = g;
+        int row = n0 + g * 8 + lrow;
+        if (row >= p.N) row = p.N - 1;
+        b_off[i] = row * p.ldw;
+    }
+    auto stage_a = [&](int s, int k0) {
+        char* sa = smem + s * STAGE;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int key = ((a_g[i] << 2) | (lrow >> 1)) & 7;
+            const int k = k0 + ((pslot ^ key) << 3);
+            const bf16_t* src = p.zero;
+            if (MODE == A_DENSE) {
+                src = k < p.K ? p.A + a_off[i] + k : p.zero;
+            } else if (k < p.K) {
+                const int tap = k / p.Cin, c = k - tap * p.Cin, ky = tap / 3, kx = tap - ky * 3;
+                int yy, xx; bool ok;
+                if (MODE == A_CONV3) {
+                    yy = cy[i] + ky - 1; xx = cx[i] + kx - 1;
+                    ok = yy >= 0 && yy < p.Hin && xx >= 0 && xx < p.Win;
+                } else if (MODE == A_CONV3_S2) {
+                    yy = cy[i] * 2 + ky - 1; xx = cx[i] * 2 + kx - 1;
+                    ok = yy >= 0 && yy < p.Hin && xx >= 0 && xx < p.Win;
+                } else {
+                    yy = cy[i] + ky - 1; xx = cx[i] + kx - 1;
+                    ok = yy >= 0 && yy < 2 * p.Hin && xx >= 0 && xx < 2 * p.Win;
+                    yy >>= 1; xx >>= 1;
+                }
+                if (ok) src = p.A + a_off[i] + (yy * p.Win + xx) * p.Cin + c;
+            }
+            glds16(src, sa + a_g[i] * 1024);
+        }
+    };
+    auto stage_b = [&](int s, int k0) {
+        char* sb = smem + s * STAGE + BM * BK * 2;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int key = ((b_g[i] << 2) | (lrow >> 1)) & 7;
+            const int k = k0 + ((pslot ^ key) << 3);
+            const bf16_t* src = k < p.K ? p.W + b_off[i] + k : p.zero;
+            glds16(src, sb + b_g[i] * 1024);
+        }
+    };
+
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, hi = lane >> 5;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // all fragments of a lane share the swizzle key: (row>>1)&7 with row = 32*t + (lane&31)
+    const int key = (l31 >> 1) & 7;
+    const int a_base = (wm * (BM / WM) + l31) * 128;
+    const int b_base = BM * BK * 2 + (wn * (BN / WN) + l31) * 128;
+    int kx[BK / 16];
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) kx[ks] = ((ks * 2 + hi) ^ key) << 4;
+
+    const int nk = (p.K + BK - 1) / BK;
+    stage_a(0, 0); stage_b(0, 0);
+    if (nk > 1) {
+        stage_a(1, BK); stage_b(1, BK);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                  // tile 0 is in LDS for everyone
+    // fragments: fr[c] feeds phase c of a tile; M(kt,0) prefetches fr[1] (k-steps 2,3), M(kt,1) prefetches fr[0] of tile kt+1
+    bf16x8 fa[2][2][TM], fb[2][2][TN];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[0][h][i] = *(const bf16x8*)(smem + a_base + i * 4096 + kx[h]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[0][h][j] = *(const bf16x8*)(smem + b_base + j * 4096 + kx[h]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (grp1) __builtin_amdgcn_s_barrier();        // group 1 runs one barrier behind group 0
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef RT_PP_TIMING
+    long long tacc[5] = {0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* sbase = smem + (kt % S) * STAGE;
+        const char* snext = smem + ((kt + 1) % S) * STAGE;
+        const bool more2 = kt + 2 < nk;
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            // ---------------- L section: LDS-DMA issue only (the wave sits in the copy queue's back-pressure)
+            if (ph == 0) {
+                if (more2) {
+                    stage_a((kt + 2) % S, (kt + 2) * BK);
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA) : "memory");      // this wave's share of tile kt+1 landed
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            } else {
+                if (more2) stage_b((kt + 2) % S, (kt + 2) * BK);
+            }
+            PP_T(0)
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            PP_T(1)
+            // ---------------- M section: MFMAs of this phase, interleaved with the ds_reads of the next phase
+            const char* rb = ph == 0 ? sbase : snext;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ph][h][j], fa[ph][h][i], acc[i][j], 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[ph ^ 1][h][i] = *(const bf16x8*)(rb + a_base + i * 4096 + kx[(ph ^ 1) * 2 + h]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[ph ^ 1][h][j] = *(const bf16x8*)(rb + b_base + j * 4096 + kx[(ph ^ 1) * 2 + h]);
+            }
+            // one read behind every MFMA (the reads of a 32-row fragment never outnumber 2*(TM*TN) + TM + TN here)
+#pragma unroll
+            for (int r = 0; r < 2 * (TM + TN); ++r) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM * TN, 0);
+            __builtin_amdgcn_s_setprio(0);
+            PP_T(2)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // next phase's fragments are in registers; slot reads retired
+            PP_T(3)
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            PP_T(4)
+        }
+    }
+#ifdef RT_PP_TIMING
+    if (blockIdx.x == 0 && lane == 0) for (int i = 0; i < 5; ++i) g_pp_times[wave * 8 + i] = tacc[i];
+#endif
+    if (!grp1) __builtin_amdgcn_s_barrier();       // pairs with group 1's last barrier
+    __syncthreads();                               // the ring becomes the epilogue's transpose slabs
     gemm_epilogue<EPI, TM, TN, NW, S * STAGE>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane, wave, smem);
 }
 
@@ -454,9 +691,9 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void gemm_ws_kernel(GemmArgs p
 
 // ---------------------------------------------------------------------------------------------- launch
 struct TileCfg { int BM, BN, threads, stages, geglu_ok; };
-#define RT_NCFG 6
+#define RT_NCFG 7
 static const TileCfg kCfg[RT_NCFG] = {{128, 128, 256, 2, 1}, {256, 128, 512, 3, 1}, {256, 160, 512, 3, 0}, {256, 256, 1024, 2, 1},
-                                       {256, 160, 768, 3, 0}, {256, 128, 768, 3, 1}};
+                                       {256, 160, 768, 3, 0}, {256, 128, 768, 3, 1}, {256, 160, 512, 3, 0}};
 
 template <int MODE, int EPI, int BM, int BN, int WM, int WN, int S>
 static void launch_cfg(const GemmArgs& a, hipStream_t st) {
@@ -492,6 +729,23 @@ static void launch_ws(const GemmArgs& a, hipStream_t st) {
     }
 }
 
+template <int MODE, int EPI, int BM, int BN, int WM, int WN>
+static void launch_pp(const GemmArgs& a, hipStream_t st) {
+    if constexpr (EPI == EPI_GEGLU && (BN / WN / 32) % 2 != 0) {
+        throw rt_error(RT_E_INVALID, "gemm: this tile configuration cannot run the GEGLU epilogue");
+    } else {
+        const size_t lds = (size_t)3 * (BM + BN) * BK * 2;
+        static bool attr = false;
+        if (!attr) {
+            HIP_CHECK(hipFuncSetAttribute((const void*)gemm_pp_kernel<MODE, EPI, BM, BN, WM, WN>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr = true;
+        }
+        dim3 grid(cdiv(a.M, BM) * cdiv(a.N, BN)), block(WM * WN * 64);
+        hipLaunchKernelGGL((gemm_pp_kernel<MODE, EPI, BM, BN, WM, WN>), grid, block, lds, st, a);
+    }
+}
+
 template <int MODE, int EPI>
 static void launch_me(const GemmArgs& a, int cfg, hipStream_t st) {
     switch (cfg) {
@@ -501,6 +755,11 @@ static void launch_me(const GemmArgs& a, int cfg, hipStream_t st) {
         case 3: launch_cfg<MODE, EPI, 256, 256, 4, 4, 2>(a, st); break;
         case 4: launch_ws<MODE, EPI, 256, 160, 8, 1, 4>(a, st); break;
         case 5: launch_ws<MODE, EPI, 256, 128, 4, 2, 4>(a, st); break;
+        case 6: launch_pp<MODE, EPI, 256, 160, 8, 1>(a, st); break;
+#ifdef RT_PROBE
+        case 7: launch_cfg<MODE, EPI, 256, 256, 2, 4, 2>(a, st); break;      // 8 waves, 128x64 per wave (ties cfg 3)
+        case 8: launch_pp<MODE, EPI, 256, 128, 4, 2>(a, st); break;          // slower than cfg 1 everywhere
+#endif
         default: throw rt_error(RT_E_INVALID, "gemm: bad tile configuration");
     }
 }

@@ -76,9 +76,9 @@ def test_gemm_temb_epilogue():
     report("gemm_temb", out, ref.reshape(B * HW, N), **BF16_OUT)
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6])
 def test_gemm_tile_configurations_are_bit_identical(cfg):
-    """Every tile configuration (incl. the 3-stage counted-vmcnt ring) must give the same bits as cfg 0."""
+    """Every tile configuration (incl. the counted-vmcnt rings, the loader-wave and the two-group ping-pong kernels) must give the same bits as cfg 0."""
     from rich_text_to_image_amd.engine import load_library
     lib = load_library()
     try:

@@ -2,8 +2,9 @@
 #include "../../rich-text-to-image_amd/csrc/gemm.hip"
 #include <vector>
 #include <algorithm>
+#include <cstring>
 int main(int argc, char** argv) {
-    struct Shape { int M, N, K; } shapes[] = {{256, 160, 64}, {7168, 1280, 64}, {7168, 1280, 128}, {7168, 1280, 320}, {7168, 1280, 640}, {7168, 1280, 1280}, {7168, 1280, 5120}, {7168, 10240, 1280}, {7168, 2560, 1280}, {28672, 640, 2560}, {8192, 8192, 8192}};
+    struct Shape { int M, N, K; } shapes[] = {{7168, 1280, 64}, {7168, 1280, 1280}, {7168, 1280, 5120}, {7168, 10240, 1280}, {28672, 5120, 640}, {8192, 8192, 8192}};
     bf16_t *A, *W, *out, *zero;
     hipMalloc(&A, (size_t)28672 * 8192 * 2); hipMalloc(&W, (size_t)10240 * 8192 * 2); hipMalloc(&out, (size_t)28672 * 10240 * 2); hipMalloc(&zero, 256);
     // pseudo-random bf16 fill (values ~ +-1): data-dependent power/clock effects matter (guide 5.4 rule 25)
@@ -12,9 +13,26 @@ int main(int argc, char** argv) {
       for (size_t off = 0; off < (size_t)10240 * 8192 * 2; off += h.size() * 2) hipMemcpy((char*)W + off, h.data(), std::min(h.size() * 2, (size_t)10240 * 8192 * 2 - off), hipMemcpyHostToDevice); }
     hipMemset(zero, 0, 256);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float *resid, *bias; hipMalloc(&resid, (size_t)28672 * 1280 * 4); hipMemset(resid, 0, (size_t)28672 * 1280 * 4); hipMalloc(&bias, 10240 * 4); hipMemset(bias, 0, 10240 * 4);
+    {   // epilogue cost on the two FF shapes: GEGLU (erf) vs plain bf16, fp32+residual vs plain bf16
+        struct E { int M, N, K, epi, cfg; const char* name; } es[] = {{7168, 10240, 1280, EPI_BF16, 3, "geglu-shape bf16"}, {7168, 10240, 1280, EPI_GEGLU, 3, "geglu-shape GEGLU"},
+            {28672, 5120, 640, EPI_BF16, 3, "geglu640 bf16"}, {28672, 5120, 640, EPI_GEGLU, 3, "geglu640 GEGLU"},
+            {7168, 1280, 1280, EPI_BF16, 2, "out-shape bf16"}, {7168, 1280, 1280, EPI_F32, 2, "out-shape f32+res"}, {7168, 1280, 5120, EPI_F32, 2, "ff2 f32+res"}, {7168, 1280, 5120, EPI_F32, 6, "ff2 f32+res pp"}};
+        for (auto e : es) {
+            GemmArgs g{}; g.A = A; g.W = W; g.out = out; g.zero = zero; g.mode = A_DENSE; g.epi = e.epi; g.bias = bias;
+            g.M = e.M; g.N = e.N; g.K = e.K; g.lda = e.K; g.ldw = e.K; g.ldo = e.epi == EPI_GEGLU ? e.N / 2 : e.N;
+            if (e.epi == EPI_F32) { g.res = resid; g.ldres = e.N; }
+            for (int r = 0; r < 3; ++r) launch_with_cfg(g, e.cfg, 0);
+            hipEventRecord(e0, 0);
+            for (int r = 0; r < 50; ++r) launch_with_cfg(g, e.cfg, 0);
+            hipEventRecord(e1, 0); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            printf("%-22s cfg%d %7.1f us\n", e.name, e.cfg, ms / 50 * 1e3);
+        }
+    }
     for (auto sh : shapes) {
         printf("%5dx%5dx%4d:", sh.M, sh.N, sh.K);
-        for (int cfg : {0, 2, 3, 4}) {
+        for (int cfg : {2, 3, 6}) {
             GemmArgs g{}; g.A = A; g.W = W; g.out = out; g.zero = zero; g.mode = A_DENSE; g.epi = EPI_BF16;
             g.M = sh.M; g.N = sh.N; g.K = sh.K; g.lda = sh.K; g.ldw = sh.K; g.ldo = sh.N;
             for (int r = 0; r < 3; ++r) launch_with_cfg(g, cfg, 0);
@@ -23,9 +41,24 @@ int main(int argc, char** argv) {
             for (int r = 0; r < it; ++r) launch_with_cfg(g, cfg, 0);
             hipEventRecord(e1, 0); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
-            printf("  cfg%d %6.1f us %6.0f TF", cfg, ms / it * 1e3, 2.0 * sh.M * sh.N * sh.K / (ms / it * 1e-3) / 1e12);
+            // every configuration must reproduce the first one bit for bit (same k order, same MFMA shape)
+            const size_t nb = std::min((size_t)sh.M * sh.N * 2, (size_t)64 << 20);
+            static std::vector<char> ref, cur; cur.resize(nb);
+            hipMemcpy(cur.data(), out, nb, hipMemcpyDeviceToHost);
+            const char* tag = "";
+            if (cfg == 2) ref = cur; else tag = memcmp(ref.data(), cur.data(), nb) ? " !!MISMATCH" : " ok";
+            printf("  cfg%d %6.1f us %6.0f TF%s", cfg, ms / it * 1e3, 2.0 * sh.M * sh.N * sh.K / (ms / it * 1e-3) / 1e12, tag);
         }
         printf("\n");
+#ifdef RT_PP_TIMING
+        { GemmArgs g{}; g.A = A; g.W = W; g.out = out; g.zero = zero; g.mode = A_DENSE; g.epi = EPI_BF16;
+          g.M = sh.M; g.N = sh.N; g.K = sh.K; g.lda = sh.K; g.ldw = sh.K; g.ldo = sh.N;
+          launch_with_cfg(g, 6, 0); hipDeviceSynchronize();
+          long long t[64]; hipMemcpyFromSymbol(t, HIP_SYMBOL(g_pp_times), sizeof(t));
+          const double nph = 2.0 * ((sh.K + 63) / 64);
+          for (int w = 0; w < 8; ++w) printf("    wave %d: dma issue %6.0f | barrier1 %5.0f | mfma+read issue %5.0f | ds wait %5.0f | barrier2 %5.0f   cycles per phase\n", w,
+              t[w * 8] / nph, t[w * 8 + 1] / nph, t[w * 8 + 2] / nph, t[w * 8 + 3] / nph, t[w * 8 + 4] / nph); }
+#endif
     }
     return 0;
 }
