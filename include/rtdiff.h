@@ -141,6 +141,12 @@ int rt_op_layernorm(const float* x, const float* gamma, const float* beta, void*
 int rt_op_small_linear(const float* a, int lda, const void* W_bf16, int ldw, const float* bias, float* out, int ldo,
                        int B, int N, int K, int silu_in, int accumulate, void* stream);
 int rt_op_timestep_embed(const float* t, int n, int dim, float* out, int ldo, void* stream);
+int rt_op_cast_bf16(const float* x, void* out_bf16, long long n, void* stream);
+/* Head-averaged attention probabilities of ONE batch entry (the `attention_probs_avg` the reference processor returns,
+ * attention_processor.py:541-545, reshape_batch_dim_to_heads_and_average): out[N, NK] (=|+=) mean_h softmax(Q_h K_h^T).
+ * Q rows q_row0+[0,N), K rows k_row0+[0,NKrows) in the rt_op_attention layouts; NK valid keys (<= 1024), NKpad = padded key count. */
+int rt_op_attention_probs_avg(const void* Q, int ldq, long long q_row0, const void* K, int ldk, long long k_row0, float* out,
+                              int H, int N, int NK, int NKpad, int NKrows, int DP, int accumulate, void* stream);
 const char* rt_op_last_error(void);
 /* GEMM tile configuration: -1 = auto-tune per shape (default); 0..6 force one (tests / micro-benchmarks).
  * All configurations give bit-identical results. */

@@ -1050,5 +1050,16 @@ int rt_op_small_linear(const float* a, int lda, const void* W, int ldw, const fl
 int rt_op_timestep_embed(const float* t, int n, int dim, float* out, int ldo, void* stream) {
     OP_TRY({ launch_timestep_embed(t, n, dim, out, ldo, (hipStream_t)stream); })
 }
+int rt_op_cast_bf16(const float* x, void* out_bf16, long long n, void* stream) {
+    OP_TRY({ RT_REQUIRE(n > 0, "cast: empty"); launch_cast_f32_bf16(x, (bf16_t*)out_bf16, (size_t)n, (hipStream_t)stream); })
+}
+int rt_op_attention_probs_avg(const void* Q, int ldq, long long q_row0, const void* K, int ldk, long long k_row0, float* out,
+                              int H, int N, int NK, int NKpad, int NKrows, int DP, int accumulate, void* stream) {
+    OP_TRY({
+        AttnStoreArgs a{}; a.Q = (const bf16_t*)Q; a.ldq = ldq; a.q_row0 = (long)q_row0; a.K = (const bf16_t*)K; a.ldk = ldk; a.k_row0 = (long)k_row0;
+        a.out = out; a.H = H; a.N = N; a.NK = NK; a.NKpad = NKpad; a.NKrows = NKrows; a.DP = DP; a.overwrite = accumulate ? 0 : 1;
+        launch_attn_store(a, (hipStream_t)stream);
+    })
+}
 
 }  // extern "C"

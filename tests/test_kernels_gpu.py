@@ -319,3 +319,46 @@ def test_small_linear_and_timestep_embedding():
     t = torch.tensor([981.0, 1.0, 500.0, 1024.0, 0.0])
     for dim in (320, 256, 32):
         report(f"timestep_embed {dim}", timestep_embed(t.to(DEV), dim), timestep_embedding(t, dim), atol=2e-4, rtol=0)
+
+
+# ----------------------------------------------------------------------------------------------- AttnProcessor seam
+class _StubAttention:
+    """The attributes of the reference `Attention` module the processor contract reads (attention_processor.py:33-152)."""
+
+    def __init__(self, sd, heads, cross_dim=None):
+        import torch.nn as nn
+        inner, qdim = sd["to_q.weight"].shape
+        self.heads, self.scale = heads, (inner // heads) ** -0.5
+        self.to_q = nn.Linear(qdim, inner, bias=False); self.to_k = nn.Linear(cross_dim or qdim, inner, bias=False)
+        self.to_v = nn.Linear(cross_dim or qdim, inner, bias=False)
+        self.to_out = nn.ModuleList([nn.Linear(inner, qdim), nn.Dropout(0.0)])
+        for n, m in (("to_q", self.to_q), ("to_k", self.to_k), ("to_v", self.to_v)):
+            m.weight.data.copy_(sd[n + ".weight"])
+        self.to_out[0].weight.data.copy_(sd["to_out.0.weight"]); self.to_out[0].bias.data.copy_(sd["to_out.0.bias"])
+        self.residual_connection, self.rescale_output_factor, self.spatial_norm, self.group_norm, self.norm_cross = False, 1.0, None, None, False
+
+
+def test_attn_processor_seam_matches_reference_module_golden():
+    """SURVEY 8b operator seam: HipAttnProcessor called with the reference processor's contract reproduces the outputs of the
+    UNMODIFIED reference Attention module (golden), including injection through the returned handle and the averaged map."""
+    import os
+    from rich_text_to_image_amd.attention_processor import AttnMapHandle, HipAttnProcessor
+    g = torch.load(os.path.join(os.path.dirname(__file__), "golden", "attention_ops.pt"))
+    proc = HipAttnProcessor()
+    x, x2, ctx = g["x"].to(DEV), g["x2"].to(DEV), g["ctx"].to(DEV)
+    cross = _StubAttention(g["cross_sd"], 2, cross_dim=ctx.shape[-1])
+    y, maps = proc(cross, x, encoder_hidden_states=ctx)
+    report("processor cross plain", y, g["y_plain"], atol=3e-2, rtol=3e-2)
+    assert maps[1].shape[-1] == 77 and maps[0].shape == (2, 256, 77)                       # what the hooks assert (rd.py:326,414)
+    assert torch.allclose(maps[0].detach().cpu().sum(-1), torch.ones(2, 256), atol=2e-2)
+    y, maps_fs = proc(cross, x, encoder_hidden_states=ctx, attn_weights={"word_pos": g["word_pos"], "font_size": g["font_size"]})
+    report("processor cross font-size", y, g["y_fs"], atol=3e-2, rtol=3e-2)
+    selfa = _StubAttention(g["self_sd"], 2)
+    y, maps = proc(selfa, x)
+    report("processor self", y, g["y_self"], atol=3e-2, rtol=3e-2)
+    assert isinstance(maps[1], AttnMapHandle) and maps[1].shape == (4, 256, 256) and maps[1].detach() is maps[1]
+    report("processor probs_avg", maps[0].detach().cpu(), g["p_self_avg"], atol=2e-3, rtol=5e-2)
+    y, _ = proc(selfa, x2, real_attn_probs=maps[1])                                            # injection hook path (rd.py:366,382)
+    report("processor self injected", y, g["y_inj"], atol=3e-2, rtol=3e-2)
+    with pytest.raises(TypeError):
+        proc(selfa, x2, real_attn_probs=torch.zeros(4, 256, 256, device=DEV))
