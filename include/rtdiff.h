@@ -151,7 +151,7 @@ const char* rt_op_last_error(void);
 /* GEMM tile configuration: -1 = auto-tune per shape (default); 0..6 force one (tests / micro-benchmarks).
  * All configurations give bit-identical results. */
 int rt_op_gemm_force_config(int cfg);
-int rt_op_gemm_debug(int flags);   /* retired ablation hook: no-op (ablations are compile-time in tools/probes/gemm_bench.hip) */
+int rt_op_gemm_debug(int flags);   /* bit 0: send patch-eligible 3x3 convs through the implicit-GEMM kernels instead (A/B tests) */
 
 /* ---- VAE decoder: colour guidance (rd.py:151-168, xl.py:849-867) and plain decode (rd.py:227-236) ----
  * AutoencoderKL.decoder + post_quant_conv (diffusers 0.18.2, third party: architecture restated in oracle/vae.py).

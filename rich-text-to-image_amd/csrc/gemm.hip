@@ -45,9 +45,12 @@
 // (measured: 7-9 us of the 12 us fixed cost of a launch).  Instead every wave transposes its 32-row slab through
 // its private slice of the (now idle) LDS ring and writes / reads HBM in row-contiguous 16-B chunks, so stores
 // (and the fp32 residual reads) move whole cache lines.  N % 4 == 0 (fp32) / N % 8 == 0 (bf16) is required.
-template <int EPI, int TM, int TN, int NWC, int LDS_BYTES>
+// PATCH (3x3-conv patch kernel): the tile's 256 rows are a 16x16 pixel patch, local row r -> output row
+// prow_base + (r>>4)*pW + (r&15); wrow0 is then the wave's first LOCAL row.
+template <int EPI, int TM, int TN, int NWC, int LDS_BYTES, bool PATCH = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[TM][TN], int wrow0, int wcol0, int lane, int wave_c,
-                                              char* smem) {
+                                              char* smem, int prow_base = 0, int pW = 0) {
+    auto grow = [&](int r) { return PATCH ? prow_base + (r >> 4) * pW + (r & 15) : r; };
     constexpr bool F32 = EPI == EPI_F32;
     constexpr int ES = F32 ? 4 : 2;
     constexpr int TO = EPI == EPI_GEGLU ? TN / 2 : TN;                 // 32-column output tiles per wave
@@ -94,7 +97,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = acc[i][t][4 * g + e] + bv[e];
                         if constexpr (EPI == EPI_BF16_TEMB) {
-                            int row = wrow0 + i * 32 + l31; if (row >= p.M) row = p.M - 1;
+                            int row = grow(wrow0 + i * 32 + l31); if (row >= p.M) row = p.M - 1;
                             if (col < p.N) {
                                 const float4 tv = *(const float4*)(p.temb + (size_t)(row / p.rows_per_batch) * p.temb_ld + col);
                                 v[0] += tv.x; v[1] += tv.y; v[2] += tv.z; v[3] += tv.w;
@@ -114,7 +117,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
                 const int idx = idx0 + lane;
                 const int r = idx / cpr_pass, ch = idx - r * cpr_pass;
                 if (r >= 32) continue;
-                const int row = wrow0 + i * 32 + r;
+                const int row = grow(wrow0 + i * 32 + r);
                 const int col = ocol0 + t0 * 32 + ch * (16 / ES);
                 if (row >= p.M || col >= NO) continue;
                 const uint4 q = *(const uint4*)(slab + r * RS + ch * 16);
@@ -689,6 +692,184 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void gemm_ws_kernel(GemmArgs p
     gemm_epilogue<EPI, TM, TN, NWC, 3 * STAGE>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane, wave, smem);
 }
 
+// ================================================================================================
+// 3x3 stride-1 convolution on 16x16 pixel patches (conv3p_kernel).  The implicit-GEMM kernels above fetch every input
+// pixel nine times (once per tap) through the L2 -> LDS copy path, which is what bounds them.  Here a
+// block owns a 16x16 output patch x 160 output channels; per 64-channel chunk the 18x18 input HALO is copied to LDS
+// once and the nine taps read their A fragments from it at shifted rows, so the copy traffic per k step drops from
+// 53 KB (A 32 KB + W 20 KB) to 25 KB (halo/9 = 4.6 KB + W 20 KB).  k order: (chunk, tap, c) - different from the
+// implicit-GEMM kernels' (tap, chunk, c), so results agree with them to rounding, not bit for bit; eligible convolutions
+// ALWAYS take this kernel (no tuning), which keeps runs reproducible.
+//   LDS: 2 halo slots (328 rows x 128 B) + 3-slot ring of W tiles (160 rows x 128 B) = 145,408 B
+//   step s = chunk*9 + tap:  k-steps 0..2 ; lgkmcnt(0) ; s_waitcnt vmcnt(N) ; s_barrier ; issue [halo part of chunk+1 | W tile of
+//   step s+3] ; k-step 3 while the first fragments of step s+1 are fetched (the barrier never exposes a ds_read)
+// Requirements: mode A_CONV3 (stride 1, pad 1), H % 16 == 0, W % 16 == 0, Cin % 64 == 0.
+template <int EPI>
+__global__ __launch_bounds__(512) void conv3p_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BN = 160, NW = 8, TN = 5;
+    constexpr int HROWS = 328, ASLOT = HROWS * 128, BSLOT = BN * 128;
+    constexpr int GA = HROWS / 8, GB = BN / 8;
+    constexpr int NAH = (GA + NW - 1) / NW, NB = (GB + NW - 1) / NW;      // 6 halo pieces, 3 W pieces per wave
+    static_assert(NAH <= 9, "one halo piece per tap step");
+    char* const sA = smem;
+    char* const sB = smem + 2 * ASLOT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int ptx = p.Wout >> 4, npatch = (p.Hout >> 4) * ptx;
+    const int ntm = (p.M / p.rows_per_batch) * npatch;
+    const int ntn = (p.N + BN - 1) / BN;
+    const int nwg = ntm * ntn;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    constexpr int GRP = 4;
+    const int gsz = GRP * ntn;
+    const int first_m = (bid / gsz) * GRP;
+    const int gm = (ntm - first_m) < GRP ? (ntm - first_m) : GRP;
+    const int tm = first_m + (bid % gsz) % gm, tn = (bid % gsz) / gm;
+    const int n0 = tn * BN;
+    const int img = tm / npatch, pp = tm - img * npatch;
+    const int y0 = (pp / ptx) << 4, x0 = (pp % ptx) << 4;
+
+    // ---- loaders
+    const int lrow = lane >> 3, pslot = lane & 7;
+    int a_off[NAH], a_g[NAH];                       // element offset of the halo pixel's channel vector, -1 = outside the image
+#pragma unroll
+    for (int i = 0; i < NAH; ++i) {
+        int g = i * NW + wave; if (g > GA - 1) g = GA - 1;
+        a_g[i] = g;
+        const int hr = g * 8 + lrow;
+        const int hy = hr / 18, hx = hr - hy * 18;
+        const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+        const bool ok = hr < 324 && yy >= 0 && yy < p.Hin && xx >= 0 && xx < p.Win;
+        a_off[i] = ok ? ((img * p.Hin + yy) * p.Win + xx) * p.Cin : -1;
+    }
+    int b_off[NB], b_g[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        int g = i * NW + wave; if (g > GB - 1) g = GB - 1;
+        b_g[i] = g;
+        int row = n0 + g * 8 + lrow;
+        if (row >= p.N) row = p.N - 1;
+        b_off[i] = row * p.ldw;
+    }
+    auto stage_halo = [&](int slot, int chunk, int i) {
+        const int key = ((a_g[i] << 2) | (lrow >> 1)) & 7;
+        const bf16_t* src = a_off[i] >= 0 ? p.A + a_off[i] + chunk * 64 + ((pslot ^ key) << 3) : p.zero;
+        glds16(src, sA + slot * ASLOT + a_g[i] * 1024);
+    };
+    auto stage_w = [&](int slot, int k0) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int key = ((b_g[i] << 2) | (lrow >> 1)) & 7;
+            glds16(p.W + b_off[i] + k0 + ((pslot ^ key) << 3), sB + slot * BSLOT + b_g[i] * 1024);
+        }
+    };
+
+    // ---- compute geometry: wave w owns patch rows 2w, 2w+1 (32 pixels) x 160 channels
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int hr0 = (2 * wave + (l31 >> 4)) * 18 + (l31 & 15);
+    const int keyb = (l31 >> 1) & 7;
+    const int b_base = l31 * 128;
+    int kxb[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) kxb[ks] = ((ks * 2 + hi) ^ keyb) << 4;
+    f32x16 acc[1][TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+
+    const int nc = p.Cin >> 6;
+    const int nsteps = nc * 9;
+    auto wait_vm = [&](int n) {                     // n is wave-uniform
+        if (n >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    static_assert(NB == 3, "wait_vm is written for 3 W pieces (+1 halo piece) per wave and step");
+    // prologue: whole halo of chunk 0, W tiles of steps 0..2 (nsteps >= 9); halo + W(0) must have landed
+#pragma unroll
+    for (int i = 0; i < NAH; ++i) stage_halo(0, 0, i);
+    stage_w(0, 0);
+    stage_w(1, p.Cin);
+    stage_w(2, 2 * p.Cin);
+    wait_vm(2 * NB);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    // fragment addressing of one (halo slot, tap): lane's halo row, its swizzle key
+    bf16x8 fa[2], fb[2][TN];
+    {
+        const char* arow = sA + hr0 * 128;
+        const int keya = (hr0 >> 1) & 7;
+        fa[0] = *(const bf16x8*)(arow + ((hi ^ keya) << 4));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[0][j] = *(const bf16x8*)(sB + b_base + j * 4096 + kxb[0]);
+    }
+    // Step s = chunk*9 + tap.  The wait + barrier sits between k-steps 2 and 3: it certifies W(s+1) (and, at tap 8, the next
+    // halo) for everyone and retires every read of W(s), so k-step 3 can already fetch the first fragments of step s+1 and
+    // the W tile of step s+3 can be copied into W(s)'s slot - no ds_read latency is exposed behind a barrier.
+    for (int chunk = 0; chunk < nc; ++chunk) {
+        const bool next_chunk = chunk + 1 < nc;
+        const char* sa = sA + (chunk & 1) * ASLOT;
+        const char* sa_next = sA + ((chunk + 1) & 1) * ASLOT;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int s = chunk * 9 + tap;
+            const int hr = hr0 + (tap / 3) * 18 + (tap % 3);
+            const char* arow = sa + hr * 128;
+            const int keya = (hr >> 1) & 7;
+            const char* sb = sB + (s % 3) * BSLOT + b_base;
+            // first fragments of step s+1
+            const int ntap = tap == 8 ? 0 : tap + 1;
+            const int nhr = hr0 + (ntap / 3) * 18 + (ntap % 3);
+            const char* narow = (tap == 8 ? sa_next : sa) + nhr * 128;
+            const int nkeya = (nhr >> 1) & 7;
+            const char* nsb = sB + ((s + 1) % 3) * BSLOT + b_base;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int cur = ks & 1, nxt = cur ^ 1;
+                if (ks < 3) {
+                    fa[nxt] = *(const bf16x8*)(arow + ((((ks + 1) * 2 + hi) ^ keya) << 4));
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) fb[nxt][j] = *(const bf16x8*)(sb + j * 4096 + kxb[ks + 1]);
+                } else {
+                    // issue order inside a step is [halo piece, W tile]; step s-2 issued W(s+1), step s-1 issued [halo piece?, W(s+2)]:
+                    // W(s+1) and everything older (incl. the whole next halo at tap 8) has landed once only those may still fly.
+                    // A halo piece is issued at step (c, t) iff t < NAH and c + 1 < nc.
+                    const bool prev_had_halo = tap >= 1 && tap - 1 < NAH && next_chunk;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // every read of W(s) / this tap's halo rows is retired
+                    wait_vm((s + 2 < nsteps ? NB : 0) + (prev_had_halo ? 1 : 0));
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (tap < NAH && next_chunk) stage_halo((chunk + 1) & 1, chunk + 1, tap);
+                    if (s + 3 < nsteps) {
+                        const int s3 = s + 3, c3 = s3 / 9, t3 = s3 - c3 * 9;
+                        stage_w(s3 % 3, t3 * p.Cin + c3 * 64);
+                    }
+                    fa[nxt] = *(const bf16x8*)(narow + ((hi ^ nkeya) << 4));
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) fb[nxt][j] = *(const bf16x8*)(nsb + j * 4096 + kxb[0]);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cur][j], fa[cur], acc[0][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    __syncthreads();
+    gemm_epilogue<EPI, 1, TN, NW, 2 * ASLOT + 3 * BSLOT, true>(p, acc, wave * 32, n0, lane, wave, smem,
+                                                                 (img * p.Hout + y0) * p.Wout + x0, p.Wout);
+}
+
 // ---------------------------------------------------------------------------------------------- launch
 struct TileCfg { int BM, BN, threads, stages, geglu_ok; };
 #define RT_NCFG 7
@@ -786,7 +967,24 @@ static void launch_with_cfg(const GemmArgs& a, int cfg, hipStream_t st) {
 // admissible configuration with HIP events on the caller's stream and caches the winner).  Because all
 // configurations are bit-identical in their results, tuning never changes outputs.
 static int g_force_cfg = -1;
-void gemm_set_debug(int) {}   // ablation hooks compiled out (see git history / tools/probes)
+static int g_conv_patch = 1;
+void gemm_set_debug(int flags) { g_conv_patch = (flags & 1) ? 0 : 1; }   // bit 0: route eligible convs through the implicit-GEMM kernels (A/B tests)
+
+template <int EPI>
+static void launch_conv3p(const GemmArgs& a, hipStream_t st) {
+    constexpr int LDS = 2 * 328 * 128 + 3 * 160 * 128;
+    static bool attr = false;
+    if (!attr) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)conv3p_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr = true;
+    }
+    const int ntm = (a.M / a.rows_per_batch) * (a.Hout / 16) * (a.Wout / 16);
+    hipLaunchKernelGGL((conv3p_kernel<EPI>), dim3(ntm * cdiv(a.N, 160)), dim3(512), LDS, st, a);
+}
+static bool conv_patch_eligible(const GemmArgs& a) {
+    return g_conv_patch && a.mode == A_CONV3 && a.Hout % 16 == 0 && a.Wout % 16 == 0 && a.Cin % 64 == 0 && a.Hin == a.Hout && a.Win == a.Wout &&
+           a.M % a.rows_per_batch == 0 && (a.epi == EPI_BF16 || a.epi == EPI_F32 || a.epi == EPI_BF16_TEMB);
+}
 void gemm_force_config(int cfg) { g_force_cfg = cfg; }
 
 static int pick_config(const GemmArgs& a, hipStream_t st) {
@@ -853,6 +1051,14 @@ void launch_gemm(const GemmArgs& a, hipStream_t st) {
     if (a.bias) RT_REQUIRE(((uintptr_t)a.bias & 15) == 0, "gemm: bias must be 16-B aligned");
     if (a.temb) RT_REQUIRE(a.temb_ld % 4 == 0 && ((uintptr_t)a.temb & 15) == 0, "gemm: temb must be 16-B aligned");
     // In-place residual (out == res) is safe: every element is read and written by the same thread.
+    if (conv_patch_eligible(a)) {
+        switch (a.epi) {
+            case EPI_BF16: launch_conv3p<EPI_BF16>(a, st); break;
+            case EPI_F32: launch_conv3p<EPI_F32>(a, st); break;
+            default: launch_conv3p<EPI_BF16_TEMB>(a, st); break;
+        }
+        return;
+    }
     const int cfg = pick_config(a, st);
     launch_with_cfg(a, cfg, st);
 }

@@ -137,6 +137,38 @@ def test_conv3x3_implicit_gemm(mode, B, H, W_, Cin, Cout):
     report(f"conv mode{mode} {B}x{H}x{W_}x{Cin}->{Cout}", out.reshape(B, Hout, Wout, Cout), ref.permute(0, 2, 3, 1), **F32_OUT)
 
 
+@pytest.mark.parametrize("B,H,W_,Cin,Cout,epi", [(2, 32, 32, 64, 96, 1), (1, 16, 48, 128, 200, 1), (3, 16, 16, 192, 160, 0), (2, 32, 16, 64, 320, 2),
+                                                  (7, 32, 32, 1280, 1280, 1), (2, 64, 64, 640, 320, 2)])
+def test_conv3x3_patch_kernel(B, H, W_, Cin, Cout, epi):
+    """The 16x16-patch kernel (halo staged once per 64-channel chunk) against torch AND against the implicit-GEMM kernels
+    it replaces (same inputs, `rt_op_gemm_debug(1)` routes around it): k order differs, so agreement is to fp32 rounding."""
+    from rich_text_to_image_amd.engine import load_library
+    lib = load_library()
+    x = rnd(B, Cin, H, W_, seed=20)
+    w = rnd(Cout, Cin, 3, 3, seed=21, scale=(9 * Cin) ** -0.5)
+    bias = rnd(Cout, seed=22)
+    A, Wp = bf(x.permute(0, 2, 3, 1)), bf(_conv_weight_packed(w))
+    res = rnd(B * H * W_, Cout, seed=23).to(DEV) if epi == 1 else None
+    temb = rnd(B, Cout, seed=24).to(DEV) if epi == 2 else None
+    ref = F.conv2d(x.to(torch.bfloat16).float().to(DEV), w.to(torch.bfloat16).float().to(DEV), bias.to(DEV), padding=1).permute(0, 2, 3, 1)
+    if res is not None:
+        ref = ref + res.reshape(B, H, W_, Cout)
+    if temb is not None:
+        ref = ref + temb[:, None, None, :]
+    kw = dict(epi=epi, mode=1, conv=(H, W_), res=res, temb=temb)
+    try:
+        out = gemm(A, Wp, bias.to(DEV), **kw)
+        out2 = gemm(A, Wp, bias.to(DEV), **kw)
+        assert torch.equal(out, out2), "patch conv is not run-to-run deterministic"
+        lib.rt_op_gemm_debug(1)
+        old = gemm(A, Wp, bias.to(DEV), **kw)
+    finally:
+        lib.rt_op_gemm_debug(0)
+    tol = F32_OUT if epi == 1 else BF16_OUT
+    report(f"patch conv {B}x{H}x{W_}x{Cin}->{Cout} epi{epi} vs torch", out.reshape(B, H, W_, Cout), ref, **tol)
+    report("patch conv vs implicit GEMM", out, old, atol=1e-4 if epi == 1 else 2e-2, rtol=1e-4 if epi == 1 else 1e-2)
+
+
 # ----------------------------------------------------------------------------------------------- attention
 def _ref_attention(q, k, v, heads, fontsize=None):
     """q [B,N,C], k,v [B,NK,C] fp32: the reference math (attention_processor.py:476-545, 359-407)."""

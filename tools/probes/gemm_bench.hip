@@ -30,6 +30,25 @@ int main(int argc, char** argv) {
             printf("%-22s cfg%d %7.1f us\n", e.name, e.cfg, ms / 50 * 1e3);
         }
     }
+    {   // 3x3 convolutions: patch kernel vs the implicit-GEMM configuration 2
+        struct Cv { int B, H, W, Cin, Cout; } cs[] = {{7, 32, 32, 1280, 1280}, {7, 32, 32, 2560, 1280}, {7, 64, 64, 640, 640}, {7, 64, 64, 1920, 640}, {7, 128, 128, 320, 320}, {7, 128, 128, 960, 320}};
+        for (auto c : cs) {
+            GemmArgs g{}; g.A = A; g.W = W; g.out = out; g.zero = zero; g.mode = A_CONV3; g.epi = EPI_BF16; g.bias = bias;
+            g.M = c.B * c.H * c.W; g.N = c.Cout; g.K = 9 * c.Cin; g.ldw = g.K; g.ldo = c.Cout; g.rows_per_batch = c.H * c.W;
+            g.Hin = g.Hout = c.H; g.Win = g.Wout = c.W; g.Cin = c.Cin;
+            printf("conv %dx%dx%dx%d->%d:", c.B, c.H, c.W, c.Cin, c.Cout);
+            for (int variant = 0; variant < 2; ++variant) {
+                auto run = [&]() { if (variant == 0) launch_conv3p<EPI_BF16>(g, 0); else launch_with_cfg(g, 2, 0); };
+                for (int r = 0; r < 3; ++r) run();
+                hipEventRecord(e0, 0);
+                for (int r = 0; r < 20; ++r) run();
+                hipEventRecord(e1, 0); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                printf("  %s %7.1f us %6.0f TF", variant == 0 ? "patch" : "cfg2 ", ms / 20 * 1e3, 2.0 * g.M * g.N * g.K / (ms / 20 * 1e-3) / 1e12);
+            }
+            printf("\n");
+        }
+    }
     for (auto sh : shapes) {
         printf("%5dx%5dx%4d:", sh.M, sh.N, sh.K);
         for (int cfg : {2, 3, 6}) {
