@@ -939,7 +939,7 @@ static void launch_me(const GemmArgs& a, int cfg, hipStream_t st) {
         case 6: launch_pp<MODE, EPI, 256, 160, 8, 1>(a, st); break;
 #ifdef RT_PROBE
         case 7: launch_cfg<MODE, EPI, 256, 256, 2, 4, 2>(a, st); break;      // 8 waves, 128x64 per wave (ties cfg 3)
-        case 8: launch_pp<MODE, EPI, 256, 128, 4, 2>(a, st); break;          // slower than cfg 1 everywhere
+        case 8: launch_cfg<MODE, EPI, 256, 320, 4, 2, 2>(a, st); break;      // 64x160 per wave, 142 flop/B through the copy path
 #endif
         default: throw rt_error(RT_E_INVALID, "gemm: bad tile configuration");
     }
