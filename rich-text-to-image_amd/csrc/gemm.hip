@@ -704,11 +704,14 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void gemm_ws_kernel(GemmArgs p
 //   step s = chunk*9 + tap:  k-steps 0..2 ; lgkmcnt(0) ; s_waitcnt vmcnt(N) ; s_barrier ; issue [halo part of chunk+1 | W tile of
 //   step s+3] ; k-step 3 while the first fragments of step s+1 are fetched (the barrier never exposes a ds_read)
 // Requirements: mode A_CONV3 (stride 1, pad 1), H % 16 == 0, W % 16 == 0, Cin % 64 == 0.
-template <int EPI>
+// UP2: the nearest-2x upsample of Upsample2D (resnet.py:137-172) folded in: the 16x16 OUTPUT patch reads a 10x10 input halo
+// (input pixel = output pixel >> 1), so the halo is 100 rows instead of 324.
+template <int EPI, bool UP2>
 __global__ __launch_bounds__(512) void conv3p_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BN = 160, NW = 8, TN = 5;
-    constexpr int HROWS = 328, ASLOT = HROWS * 128, BSLOT = BN * 128;
+    constexpr int HW_ = UP2 ? 10 : 18;                                    // halo width (input pixels)
+    constexpr int HROWS = UP2 ? 104 : 328, ASLOT = HROWS * 128, BSLOT = BN * 128;
     constexpr int GA = HROWS / 8, GB = BN / 8;
     constexpr int NAH = (GA + NW - 1) / NW, NB = (GB + NW - 1) / NW;      // 6 halo pieces, 3 W pieces per wave
     static_assert(NAH <= 9, "one halo piece per tap step");
@@ -743,9 +746,9 @@ __global__ __launch_bounds__(512) void conv3p_kernel(GemmArgs p) {
         int g = i * NW + wave; if (g > GA - 1) g = GA - 1;
         a_g[i] = g;
         const int hr = g * 8 + lrow;
-        const int hy = hr / 18, hx = hr - hy * 18;
-        const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
-        const bool ok = hr < 324 && yy >= 0 && yy < p.Hin && xx >= 0 && xx < p.Win;
+        const int hy = hr / HW_, hx = hr - hy * HW_;
+        const int yy = (UP2 ? (y0 >> 1) : y0) - 1 + hy, xx = (UP2 ? (x0 >> 1) : x0) - 1 + hx;
+        const bool ok = hr < HW_ * HW_ && yy >= 0 && yy < p.Hin && xx >= 0 && xx < p.Win;
         a_off[i] = ok ? ((img * p.Hin + yy) * p.Win + xx) * p.Cin : -1;
     }
     int b_off[NB], b_g[NB];
@@ -772,7 +775,13 @@ __global__ __launch_bounds__(512) void conv3p_kernel(GemmArgs p) {
 
     // ---- compute geometry: wave w owns patch rows 2w, 2w+1 (32 pixels) x 160 channels
     const int l31 = lane & 31, hi = lane >> 5;
-    const int hr0 = (2 * wave + (l31 >> 4)) * 18 + (l31 & 15);
+    const int py = 2 * wave + (l31 >> 4), px = l31 & 15;                  // this lane's pixel inside the patch
+    // halo row read by tap (ky, kx): plain: (py+ky, px+kx); UP2: (((py+ky-1)>>1)+1, ((px+kx-1)>>1)+1)
+    auto halo_row = [&](int tap) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        return UP2 ? (((py + ky - 1) >> 1) + 1) * HW_ + ((px + kx - 1) >> 1) + 1 : (py + ky) * HW_ + px + kx;
+    };
+    const int hr0 = halo_row(0);
     const int keyb = (l31 >> 1) & 7;
     const int b_base = l31 * 128;
     int kxb[4];
@@ -823,13 +832,13 @@ __global__ __launch_bounds__(512) void conv3p_kernel(GemmArgs p) {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int s = chunk * 9 + tap;
-            const int hr = hr0 + (tap / 3) * 18 + (tap % 3);
+            const int hr = halo_row(tap);
             const char* arow = sa + hr * 128;
             const int keya = (hr >> 1) & 7;
             const char* sb = sB + (s % 3) * BSLOT + b_base;
             // first fragments of step s+1
             const int ntap = tap == 8 ? 0 : tap + 1;
-            const int nhr = hr0 + (ntap / 3) * 18 + (ntap % 3);
+            const int nhr = halo_row(ntap);
             const char* narow = (tap == 8 ? sa_next : sa) + nhr * 128;
             const int nkeya = (nhr >> 1) & 7;
             const char* nsb = sB + ((s + 1) % 3) * BSLOT + b_base;
@@ -970,20 +979,22 @@ static int g_force_cfg = -1;
 static int g_conv_patch = 1;
 void gemm_set_debug(int flags) { g_conv_patch = (flags & 1) ? 0 : 1; }   // bit 0: route eligible convs through the implicit-GEMM kernels (A/B tests)
 
-template <int EPI>
+template <int EPI, bool UP2>
 static void launch_conv3p(const GemmArgs& a, hipStream_t st) {
-    constexpr int LDS = 2 * 328 * 128 + 3 * 160 * 128;
+    constexpr int LDS = 2 * (UP2 ? 104 : 328) * 128 + 3 * 160 * 128;
     static bool attr = false;
     if (!attr) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)conv3p_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        HIP_CHECK(hipFuncSetAttribute((const void*)conv3p_kernel<EPI, UP2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr = true;
     }
     const int ntm = (a.M / a.rows_per_batch) * (a.Hout / 16) * (a.Wout / 16);
-    hipLaunchKernelGGL((conv3p_kernel<EPI>), dim3(ntm * cdiv(a.N, 160)), dim3(512), LDS, st, a);
+    hipLaunchKernelGGL((conv3p_kernel<EPI, UP2>), dim3(ntm * cdiv(a.N, 160)), dim3(512), LDS, st, a);
 }
 static bool conv_patch_eligible(const GemmArgs& a) {
-    return g_conv_patch && a.mode == A_CONV3 && a.Hout % 16 == 0 && a.Wout % 16 == 0 && a.Cin % 64 == 0 && a.Hin == a.Hout && a.Win == a.Wout &&
-           a.M % a.rows_per_batch == 0 && (a.epi == EPI_BF16 || a.epi == EPI_F32 || a.epi == EPI_BF16_TEMB);
+    if (!g_conv_patch || a.mode == A_DENSE || a.rows_per_batch <= 0 || a.Hout % 16 || a.Wout % 16 || a.Cin % 64 || a.M % a.rows_per_batch) return false;
+    if (a.mode == A_CONV3) return a.Hin == a.Hout && a.Win == a.Wout && (a.epi == EPI_BF16 || a.epi == EPI_F32 || a.epi == EPI_BF16_TEMB);
+    if (a.mode == A_CONV3_UP2) return a.Hout == 2 * a.Hin && a.Wout == 2 * a.Win && a.epi == EPI_F32;
+    return false;
 }
 void gemm_force_config(int cfg) { g_force_cfg = cfg; }
 
@@ -1052,10 +1063,11 @@ void launch_gemm(const GemmArgs& a, hipStream_t st) {
     if (a.temb) RT_REQUIRE(a.temb_ld % 4 == 0 && ((uintptr_t)a.temb & 15) == 0, "gemm: temb must be 16-B aligned");
     // In-place residual (out == res) is safe: every element is read and written by the same thread.
     if (conv_patch_eligible(a)) {
-        switch (a.epi) {
-            case EPI_BF16: launch_conv3p<EPI_BF16>(a, st); break;
-            case EPI_F32: launch_conv3p<EPI_F32>(a, st); break;
-            default: launch_conv3p<EPI_BF16_TEMB>(a, st); break;
+        if (a.mode == A_CONV3_UP2) launch_conv3p<EPI_F32, true>(a, st);
+        else switch (a.epi) {
+            case EPI_BF16: launch_conv3p<EPI_BF16, false>(a, st); break;
+            case EPI_F32: launch_conv3p<EPI_F32, false>(a, st); break;
+            default: launch_conv3p<EPI_BF16_TEMB, false>(a, st); break;
         }
         return;
     }

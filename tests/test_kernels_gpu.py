@@ -169,6 +169,27 @@ def test_conv3x3_patch_kernel(B, H, W_, Cin, Cout, epi):
     report("patch conv vs implicit GEMM", out, old, atol=1e-4 if epi == 1 else 2e-2, rtol=1e-4 if epi == 1 else 1e-2)
 
 
+@pytest.mark.parametrize("B,H,W_,Cin,Cout", [(2, 16, 16, 64, 96), (1, 8, 24, 128, 200), (7, 32, 32, 1280, 1280)])
+def test_conv3x3_patch_kernel_upsample(B, H, W_, Cin, Cout):
+    """Upsample2D folded into the patch kernel (10x10 input halo per 16x16 output patch) vs torch and vs the implicit-GEMM loader."""
+    from rich_text_to_image_amd.engine import load_library
+    lib = load_library()
+    x = rnd(B, Cin, H, W_, seed=25)
+    w = rnd(Cout, Cin, 3, 3, seed=26, scale=(9 * Cin) ** -0.5)
+    bias = rnd(Cout, seed=27)
+    A, Wp = bf(x.permute(0, 2, 3, 1)), bf(_conv_weight_packed(w))
+    xb = x.to(torch.bfloat16).float().to(DEV)
+    ref = F.conv2d(F.interpolate(xb, scale_factor=2.0, mode="nearest"), w.to(torch.bfloat16).float().to(DEV), bias.to(DEV), padding=1).permute(0, 2, 3, 1)
+    try:
+        out = gemm(A, Wp, bias.to(DEV), epi=1, mode=3, conv=(2 * H, 2 * W_))
+        lib.rt_op_gemm_debug(1)
+        old = gemm(A, Wp, bias.to(DEV), epi=1, mode=3, conv=(2 * H, 2 * W_))
+    finally:
+        lib.rt_op_gemm_debug(0)
+    report(f"patch upsample-conv {B}x{H}x{W_}x{Cin}->{Cout} vs torch", out.reshape(B, 2 * H, 2 * W_, Cout), ref, **F32_OUT)
+    report("patch upsample-conv vs implicit GEMM", out, old, atol=1e-4, rtol=1e-4)
+
+
 # ----------------------------------------------------------------------------------------------- attention
 def _ref_attention(q, k, v, heads, fontsize=None):
     """q [B,N,C], k,v [B,NK,C] fp32: the reference math (attention_processor.py:476-545, 359-407)."""

@@ -38,7 +38,7 @@ int main(int argc, char** argv) {
             g.Hin = g.Hout = c.H; g.Win = g.Wout = c.W; g.Cin = c.Cin;
             printf("conv %dx%dx%dx%d->%d:", c.B, c.H, c.W, c.Cin, c.Cout);
             for (int variant = 0; variant < 2; ++variant) {
-                auto run = [&]() { if (variant == 0) launch_conv3p<EPI_BF16>(g, 0); else launch_with_cfg(g, 2, 0); };
+                auto run = [&]() { if (variant == 0) launch_conv3p<EPI_BF16, false>(g, 0); else launch_with_cfg(g, 2, 0); };
                 for (int r = 0; r < 3; ++r) run();
                 hipEventRecord(e0, 0);
                 for (int r = 0; r < 20; ++r) run();
