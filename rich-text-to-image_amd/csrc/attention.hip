@@ -18,10 +18,17 @@
 //                                the MFMA k-slot (lane>>5, j) is bound to the same key on both operands,
 //                                so no cross-lane shuffle of P is needed)
 // One workgroup = 4 waves x 32 queries; K and V^T tiles are staged with global_load_lds into a double
-// buffer of 64-byte-row sub-tiles, XOR-swizzled on 16-B slots via the source address.
+// buffer of 64-byte-row sub-tiles, XOR-swizzled on 16-B slots via the source address (register staging was
+// measured and is slower here: 376-423 vs 700 TFLOP/s).  Built with -amdgpu-mfma-vgpr-form (Makefile).
 #include "common.h"
 #include <math.h>
 
+#ifdef RT_ATTN_TIMING
+__device__ long long g_attn_times[4 * 8];
+#define AT_T(i) { const long long now_ = __builtin_readcyclecounter(); tacc[i] += now_ - tlast; tlast = now_; }
+#else
+#define AT_T(i)
+#endif
 template <int DP, int KT, bool CROSS>
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -89,9 +96,13 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#ifdef RT_ATTN_TIMING
+    long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
     for (int kt = 0; kt < ntile; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < ntile) stage(cur ^ 1, (kt + 1) * KT);
+        AT_T(0)
         const char* ks_ = smem + cur * STAGE;
         const char* vs_ = ks_ + TILE;
 
@@ -99,9 +110,11 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
         f32x16 s[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[j][r] = 0.f;
-            const int row = j * 32 + l31;
+            s[j] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // folds into the first MFMA's inline-constant C operand
+            // MFMA row i of this 32-key sub-tile reads key perm(i) = i with bits 2 and 3 swapped: the accumulator register
+            // r of lane half `hi` then holds key 16*(r>>3) + 8*hi + (r&7), i.e. each run of 8 registers is 8 CONSECUTIVE
+            // keys and the matching V^T fragment is a single ds_read_b128 (no register shuffling in the P.V loop).
+            const int row = j * 32 + ((l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1));
             const int key = (row >> 2) & 3;
 #pragma unroll
             for (int ks = 0; ks < DP / 16; ++ks) {
@@ -110,14 +123,15 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
                 s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[j], 0, 0, 0);
             }
         }
-        // ---- online softmax (lane holds 16 of the 32 keys of each sub-tile for its query; partner = lane^32)
+        AT_T(1)
+        // ---- online softmax (lane holds 16 of the 32 keys of each sub-tile for its query: 8*hi + [0,8) and 16 + 8*hi + [0,8); partner = lane^32)
         float mx = m;
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 if (CROSS) {
-                    const int key = kt * KT + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const int key = kt * KT + j * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
                     if (key >= p.nk_valid) s[j][r] = -INFINITY;
                 }
                 mx = fmaxf(mx, s[j][r]);
@@ -143,16 +157,17 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
             for (int r = 0; r < 16; ++r) {
                 float pv = __builtin_amdgcn_exp2f(s[j][r] - m);      // v_exp_f32: argument <= 8, underflow flushes to 0
                 if (CROSS) {
-                    const int kl = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const int kl = j * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
                     pv *= wl[kl];
                     rs += pv;
                     pv *= wl[KT + kl];
                 } else {
-                    rs += pv;
+                    rs += pv;                                      // (v_pk_add_f32 pairs measured slower: 131 extra v_mov)
                 }
                 s[j][r] = pv;
             }
         l += rs;
+        AT_T(2)
 
         // ---- O^T += V^T P^T
 #pragma unroll
@@ -165,21 +180,29 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
             for (int dt = 0; dt < ND; ++dt) {
                 const int row = dt * 32 + l31;
                 const int key = (row >> 2) & 3;
-                const char* rp = vs_ + (j * DP + row) * 64 + hi * 8;
-                const bf16x4 lo = *(const bf16x4*)(rp + (((2 * hh) ^ key) << 4));
-                const bf16x4 hi4 = *(const bf16x4*)(rp + (((2 * hh + 1) ^ key) << 4));
-                const bf16x8 vf = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+                const bf16x8 vf = *(const bf16x8*)(vs_ + (j * DP + row) * 64 + (((2 * hh + hi) ^ key) << 4));
                 o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
             }
         }
+        AT_T(3)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        AT_T(4)
         __syncthreads();
+        AT_T(5)
     }
+#ifdef RT_ATTN_TIMING
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0) for (int i = 0; i < 6; ++i) g_attn_times[wave * 8 + i] = tacc[i];
+#endif
 
     l += __shfl_xor(l, 32);
     const float inv = 1.f / l;
-    if (q < p.N) {
-        bf16_t* optr = p.O + ((size_t)b * p.N + q) * p.ldo + h * DP + 4 * hi;
+    // Epilogue through LDS: in the accumulator layout a lane owns ONE query row and 4-element runs of d, so direct stores touch
+    // 32 rows with 8 B each per instruction (store-issue-bound tail, guide T21).  Every wave transposes its 32 x DP tile in its
+    // own slab of the (now idle) K/V buffers - the loop ended with a barrier - and writes whole 16-B chunks, 8 lanes per row.
+    {
+        constexpr int RS = DP * 2 + 16;                          // slab row stride (16-B pad)
+        constexpr int CPR = DP * 2 / 16;                          // 16-B chunks per row
+        char* slab = smem + wave * 32 * RS;
 #pragma unroll
         for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
@@ -187,8 +210,17 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
                 uint2 v;
                 v.x = pack_bf16x2(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv);
                 v.y = pack_bf16x2(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
-                *(uint2*)(optr + dt * 32 + 8 * g) = v;
+                *(uint2*)(slab + l31 * RS + (dt * 32 + 8 * g + 4 * hi) * 2) = v;
             }
+        // LDS operations of one wave execute in order: no barrier between the slab write and read
+#pragma unroll
+        for (int idx0 = 0; idx0 < 32 * CPR; idx0 += 64) {
+            const int idx = idx0 + lane;
+            const int r = idx / CPR, ch = idx - r * CPR;
+            const int qq = q0 + wave * 32 + r;
+            if (r < 32 && qq < p.N)
+                *(uint4*)(p.O + ((size_t)b * p.N + qq) * p.ldo + h * DP + ch * 8) = *(const uint4*)(slab + r * RS + ch * 16);
+        }
     }
 }
 
@@ -208,9 +240,9 @@ static void launch_t(const AttnArgs& a, hipStream_t st) {
 
 void launch_attention(const AttnArgs& a, hipStream_t st) {
     RT_REQUIRE(a.B >= 1 && a.B <= RT_MAXB, "attention: batch must be in [1,16]");
-    RT_REQUIRE(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldvt % 8 == 0 && a.ldo % 4 == 0, "attention: leading dims");
+    RT_REQUIRE(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldvt % 8 == 0 && a.ldo % 8 == 0, "attention: leading dims");
     RT_REQUIRE(((uintptr_t)a.Q & 15) == 0 && ((uintptr_t)a.K & 15) == 0 && ((uintptr_t)a.VT & 15) == 0 &&
-               ((uintptr_t)a.O & 7) == 0, "attention: alignment");
+               ((uintptr_t)a.O & 15) == 0, "attention: alignment");
     if (a.cross) {
         RT_REQUIRE(a.NK == 96 && a.nk_valid <= 96 && a.wabs && a.wsgn, "cross-attention expects 77 keys padded to 96");
         switch (a.DP) {
