@@ -174,6 +174,7 @@ struct GroupNormBwdArgs {
     bf16_t* out_bf16;                  // optional bf16 copy (operand of the next backward conv)
 };
 void launch_groupnorm_bwd(const GroupNormBwdArgs& a, hipStream_t st);
+void launch_gn_finalize(float* partial, int B, int nchunk, int G, double n, float eps, int mode, hipStream_t st);
 void launch_transpose_bf16(const bf16_t* in, bf16_t* out, int R, int C, hipStream_t st);        // [R,C] -> [C,R]
 void launch_softmax_rows(const float* s, bf16_t* p, int rows, int cols, float scale, hipStream_t st);
 // dS = scale * P o (dP - rowsum(dP o P))   (bf16 out)

@@ -66,24 +66,50 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GroupNormArgs p) {
     }
 }
 
-// grid (nchunk, B)
+// grid (B): reduce the per-chunk partials ONCE per batch entry (fixed order => deterministic; fp64) and leave the result in
+// chunk 0's slot: partial[b][0][g] = (A, B).  mode 0: (mean, rstd) from (sum, sumsq); mode 1: (s/n, q/n) (backward means).
+// Before this kernel existed every block of the apply kernels re-reduced all nchunk partials itself: at the VAE's 1024^2
+// maps (8192 chunks) that was 4.8 ms per GroupNorm backward instead of ~0.3 ms.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(float* partial, int nchunk, int G, double n, float eps, int mode) {
+    __shared__ double sh[2][8][32];
+    const int b = blockIdx.x, g = threadIdx.x & 31, k0 = threadIdx.x >> 5;
+    double s = 0.0, q = 0.0;
+    if (g < G)
+        for (int k = k0; k < nchunk; k += 8) {
+            s += (double)partial[((size_t)b * nchunk + k) * 2 * G + 2 * g];
+            q += (double)partial[((size_t)b * nchunk + k) * 2 * G + 2 * g + 1];
+        }
+    sh[0][k0][g] = s; sh[1][k0][g] = q;
+    __syncthreads();
+    if (threadIdx.x < G) {
+        s = 0.0; q = 0.0;
+        for (int k = 0; k < 8; ++k) { s += sh[0][k][g]; q += sh[1][k][g]; }
+        float A, Bv;
+        if (mode == 0) {
+            const double mu = s / n;
+            double var = q / n - mu * mu;
+            if (var < 0) var = 0;
+            A = (float)mu; Bv = (float)(1.0 / sqrt(var + (double)eps));
+        } else {
+            A = (float)(s / n); Bv = (float)(q / n);
+        }
+        partial[(size_t)b * nchunk * 2 * G + 2 * g] = A;
+        partial[(size_t)b * nchunk * 2 * G + 2 * g + 1] = Bv;
+    }
+}
+void launch_gn_finalize(float* partial, int B, int nchunk, int G, double n, float eps, int mode, hipStream_t st) {
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, st, partial, nchunk, G, n, eps, mode);
+}
+
+// grid (nchunk, B); reads the finalized (mean, rstd) of partial[b][0][g]
 template <bool BF16IN>
 __global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormArgs p) {
     __shared__ float mean[32], rstd[32];
     const int C = p.C1 + p.C2, cpg = C / p.G, nv = C >> 2;
     const int b = blockIdx.y, chunk = blockIdx.x;
     if (threadIdx.x < p.G) {
-        double s = 0.0, ss = 0.0;
-        for (int k = 0; k < p.nchunk; ++k) {
-            s += (double)p.partial[((size_t)b * p.nchunk + k) * 2 * p.G + 2 * threadIdx.x];
-            ss += (double)p.partial[((size_t)b * p.nchunk + k) * 2 * p.G + 2 * threadIdx.x + 1];
-        }
-        const double n = (double)cpg * p.HW;
-        const double mu = s / n;
-        double var = ss / n - mu * mu;
-        if (var < 0) var = 0;
-        mean[threadIdx.x] = (float)mu;
-        rstd[threadIdx.x] = (float)(1.0 / sqrt(var + (double)p.eps));
+        mean[threadIdx.x] = p.partial[(size_t)b * p.nchunk * 2 * p.G + 2 * threadIdx.x];
+        rstd[threadIdx.x] = p.partial[(size_t)b * p.nchunk * 2 * p.G + 2 * threadIdx.x + 1];
     }
     __syncthreads();
     const int r0 = chunk * p.rows_per_chunk;
@@ -127,11 +153,14 @@ void launch_groupnorm(const GroupNormArgs& a, hipStream_t st) {
     RT_REQUIRE(a.nchunk == groupnorm_nchunk(a.HW) && a.rows_per_chunk == gn_rows_per_chunk(a.HW), "groupnorm: nchunk mismatch");
     RT_REQUIRE(C <= GN_MAXC, "groupnorm: too many channels");
     dim3 grid(a.nchunk, a.B), block(256);
+    const double n = (double)(C / a.G) * a.HW;
     if (a.in_bf16) {
         hipLaunchKernelGGL(gn_stats_kernel<true>, grid, block, 0, st, a);
+        launch_gn_finalize(a.partial, a.B, a.nchunk, a.G, n, a.eps, 0, st);
         hipLaunchKernelGGL(gn_apply_kernel<true>, grid, block, 0, st, a);
     } else {
         hipLaunchKernelGGL(gn_stats_kernel<false>, grid, block, 0, st, a);
+        launch_gn_finalize(a.partial, a.B, a.nchunk, a.G, n, a.eps, 0, st);
         hipLaunchKernelGGL(gn_apply_kernel<false>, grid, block, 0, st, a);
     }
     HIP_CHECK(hipGetLastError());

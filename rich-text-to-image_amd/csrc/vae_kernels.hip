@@ -17,17 +17,11 @@ __device__ __forceinline__ void ld4(const void* x, int bf16in, size_t off, float
         v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
     }
 }
+// forward statistics as launch_groupnorm left them: partial[b][0][g] = (mean, rstd) (gn_finalize_kernel, norm.hip)
 __device__ __forceinline__ void fwd_stats(const GroupNormBwdArgs& p, int b, float* mean, float* rstd) {
-    const int cpg = p.C / p.G;
     if (threadIdx.x < p.G) {
-        double s = 0.0, ss = 0.0;
-        for (int k = 0; k < p.nchunk; ++k) {
-            s += (double)p.fwd_partial[((size_t)b * p.nchunk + k) * 2 * p.G + 2 * threadIdx.x];
-            ss += (double)p.fwd_partial[((size_t)b * p.nchunk + k) * 2 * p.G + 2 * threadIdx.x + 1];
-        }
-        const double n = (double)cpg * p.HW, mu = s / n;
-        double var = ss / n - mu * mu; if (var < 0) var = 0;
-        mean[threadIdx.x] = (float)mu; rstd[threadIdx.x] = (float)(1.0 / sqrt(var + (double)p.eps));
+        mean[threadIdx.x] = p.fwd_partial[(size_t)b * p.nchunk * 2 * p.G + 2 * threadIdx.x];
+        rstd[threadIdx.x] = p.fwd_partial[(size_t)b * p.nchunk * 2 * p.G + 2 * threadIdx.x + 1];
     }
 }
 // dxh for 4 channels of one row
@@ -90,14 +84,9 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GroupNormBwdArgs p) {
     const int C = p.C, cpg = C / p.G, nv = C >> 2;
     const int b = blockIdx.y, chunk = blockIdx.x;
     fwd_stats(p, b, mean, rstd);
-    if (threadIdx.x < p.G) {
-        double s = 0.0, q = 0.0;
-        for (int k = 0; k < p.nchunk; ++k) {
-            s += (double)p.bwd_partial[((size_t)b * p.nchunk + k) * 2 * p.G + 2 * threadIdx.x];
-            q += (double)p.bwd_partial[((size_t)b * p.nchunk + k) * 2 * p.G + 2 * threadIdx.x + 1];
-        }
-        const double n = (double)cpg * p.HW;
-        m1[threadIdx.x] = (float)(s / n); m2[threadIdx.x] = (float)(q / n);
+    if (threadIdx.x < p.G) {           // finalized by gn_finalize_kernel (mode 1)
+        m1[threadIdx.x] = p.bwd_partial[(size_t)b * p.nchunk * 2 * p.G + 2 * threadIdx.x];
+        m2[threadIdx.x] = p.bwd_partial[(size_t)b * p.nchunk * 2 * p.G + 2 * threadIdx.x + 1];
     }
     __syncthreads();
     const int r0 = chunk * p.rows_per_chunk, r1 = min(r0 + p.rows_per_chunk, p.HW);
@@ -126,6 +115,7 @@ void launch_groupnorm_bwd(const GroupNormBwdArgs& a, hipStream_t st) {
     RT_REQUIRE(a.G >= 1 && a.G <= 32 && a.C % a.G == 0 && a.C % 4 == 0 && a.C <= GN_MAXC, "groupnorm_bwd: bad channel/group count");
     dim3 grid(a.nchunk, a.B), block(256);
     hipLaunchKernelGGL(gn_bwd_stats_kernel, grid, block, 0, st, a);
+    launch_gn_finalize(a.bwd_partial, a.B, a.nchunk, a.G, (double)(a.C / a.G) * a.HW, 0.f, 1, st);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, grid, block, 0, st, a);
     HIP_CHECK(hipGetLastError());
 }

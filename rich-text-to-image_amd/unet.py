@@ -31,7 +31,10 @@ class HipUNet2DConditionModel:
                        max_prompts=self.max_prompts)
             if self._state_dict is None:
                 raise RuntimeError("HipUNet2DConditionModel: no weights loaded (call load_state_dict)")
-            e.load_state_dict(self._state_dict)
+            if isinstance(self._state_dict, str) and self._state_dict.startswith("random"):
+                e.init_random_weights(seed=int(self._state_dict[6:] or 0))      # "random<seed>": benchmarks without checkpoints
+            else:
+                e.load_state_dict(self._state_dict)
             self._engines[key] = e
         return self._engines[key]
 
