@@ -66,24 +66,26 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GroupNormArgs p) {
     }
 }
 
-// grid (B): reduce the per-chunk partials ONCE per batch entry (fixed order => deterministic; fp64) and leave the result in
+// grid (G, B): reduce the per-chunk partials ONCE per (batch entry, group) (fixed order => deterministic; fp64) and leave the result in
 // chunk 0's slot: partial[b][0][g] = (A, B).  mode 0: (mean, rstd) from (sum, sumsq); mode 1: (s/n, q/n) (backward means).
 // Before this kernel existed every block of the apply kernels re-reduced all nchunk partials itself: at the VAE's 1024^2
 // maps (8192 chunks) that was 4.8 ms per GroupNorm backward instead of ~0.3 ms.
 __global__ __launch_bounds__(256) void gn_finalize_kernel(float* partial, int nchunk, int G, double n, float eps, int mode) {
-    __shared__ double sh[2][8][32];
-    const int b = blockIdx.x, g = threadIdx.x & 31, k0 = threadIdx.x >> 5;
+    __shared__ double sh[2][256];
+    const int b = blockIdx.y, g = blockIdx.x, t = threadIdx.x;          // one block per (batch entry, group)
     double s = 0.0, q = 0.0;
-    if (g < G)
-        for (int k = k0; k < nchunk; k += 8) {
-            s += (double)partial[((size_t)b * nchunk + k) * 2 * G + 2 * g];
-            q += (double)partial[((size_t)b * nchunk + k) * 2 * G + 2 * g + 1];
-        }
-    sh[0][k0][g] = s; sh[1][k0][g] = q;
+    for (int k = t; k < nchunk; k += 256) {
+        s += (double)partial[((size_t)b * nchunk + k) * 2 * G + 2 * g];
+        q += (double)partial[((size_t)b * nchunk + k) * 2 * G + 2 * g + 1];
+    }
+    sh[0][t] = s; sh[1][t] = q;
     __syncthreads();
-    if (threadIdx.x < G) {
-        s = 0.0; q = 0.0;
-        for (int k = 0; k < 8; ++k) { s += sh[0][k][g]; q += sh[1][k][g]; }
+    for (int w = 128; w > 0; w >>= 1) {                                 // fixed tree => deterministic
+        if (t < w) { sh[0][t] += sh[0][t + w]; sh[1][t] += sh[1][t + w]; }
+        __syncthreads();
+    }
+    if (t == 0) {
+        s = sh[0][0]; q = sh[1][0];
         float A, Bv;
         if (mode == 0) {
             const double mu = s / n;
@@ -93,12 +95,13 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(float* partial, int nc
         } else {
             A = (float)(s / n); Bv = (float)(q / n);
         }
+        // chunk 0's raw partial of THIS group was read above by this block only (thread 0, k = 0): safe to overwrite
         partial[(size_t)b * nchunk * 2 * G + 2 * g] = A;
         partial[(size_t)b * nchunk * 2 * G + 2 * g + 1] = Bv;
     }
 }
 void launch_gn_finalize(float* partial, int B, int nchunk, int G, double n, float eps, int mode, hipStream_t st) {
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, st, partial, nchunk, G, n, eps, mode);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, B), dim3(256), 0, st, partial, nchunk, G, n, eps, mode);
 }
 
 // grid (nchunk, B); reads the finalized (mean, rstd) of partial[b][0][g]
