@@ -27,7 +27,7 @@ def main(fetch_db, write_db, out):
             continue
         res[name] = dict(launches=fn, avg_us=fd / fn / 1e3, fetch_kib_per_launch=fv / fn, write_kib_per_launch=wv / wn,
                          hbm_bytes_per_launch=(2 * fv / fn + wv / wn) * 1024)
-    classes = {"gemm_dense": lambda n: "gemm" in n and ("<0," in n), "gemm_conv": lambda n: "gemm" in n and "<0," not in n,
+    classes = {"gemm_dense": lambda n: "gemm" in n and ("<0," in n), "gemm_conv": lambda n: ("gemm" in n and "<0," not in n) or "conv3p" in n,
                "attn_self": lambda n: "attn_kernel" in n and "false" in n, "attn_cross": lambda n: "attn_kernel" in n and "true" in n}
     summary = {}
     for c, pred in classes.items():
