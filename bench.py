@@ -108,7 +108,7 @@ def main():
     # ---- weights: rank 0 draws + packs them, everyone else receives the packed bf16 arena (one broadcast)
     sd_cpu = None
     if rank == 0:
-        keep_cpu = (world == 1 or True) and not args.no_cpu_baseline
+        keep_cpu = world == 1 and not args.no_cpu_baseline          # the CPU baseline is an N=1, rank-0 leg only
         g = torch.Generator(device=dev).manual_seed(0)
         sd_cpu = {} if keep_cpu else None
         for name, shape in eng.weight_table():

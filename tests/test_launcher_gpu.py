@@ -1,0 +1,50 @@
+"""GPU side of the seed-parallel launcher: the packed weight arena as a zero-copy torch tensor and an RCCL ("nccl") broadcast of
+it.  One GPU is available to the tests, so the process group has a single rank (two ranks cannot share a device under RCCL);
+the 2-rank logic is covered by the gloo test."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_SCRIPT = r'''
+import os, sys, torch
+sys.path.insert(0, %r)
+import torch.distributed as dist
+from rich_text_to_image_amd import launcher
+from rich_text_to_image_amd.engine import Engine
+from oracle.unet import TINY_XL_CONFIG, random_state_dict
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d", rank=0, world_size=1)
+eng = Engine(TINY_XL_CONFIG, 32, 32, device=0)
+eng.load_state_dict(random_state_dict(TINY_XL_CONFIG, seed=3))
+t = launcher.arena_tensor(eng)
+ptr, nbytes = eng.arena()
+assert t.is_cuda and t.dtype == torch.uint8 and t.numel() == nbytes and t.data_ptr() == ptr
+before = t.clone()
+assert int(before.count_nonzero()) > nbytes // 4                     # packed weights are really there
+flat = t.view(-1)
+for off in range(0, flat.numel(), 1 << 20):                             # the chunked broadcast of launcher.broadcast_tensor
+    dist.broadcast(flat[off:off + (1 << 20)], src=0)
+torch.cuda.synchronize()
+assert torch.equal(t, before)
+assert launcher.max_over_ranks(2.5, device="cuda:0") == 2.5
+launcher.barrier()
+x = torch.randn(2, 4, 32, 32, device="cuda:0")
+eng.set_prompts(torch.randn(2, 77, TINY_XL_CONFIG["cross_attention_dim"], device="cuda:0"), torch.randn(2, 32, device="cuda:0"),
+                torch.tensor([[256., 256, 0, 0, 256, 256]]))
+y = eng.unet_forward(x, 500.0, [0, 1])
+assert torch.isfinite(y).all()
+dist.destroy_process_group()
+print("LAUNCHER_GPU_OK")
+'''
+
+
+def test_arena_view_and_rccl_broadcast_single_rank():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29600 + os.getpid() % 300
+    r = subprocess.run([sys.executable, "-c", _SCRIPT % (ROOT, port)], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0 and "LAUNCHER_GPU_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
