@@ -47,10 +47,14 @@ void run(const char* name, int blocks, const char* src, int ld) {
 }
 int main() {
     char* src; hipMalloc(&src, 64 << 20); hipMemset(src, 1, 64 << 20);
-    for (int ld : {2560, 2688, 2816, 3072, 1280, 1408, 5120, 5376, 10240, 10496}) {
-        char nm[64]; snprintf(nm, 64, "swizzled rows ld=%d, all CUs", ld);
-        run<8, 8, 1>(nm, 256, src, ld);
-    }
-    run<8, 8, 2>("contiguous 1 KiB, all CUs", 256, src, 2560);
+    run<8, 8, 1>("swizzled rows ld=2560, all CUs", 256, src, 2560);
+    run<8, 8, 2>("contiguous 1 KiB pieces, all CUs", 256, src, 2560);
+    run<8, 8, 1>("swizzled rows ld=2560, 128 CUs", 128, src, 2560);
+    run<8, 8, 2>("contiguous 1 KiB pieces, 128 CUs", 128, src, 2560);
+    run<8, 8, 1>("swizzled rows ld=2560, 32 CUs", 32, src, 2560);
+    run<8, 8, 1>("swizzled rows ld=2560, 1 CU", 1, src, 2560);
+    run<4, 8, 1>("swizzled rows, 4 waves, all CUs", 256, src, 2560);
+    run<16, 4, 1>("swizzled rows, 16 waves, all CUs", 256, src, 2560);
+    run<8, 8, 3>("plain dwordx4 loads to VGPR, all CUs", 256, src, 2560);
     return 0;
 }
