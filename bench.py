@@ -86,6 +86,47 @@ def cpu_baseline(sd_cpu, threads):
                 forward_seconds=dt)
 
 
+def cross_attention_block(dev, F=7):
+    """The block BASELINE.json's north star names: SDXL cross-attention (attn2) = to_q GEMM -> attention over 77 keys (K/V from the
+    per-prompt cache, font-size multipliers) -> to_out GEMM + fp32 residual, for the F batched streams of a step, through the
+    C-ABI operators the engine itself launches.  FLOPs = executed MFMA work (7.51 G shape A / 7.11 G shape B per stream)."""
+    import ctypes as C
+    from rich_text_to_image_amd.engine import _ptr, load_library
+    lib = load_library()
+    out = {}
+    for name, N, Cc, H in (("A_4096x640", 4096, 640, 10), ("B_1024x1280", 1024, 1280, 20)):
+        DP, M = 64, F * N
+        g = torch.Generator(device=dev).manual_seed(1)
+        bf = lambda *s, sc=1.0: (torch.randn(*s, generator=g, device=dev) * sc).to(torch.bfloat16)
+        x, wq, wo = bf(M, Cc), bf(H * DP, Cc, sc=Cc ** -0.5), bf(Cc, H * DP, sc=(H * DP) ** -0.5)
+        K, VT = bf(5 * 96, H * DP), bf(H * DP, 5 * 96)
+        wabs = torch.zeros(2, 96, device=dev); wabs[:, :77] = 1.0; wabs[1, 5:7] = 20.0
+        wsgn = torch.ones(2, 96, device=dev)
+        trunk = torch.randn(M, Cc, generator=g, device=dev)
+        q = torch.empty(M, H * DP, device=dev, dtype=torch.bfloat16); o = torch.empty_like(q); y = torch.empty_like(trunk)
+        ia = lambda v: (C.c_int * F)(*v)
+        idx, prm, ws = ia(range(F)), ia([0, 4, 0, 4, 1, 2, 3][:F]), ia([0, 1, 0, 0, 0, 0, 0][:F])
+
+        def block():
+            lib.rt_op_gemm(_ptr(x), _ptr(wq), None, _ptr(q), None, None, 0, 0, M, H * DP, Cc, Cc, Cc, H * DP, 0, 0, 0, 0, 0, 0, 0, 0, None)
+            lib.rt_op_attention(_ptr(q), H * DP, _ptr(K), H * DP, _ptr(VT), 5 * 96, _ptr(o), H * DP, idx, prm, prm, ws, _ptr(wabs), _ptr(wsgn),
+                                F, H, N, 96, 77, DP, 1, None)
+            lib.rt_op_gemm(_ptr(o), _ptr(wo), None, _ptr(y), _ptr(trunk), None, 0, 1, M, Cc, H * DP, H * DP, H * DP, Cc, Cc, 0, 0, 0, 0, 0, 0, 0, None)
+        for _ in range(3):
+            block()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(20):
+            block()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        flops = F * (4.0 * N * Cc * H * DP + 4.0 * H * N * 77 * 64)
+        out[name] = dict(ms=ms, tflops=flops / (ms * 1e-3) / 1e12, frac=flops / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS)
+    out["note"] = "to_q + attention(77 keys, cached K/V, font-size softmax) + to_out(+fp32 residual) for the 7 streams of a step; executed FLOPs"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -196,6 +237,13 @@ def main():
                                         tflops=(v["total_flops"] / (v["total_ms"] * 1e-3) / 1e12) if v["total_ms"] > 0 else 0.0)
                                 for k, v in prof.items()})
 
+    xblock = None
+    if rank == 0:
+        try:
+            xblock = cross_attention_block(dev)
+        except Exception as ex:          # the headline line must still print
+            xblock = {"error": repr(ex)}
+
     cpu = None
     if rank == 0 and not args.no_cpu_baseline and sd_cpu is not None:
         threads = max(1, min(os.cpu_count() or 1, 256))
@@ -223,7 +271,7 @@ def main():
             "whole_step_tflops_per_gpu": step_tflop / (dt / args.steps),
             "whole_step_mfma_frac": step_tflop / (dt / args.steps) / PEAK_BF16_TFLOPS,
             "weight_broadcast_s": bcast_s, "finite": finite,
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "cross_attention_block": xblock,
         }
         print(json.dumps(line))
     if world > 1:
