@@ -26,24 +26,31 @@ __device__ __forceinline__ void load4(const void* x1, const void* x2, int C1, in
     }
 }
 
-// Thread decomposition shared by both kernels: nv = C/4 channel vectors per row.
-//   nv >= 256: every thread walks vectors tid, tid+256, ... over all rows of the chunk (1 row lane)
-//   nv <  256: 256/nv row lanes, each thread owns one vector and every (256/nv)-th row
+// Thread decomposition shared by both kernels: nv = C/4 channel vectors per row; the block is tcols x nrl threads
+// (gn_block_shape): tcols = ceil(nv / ceil(nv/512)) vector columns, nrl = 512 / tcols row lanes; a thread owns the vectors
+// v0, v0 + tcols, ... and every nrl-th row.  (With a fixed 256-thread block 38 % of the threads idled at C = 640 / 1280.)
 #define GN_MAXC 2560
+struct GnShape { int tcols, nrl; };
+__host__ __device__ inline GnShape gn_block_shape(int nv) {
+    const int iters = (nv + 511) / 512;
+    GnShape s; s.tcols = (nv + iters - 1) / iters; s.nrl = 512 / s.tcols; if (s.nrl < 1) s.nrl = 1;
+    return s;
+}
 
 // grid (nchunk, B); partial[b][chunk][g][2] = (sum, sumsq) over this chunk's rows
 template <bool BF16IN>
-__global__ __launch_bounds__(256) void gn_stats_kernel(GroupNormArgs p) {
+__global__ __launch_bounds__(512) void gn_stats_kernel(GroupNormArgs p) {
     __shared__ float sh_s[GN_MAXC], sh_q[GN_MAXC];
     const int C = p.C1 + p.C2, cpg = C / p.G, nv = C >> 2;
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int r0 = chunk * p.rows_per_chunk;
     const int r1 = min(r0 + p.rows_per_chunk, p.HW);
-    const int nrl = nv >= 256 ? 1 : 256 / nv;
-    const int rl = nv >= 256 ? 0 : threadIdx.x / nv;
-    const int v0 = nv >= 256 ? threadIdx.x : threadIdx.x % nv;
+    const GnShape shp = gn_block_shape(nv);
+    const int nrl = shp.nrl, tcols = shp.tcols;
+    const int rl = threadIdx.x / tcols;
+    const int v0 = threadIdx.x - rl * tcols;
     if (rl < nrl) {
-        for (int vec = v0; vec < nv; vec += 256) {
+        for (int vec = v0; vec < nv; vec += tcols) {
             const int c = vec * 4;
             float s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
             for (int r = r0 + rl; r < r1; r += nrl) {
@@ -106,7 +113,7 @@ void launch_gn_finalize(float* partial, int B, int nchunk, int G, double n, floa
 
 // grid (nchunk, B); reads the finalized (mean, rstd) of partial[b][0][g]
 template <bool BF16IN>
-__global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormArgs p) {
+__global__ __launch_bounds__(512) void gn_apply_kernel(GroupNormArgs p) {
     __shared__ float mean[32], rstd[32];
     const int C = p.C1 + p.C2, cpg = C / p.G, nv = C >> 2;
     const int b = blockIdx.y, chunk = blockIdx.x;
@@ -117,11 +124,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormArgs p) {
     __syncthreads();
     const int r0 = chunk * p.rows_per_chunk;
     const int r1 = min(r0 + p.rows_per_chunk, p.HW);
-    const int nrl = nv >= 256 ? 1 : 256 / nv;
-    const int rl = nv >= 256 ? 0 : threadIdx.x / nv;
-    const int v0 = nv >= 256 ? threadIdx.x : threadIdx.x % nv;
+    const GnShape shp = gn_block_shape(nv);
+    const int nrl = shp.nrl, tcols = shp.tcols;
+    const int rl = threadIdx.x / tcols;
+    const int v0 = threadIdx.x - rl * tcols;
     if (rl >= nrl) return;
-    for (int vec = v0; vec < nv; vec += 256) {
+    for (int vec = v0; vec < nv; vec += tcols) {
         const int c = vec * 4;
         float ga[4], be[4], mu[4], rs[4];
 #pragma unroll
@@ -155,7 +163,9 @@ void launch_groupnorm(const GroupNormArgs& a, hipStream_t st) {
     RT_REQUIRE(!(a.in_bf16 && a.x2), "groupnorm: bf16 input cannot be a concat");
     RT_REQUIRE(a.nchunk == groupnorm_nchunk(a.HW) && a.rows_per_chunk == gn_rows_per_chunk(a.HW), "groupnorm: nchunk mismatch");
     RT_REQUIRE(C <= GN_MAXC, "groupnorm: too many channels");
-    dim3 grid(a.nchunk, a.B), block(256);
+    const GnShape shp = gn_block_shape(C >> 2);
+    RT_REQUIRE(shp.nrl * C <= GN_MAXC || shp.nrl == 1, "groupnorm: LDS staging too small");
+    dim3 grid(a.nchunk, a.B), block(shp.tcols * shp.nrl);
     const double n = (double)(C / a.G) * a.HW;
     if (a.in_bf16) {
         hipLaunchKernelGGL(gn_stats_kernel<true>, grid, block, 0, st, a);
