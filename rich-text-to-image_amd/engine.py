@@ -93,6 +93,9 @@ def load_library(path=None):
     for name in _SYMBOLS:
         if name not in ("rt_last_error", "rt_op_last_error", "rt_vae_last_error"):
             getattr(lib, name).restype = C.c_int
+    flags = int(os.environ.get("RTDIFF_DEBUG_FLAGS", "0"))      # A/B switches of rt_op_gemm_debug (benchmarks only)
+    if flags:
+        lib.rt_op_gemm_debug(flags)
     if path is None:
         _lib = lib
     return lib
