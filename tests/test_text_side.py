@@ -60,3 +60,29 @@ def test_sdxl_prompt_encoding_rules(tok):
     with torch.no_grad():
         o1, o2 = e1(ids, output_hidden_states=True), e2(ids, output_hidden_states=True)
     assert torch.allclose(pe[:1], torch.cat([o1.hidden_states[-2], o2.hidden_states[-2]], -1)) and torch.allclose(pp[:1], o2[0])
+
+
+def test_bpe_matches_the_hf_tokenizers_clip_recipe(tmp_path):
+    """Independent pin for the BPE merge loop / byte alphabet / pre-tokenisation: the `tokenizers` library configured the way
+    CLIPTokenizerFast is (NFC + whitespace collapse + lowercase, the CLIP split regex, byte-level alphabet, `</w>` suffix)."""
+    from tokenizers import Regex, Tokenizer, normalizers, pre_tokenizers
+    from tokenizers.models import BPE
+    from rich_text_to_image_amd import clip_tokenizer as ct
+    alpha = list(ct._byte_alphabet().values())
+    vocab = alpha + [a + "</w>" for a in alpha]
+    merges = [("c", "a"), ("ca", "t</w>"), ("t", "h"), ("th", "e</w>"), ("d", "o"), ("do", "g</w>"), ("i", "n"), ("in", "g</w>"), ("r", "u"),
+              ("ru", "n"), ("n", "ing</w>"), ("a", "n"), ("an", "d</w>"), ("s", "k"), ("sk", "y</w>"), ("'", "s</w>")]
+    vocab += [a + b for a, b in merges] + ["<|startoftext|>", "<|endoftext|>"]
+    v = {t: i for i, t in enumerate(vocab)}
+    ref = Tokenizer(BPE(vocab=v, merges=merges, end_of_word_suffix="</w>", unk_token="<|endoftext|>", continuing_subword_prefix="", fuse_unk=False))
+    ref.normalizer = normalizers.Sequence([normalizers.NFC(), normalizers.Replace(Regex(r"\s+"), " "), normalizers.Lowercase()])
+    pat = r"""<\|startoftext\|>|<\|endoftext\|>|'s|'t|'re|'ve|'m|'ll|'d|[\p{L}]+|[\p{N}]|[^\s\p{L}\p{N}]+"""
+    ref.pre_tokenizer = pre_tokenizers.Sequence([pre_tokenizers.Split(Regex(pat), behavior="removed", invert=True),
+                                                 pre_tokenizers.ByteLevel(add_prefix_space=False)])
+    json.dump(v, open(tmp_path / "vocab.json", "w"))
+    open(tmp_path / "merges.txt", "w").write("#version: 0.2\n" + "\n".join(a + " " + b for a, b in merges) + "\n")
+    mine = ct.ClipBPETokenizer.from_pretrained(str(tmp_path))
+    for txt in ["The cat's  running dog, 42 cats!", "a night sky and the dog's running", "café über naïve 東京", "it's the cats' sky...!!",
+                "  multiple   spaces\tand\nnewlines ", "A close-up 4k dslr photo of a cat riding a scooter. There are palm trees in the background."]:
+        assert mine._tokenize(txt) == ref.encode(txt).tokens, txt
+        assert mine.convert_tokens_to_ids(mine._tokenize(txt)) == ref.encode(txt).ids
