@@ -151,8 +151,8 @@ class HipAttnProcessor:
             ctx[:, :NK].copy_(encoder_hidden_states)
             kv_in = self._bf16(ctx.reshape(B * NKp, Dc))
         else:
-            if N % 64:
-                raise NotImplementedError("self-attention needs a token count that is a multiple of 64")
+            if N % 8:
+                raise NotImplementedError("self-attention needs a token count that is a multiple of 8")
             NK = NKp = N
             kv_in = x
         if isinstance(real_attn_probs, AttnMapHandle):

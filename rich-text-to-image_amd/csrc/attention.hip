@@ -29,7 +29,10 @@ __device__ long long g_attn_times[4 * 8];
 #else
 #define AT_T(i)
 #endif
-template <int DP, int KT, bool CROSS>
+// RAGGED (self-attention only): NK is not a multiple of the key tile (token grids like 12x12 or 20x20): the last tile re-reads
+// clamped rows / 8-key chunks (always valid memory of this batch entry) and masks the keys >= NK.  NK % 8 == 0 is required so
+// that the 16-B V^T chunks of every batch entry stay aligned.
+template <int DP, int KT, bool CROSS, bool RAGGED = false>
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE = KT * DP * 2;          // bytes of one K (or V^T) tile
@@ -74,12 +77,14 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
                 {
                     const int sub = rl / KT, row = rl - sub * KT;
                     const int ls = ps ^ ((row >> 2) & 3);
-                    glds16(kbase + (size_t)(key0 + row) * p.ldk + sub * 32 + ls * 8, ks_ + (c0 + wave * 64) * 16);
+                    int kr = key0 + row; if (RAGGED && kr > p.NK - 1) kr = p.NK - 1;
+                    glds16(kbase + (size_t)kr * p.ldk + sub * 32 + ls * 8, ks_ + (c0 + wave * 64) * 16);
                 }
                 {
                     const int sub = rl / DP, row = rl - sub * DP;
                     const int ls = ps ^ ((row >> 2) & 3);
-                    glds16(vbase + (size_t)row * p.ldvt + key0 + sub * 32 + ls * 8, vs_ + (c0 + wave * 64) * 16);
+                    int kc = key0 + sub * 32 + ls * 8; if (RAGGED && kc > p.NK - 8) kc = p.NK - 8;
+                    glds16(vbase + (size_t)row * p.ldvt + kc, vs_ + (c0 + wave * 64) * 16);
                 }
             }
         }
@@ -92,7 +97,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
     float m = -1e30f, l = 0.f;
 
-    const int ntile = p.NK / KT;
+    const int ntile = (p.NK + KT - 1) / KT;
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -130,9 +135,9 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                if (CROSS) {
+                if (CROSS || RAGGED) {
                     const int key = kt * KT + j * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
-                    if (key >= p.nk_valid) s[j][r] = -INFINITY;
+                    if (key >= (CROSS ? p.nk_valid : p.NK)) s[j][r] = -INFINITY;
                 }
                 mx = fmaxf(mx, s[j][r]);
             }
@@ -224,17 +229,17 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     }
 }
 
-template <int DP, int KT, bool CROSS>
+template <int DP, int KT, bool CROSS, bool RAGGED = false>
 static void launch_t(const AttnArgs& a, hipStream_t st) {
     const size_t lds = 4 * (size_t)KT * DP * 2 + (CROSS ? 2 * KT * sizeof(float) : 0);
     static bool attr = false;
     if (!attr) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)attn_kernel<DP, KT, CROSS>,
+        HIP_CHECK(hipFuncSetAttribute((const void*)attn_kernel<DP, KT, CROSS, RAGGED>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
     dim3 grid(cdiv(a.N, 128), a.H, a.B), block(256);
-    hipLaunchKernelGGL((attn_kernel<DP, KT, CROSS>), grid, block, lds, st, a);
+    hipLaunchKernelGGL((attn_kernel<DP, KT, CROSS, RAGGED>), grid, block, lds, st, a);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -253,12 +258,13 @@ void launch_attention(const AttnArgs& a, hipStream_t st) {
             default: throw rt_error(RT_E_UNSUPPORTED, "attention: unsupported padded head dim");
         }
     } else {
-        RT_REQUIRE(a.NK % 64 == 0, "self-attention: key count must be a multiple of 64");
+        RT_REQUIRE(a.NK % 8 == 0 && a.NK >= 8, "self-attention: key count must be a multiple of 8");
+        const bool ragged = a.NK % 64 != 0;
         switch (a.DP) {
-            case 32: launch_t<32, 64, false>(a, st); break;
-            case 64: launch_t<64, 64, false>(a, st); break;
-            case 96: launch_t<96, 64, false>(a, st); break;
-            case 160: launch_t<160, 64, false>(a, st); break;
+            case 32: ragged ? launch_t<32, 64, false, true>(a, st) : launch_t<32, 64, false>(a, st); break;
+            case 64: ragged ? launch_t<64, 64, false, true>(a, st) : launch_t<64, 64, false>(a, st); break;
+            case 96: ragged ? launch_t<96, 64, false, true>(a, st) : launch_t<96, 64, false>(a, st); break;
+            case 160: ragged ? launch_t<160, 64, false, true>(a, st) : launch_t<160, 64, false>(a, st); break;
             default: throw rt_error(RT_E_UNSUPPORTED, "attention: unsupported padded head dim");
         }
     }

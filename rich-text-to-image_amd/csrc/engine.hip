@@ -460,7 +460,7 @@ struct rt_engine {
     Tensor transformer(TransformerP& t, const FwdIn& in, int HW, Tensor x) {
         const int B = in.B, M = B * HW, C = t.C, HD = t.heads * t.DP;
         RT_REQUIRE(x.C == C, "transformer: channel mismatch");
-        RT_REQUIRE(HW % 64 == 0, "transformer: token count must be a multiple of 64");
+        RT_REQUIRE(HW % 8 == 0, "transformer: token count (h*w of the attention level) must be a multiple of 8");
         float* out = ws.f32((size_t)M * C);
         {
             Scope sc(ws);

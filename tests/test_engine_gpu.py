@@ -177,3 +177,31 @@ def test_errors_are_reported_like_the_reference(tiny_sd):
     eng.set_masks(g["inputs"]["masks"].repeat(1, 4, 1, 1).to(DEV))
     with pytest.raises(RtError):
         eng.region_step(0, 7.5, 0, 0, xl=False)
+
+
+def test_forward_at_a_ragged_token_grid_matches_oracle():
+    """Image sizes whose deepest attention level is not a multiple of 64 tokens (here latent 96 -> 12x12 = 144 keys): the
+    self-attention kernel masks the tail of its last key tile.  Streams incl. injection, against the oracle."""
+    from rich_text_to_image_amd.engine import RtError
+    cfg, sd = TINY_SD_CONFIG, random_state_dict(TINY_SD_CONFIG, seed=11)
+    hw = 96
+    eng = make_engine(cfg, hw, sd)
+    g = torch.Generator().manual_seed(5)
+    emb = torch.randn(2, 77, cfg["cross_attention_dim"], generator=g)
+    lat, lat_ref = torch.randn(1, 4, hw, hw, generator=g), torch.randn(1, 4, hw, hw, generator=g)
+    o = OracleUNet(cfg, sd)
+    t = 601.0
+    with torch.no_grad():
+        r0 = o.forward(lat, t, emb[:1], None)
+        cap = {}
+        r1 = o.forward(lat_ref, t, emb[1:2], None, ctl={"capture": cap})
+        inj = {k: v for k, v in cap.items() if k.endswith("attn1")}
+        r2 = o.forward(lat, t, emb[1:2], None, ctl={"inject": inj})
+    eng.set_prompts(emb.to(DEV))
+    out = eng.unet_forward(torch.cat([lat, lat_ref, lat]).to(DEV), t, [0, 1, 1], qk_src=[0, 1, 1])
+    for name, got, ref in (("uncond", out[0], r0[0]), ("text_ref", out[1], r1[0]), ("injected", out[2], r2[0])):
+        r = rel_l2(got, ref)
+        print(f"ragged grid {name}: rel-L2 {r:.3e}")
+        assert r < 1.5e-2
+    with pytest.raises(RtError):                               # 10x10 = 100 tokens at the deepest level: not a multiple of 8
+        make_engine(cfg, 80, sd).unet_forward(torch.randn(1, 4, 80, 80, device=DEV), t, [0])

@@ -221,7 +221,8 @@ def _pack_heads(t, heads, d, DP, scale=1.0):
 
 
 @pytest.mark.parametrize("B,H,N,d", [(2, 2, 256, 64), (1, 4, 128, 8), (2, 3, 320, 40), (1, 2, 64, 160), (1, 2, 192, 80),
-                                     (2, 10, 1024, 64)])
+                                     (2, 10, 1024, 64),
+                                     (3, 2, 144, 64), (2, 5, 400, 64), (2, 2, 16, 32), (1, 3, 72, 40), (2, 2, 1296, 64)])    # ragged: N % 64 != 0
 def test_self_attention(B, H, N, d):
     DP = 32 if d <= 32 else 64 if d <= 64 else 96 if d <= 96 else 160
     q, k, v = rnd(B, N, H * d, seed=30), rnd(B, N, H * d, seed=31), rnd(B, N, H * d, seed=32)
