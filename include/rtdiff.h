@@ -142,6 +142,14 @@ int rt_op_small_linear(const float* a, int lda, const void* W_bf16, int ldw, con
                        int B, int N, int K, int silu_in, int accumulate, void* stream);
 int rt_op_timestep_embed(const float* t, int n, int dim, float* out, int ldo, void* stream);
 int rt_op_cast_bf16(const float* x, void* out_bf16, long long n, void* stream);
+/* ---- CLIP text encoder pieces (transformers' CLIPTextModel[WithProjection] as called at rd.py:53-66, xl.py:330-356); the linear layers
+ * and LayerNorms are rt_op_gemm / rt_op_layernorm.  ids [rows] int32 (device), tok [vocab, C], pos [N, C] fp32 -> out [rows, C] fp32 */
+int rt_op_embed(const int* ids, const float* tok, const float* pos, float* out, int rows, int N, int C, int vocab, void* stream);
+/* kind 0: quick_gelu (CLIP ViT-L), 1: gelu/erf (OpenCLIP bigG); bf16 -> bf16, n elements */
+int rt_op_activation(const void* x_bf16, void* out_bf16, long long n, int kind, void* stream);
+/* causal self-attention over N <= 128 tokens: q, k, v bf16 [B*N, ld] with head h at column h*d; out bf16 [B*N, ldo] */
+int rt_op_causal_attention(const void* q, const void* k, const void* v, int ld, void* out, int ldo, int B, int H, int N, int d, float scale,
+                           void* stream);
 /* Head-averaged attention probabilities of ONE batch entry (the `attention_probs_avg` the reference processor returns,
  * attention_processor.py:541-545, reshape_batch_dim_to_heads_and_average): out[N, NK] (=|+=) mean_h softmax(Q_h K_h^T).
  * Q rows q_row0+[0,N), K rows k_row0+[0,NKrows) in the rt_op_attention layouts; NK valid keys (<= 1024), NKpad = padded key count. */

@@ -1,9 +1,9 @@
 """Checkpoint / text-side plumbing around the engine: diffusers-layout directory -> façade objects.
 
 Replaces `StableDiffusionPipeline / AutoencoderKL / CLIPTextModel.from_pretrained` at rd.py:26-33 and xl.py:95-130.
-The UNet and VAE decoder go to the HIP engine; the CLIP text encoders run ONCE per prompt set, off the hot path, in
-torch through `transformers` (their output is the engine's `rt_set_prompts` input).  No checkpoint exists offline,
-so only the prompt-encoding logic is unit-tested (tiny random CLIP).
+The UNet and VAE decoder go to the HIP engine; the CLIP text encoders (once per prompt set, off the hot path) run on the same
+operators through `clip_text_encoder.HipCLIPTextEncoder` (checked against transformers' CLIPTextModel on random weights).  No
+checkpoint exists offline, so the directory loaders themselves are untested here.
 """
 import glob
 import json
@@ -86,10 +86,16 @@ class ClipEncodersXL:
         return pe, ne, pp, npool
 
 
+def load_text_encoder(path, device=0, with_projection=False):
+    """CLIP text encoder directory (config.json + safetensors) -> HipCLIPTextEncoder (GEMMs / LayerNorm / causal attention on the
+    engine's operators; no transformers model is instantiated)."""
+    from .clip_text_encoder import HipCLIPTextEncoder
+    return HipCLIPTextEncoder(load_state_dict_dir(path), _component_config(path), device=device, with_projection=with_projection)
+
+
 def load_pipeline(load_path, kind="SD", device=0, latent_hw=None):
     """kind 'SD' -> RegionDiffusion, 'SDXL' -> RegionDiffusionXL, from a diffusers-layout directory
     (unet/, vae/, tokenizer[_2]/, text_encoder[_2]/).  `latent_hw` sizes the VAE plan (default: the model's native size)."""
-    from transformers import CLIPTextModel, CLIPTextModelWithProjection
     from .engine import SD_VAE_CONFIG, SDXL_VAE_CONFIG, VaeDecoder
     dev = torch.device(f"cuda:{device}")
     unet_sd = load_state_dict_dir(os.path.join(load_path, "unet"))
@@ -103,12 +109,12 @@ def load_pipeline(load_path, kind="SD", device=0, latent_hw=None):
     tok = ClipBPETokenizer.from_pretrained(load_path, "tokenizer")
     if kind == "SD":
         from .region_diffusion import RegionDiffusion
-        enc = CLIPTextModel.from_pretrained(os.path.join(load_path, "text_encoder"))
+        enc = load_text_encoder(os.path.join(load_path, "text_encoder"), device)
         return RegionDiffusion(device, unet_state_dict=unet_sd, vae=vae, tokenizer=tok, text_encoder=ClipEncoderSD(enc, dev))
     from .region_diffusion_sdxl import RegionDiffusionXL
     tok2 = ClipBPETokenizer.from_pretrained(load_path, "tokenizer_2")
-    enc1 = CLIPTextModel.from_pretrained(os.path.join(load_path, "text_encoder"))
-    enc2 = CLIPTextModelWithProjection.from_pretrained(os.path.join(load_path, "text_encoder_2"))
+    enc1 = load_text_encoder(os.path.join(load_path, "text_encoder"), device)
+    enc2 = load_text_encoder(os.path.join(load_path, "text_encoder_2"), device, with_projection=True)
     fz = True
     mi = os.path.join(load_path, "model_index.json")
     if os.path.exists(mi):

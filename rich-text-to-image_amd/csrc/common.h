@@ -130,6 +130,11 @@ void launch_cast_f32_bf16(const float* x, bf16_t* out, size_t n, hipStream_t st)
 void launch_small_linear(const float* a, int lda, const bf16_t* W, int ldw, const float* bias, float* out, int ldo,
                          int B, int N, int K, int silu_in, int accumulate, hipStream_t st);
 void launch_timestep_embed(const float* t, int n, int dim, float* out, int ldo, hipStream_t st);
+// CLIP text encoder pieces (text.hip)
+void launch_embed(const int* ids, const float* tok, const float* pos, float* out, int rows, int N, int C, int vocab, hipStream_t st);
+void launch_activation(const bf16_t* x, bf16_t* out, size_t n, int kind, hipStream_t st);      // 0 quick_gelu, 1 gelu(erf)
+void launch_causal_attention(const bf16_t* q, const bf16_t* k, const bf16_t* v, int ld, bf16_t* out, int ldo, int B, int H, int N, int d,
+                             float scale, hipStream_t st);
 
 // weight packing (device side): strided gather fp32/fp16/bf16 -> bf16 (or f32) with scale.
 //   dst (r, c) <- scale * src[ srow(r)*s_r + (c / c_inner)*s_co + (c % c_inner)*s_ci ]   (0 where invalid)

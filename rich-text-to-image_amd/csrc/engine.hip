@@ -1050,6 +1050,16 @@ int rt_op_small_linear(const float* a, int lda, const void* W, int ldw, const fl
 int rt_op_timestep_embed(const float* t, int n, int dim, float* out, int ldo, void* stream) {
     OP_TRY({ launch_timestep_embed(t, n, dim, out, ldo, (hipStream_t)stream); })
 }
+int rt_op_embed(const int* ids, const float* tok, const float* pos, float* out, int rows, int N, int C, int vocab, void* stream) {
+    OP_TRY({ launch_embed(ids, tok, pos, out, rows, N, C, vocab, (hipStream_t)stream); })
+}
+int rt_op_activation(const void* x_bf16, void* out_bf16, long long n, int kind, void* stream) {
+    OP_TRY({ launch_activation((const bf16_t*)x_bf16, (bf16_t*)out_bf16, (size_t)n, kind, (hipStream_t)stream); })
+}
+int rt_op_causal_attention(const void* q, const void* k, const void* v, int ld, void* out, int ldo, int B, int H, int N, int d, float scale,
+                           void* stream) {
+    OP_TRY({ launch_causal_attention((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ld, (bf16_t*)out, ldo, B, H, N, d, scale, (hipStream_t)stream); })
+}
 int rt_op_cast_bf16(const float* x, void* out_bf16, long long n, void* stream) {
     OP_TRY({ RT_REQUIRE(n > 0, "cast: empty"); launch_cast_f32_bf16(x, (bf16_t*)out_bf16, (size_t)n, (hipStream_t)stream); })
 }
