@@ -86,6 +86,36 @@ class ClipEncodersXL:
         return pe, ne, pp, npool
 
 
+_UNET_KEYS = ("in_channels", "out_channels", "block_out_channels", "down_block_types", "up_block_types", "layers_per_block",
+              "transformer_layers_per_block", "attention_head_dim", "cross_attention_dim", "norm_num_groups", "norm_eps", "use_linear_projection",
+              "addition_embed_type", "addition_time_embed_dim", "projection_class_embeddings_input_dim")
+
+
+def unet_config(path, default):
+    """`unet/config.json` (UNet2DConditionModel kwargs) over the defaults of the model family; absent keys keep diffusers' defaults."""
+    cfg = dict(default)
+    js = _component_config(path)
+    if js:
+        cfg.update({"transformer_layers_per_block": 1, "use_linear_projection": False, "norm_eps": 1e-5, "addition_embed_type": None,
+                    "addition_time_embed_dim": None, "projection_class_embeddings_input_dim": None})
+        cfg.update({k: js[k] for k in _UNET_KEYS if k in js and js[k] is not None})
+        for k in ("block_out_channels", "down_block_types", "up_block_types"):
+            cfg[k] = tuple(cfg[k])
+        for k in ("transformer_layers_per_block", "attention_head_dim", "layers_per_block"):
+            if isinstance(cfg[k], list):
+                cfg[k] = tuple(cfg[k])
+    return cfg
+
+
+def vae_config(path, default):
+    cfg = dict(default)
+    js = _component_config(path)
+    for k in ("block_out_channels", "layers_per_block", "norm_num_groups", "scaling_factor", "latent_channels", "out_channels"):
+        if js.get(k) is not None:
+            cfg[k] = tuple(js[k]) if isinstance(js[k], list) else js[k]
+    return cfg
+
+
 def load_text_encoder(path, device=0, with_projection=False):
     """CLIP text encoder directory (config.json + safetensors) -> HipCLIPTextEncoder (GEMMs / LayerNorm / causal attention on the
     engine's operators; no transformers model is instantiated)."""
@@ -96,21 +126,19 @@ def load_text_encoder(path, device=0, with_projection=False):
 def load_pipeline(load_path, kind="SD", device=0, latent_hw=None):
     """kind 'SD' -> RegionDiffusion, 'SDXL' -> RegionDiffusionXL, from a diffusers-layout directory
     (unet/, vae/, tokenizer[_2]/, text_encoder[_2]/).  `latent_hw` sizes the VAE plan (default: the model's native size)."""
-    from .engine import SD_VAE_CONFIG, SDXL_VAE_CONFIG, VaeDecoder
+    from .engine import SD15_CONFIG, SD_VAE_CONFIG, SDXL_CONFIG, SDXL_VAE_CONFIG, VaeDecoder
     dev = torch.device(f"cuda:{device}")
     unet_sd = load_state_dict_dir(os.path.join(load_path, "unet"))
     vae_sd = load_state_dict_dir(os.path.join(load_path, "vae"))
-    vae_cfg = dict(SD_VAE_CONFIG if kind == "SD" else SDXL_VAE_CONFIG)
-    sf = _component_config(os.path.join(load_path, "vae")).get("scaling_factor")
-    if sf:
-        vae_cfg["scaling_factor"] = sf
+    unet_cfg = unet_config(os.path.join(load_path, "unet"), SD15_CONFIG if kind == "SD" else SDXL_CONFIG)
+    vae_cfg = vae_config(os.path.join(load_path, "vae"), SD_VAE_CONFIG if kind == "SD" else SDXL_VAE_CONFIG)
     hw = latent_hw or ((64, 64) if kind == "SD" else (128, 128))
     vae = VaeDecoder(vae_cfg, hw[0], hw[1], device=device, state_dict=vae_sd)
     tok = ClipBPETokenizer.from_pretrained(load_path, "tokenizer")
     if kind == "SD":
         from .region_diffusion import RegionDiffusion
         enc = load_text_encoder(os.path.join(load_path, "text_encoder"), device)
-        return RegionDiffusion(device, unet_state_dict=unet_sd, vae=vae, tokenizer=tok, text_encoder=ClipEncoderSD(enc, dev))
+        return RegionDiffusion(device, unet_state_dict=unet_sd, config=unet_cfg, vae=vae, tokenizer=tok, text_encoder=ClipEncoderSD(enc, dev))
     from .region_diffusion_sdxl import RegionDiffusionXL
     tok2 = ClipBPETokenizer.from_pretrained(load_path, "tokenizer_2")
     enc1 = load_text_encoder(os.path.join(load_path, "text_encoder"), device)
@@ -119,5 +147,5 @@ def load_pipeline(load_path, kind="SD", device=0, latent_hw=None):
     mi = os.path.join(load_path, "model_index.json")
     if os.path.exists(mi):
         fz = json.load(open(mi)).get("force_zeros_for_empty_prompt", True)
-    return RegionDiffusionXL(load_path, device, unet_state_dict=unet_sd, vae=vae, tokenizer=tok, vae_scaling_factor=vae_cfg["scaling_factor"],
+    return RegionDiffusionXL(load_path, device, unet_state_dict=unet_sd, config=unet_cfg, vae=vae, tokenizer=tok, vae_scaling_factor=vae_cfg["scaling_factor"],
                              text_encoders=ClipEncodersXL([tok, tok2], [enc1, enc2], dev, fz))

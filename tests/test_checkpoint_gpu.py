@@ -1,0 +1,119 @@
+"""From disk to image: a synthetic diffusers-layout checkpoint directory (tiny random UNet / VAE / CLIP text encoder as safetensors +
+config.json, synthetic BPE vocabulary) -> checkpoint.load_pipeline -> the sample.py flow.  Exercises the loaders no real checkpoint
+can exercise offline (rd.py:26-33 / xl.py:95-130 replacements)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle.unet import TINY_SD_CONFIG, random_state_dict  # noqa: E402
+from oracle.vae import TINY_VAE_CONFIG, random_vae_state_dict  # noqa: E402
+
+
+def _write_dir(root):
+    from safetensors.torch import save_file
+    from transformers import CLIPTextConfig, CLIPTextModel
+    from rich_text_to_image_amd import clip_tokenizer as ct
+    for sub in ("unet", "vae", "tokenizer", "text_encoder"):
+        os.makedirs(os.path.join(root, sub))
+    ucfg = {k: (list(v) if isinstance(v, tuple) else v) for k, v in TINY_SD_CONFIG.items()}
+    json.dump(dict(ucfg, _class_name="UNet2DConditionModel"), open(os.path.join(root, "unet", "config.json"), "w"))
+    save_file({k: v.contiguous() for k, v in random_state_dict(TINY_SD_CONFIG, seed=1).items()}, os.path.join(root, "unet", "diffusion_pytorch_model.safetensors"))
+    vcfg = {k: (list(v) if isinstance(v, tuple) else v) for k, v in TINY_VAE_CONFIG.items()}
+    json.dump(dict(vcfg, _class_name="AutoencoderKL"), open(os.path.join(root, "vae", "config.json"), "w"))
+    save_file({k: v.contiguous() for k, v in random_vae_state_dict(TINY_VAE_CONFIG, seed=2).items()}, os.path.join(root, "vae", "diffusion_pytorch_model.safetensors"))
+    # tokenizer: byte alphabet + a few merges
+    alpha = list(ct._byte_alphabet().values())
+    vocab = alpha + [a + "</w>" for a in alpha]
+    merges = [("s", "k"), ("sk", "y</w>"), ("b", "a"), ("ba", "r"), ("bar", "n</w>"), ("f", "e"), ("fe", "n"), ("fen", "c"), ("fenc", "e</w>")]
+    vocab += [a + b for a, b in merges] + ["<|startoftext|>", "<|endoftext|>"]
+    json.dump({t: i for i, t in enumerate(vocab)}, open(os.path.join(root, "tokenizer", "vocab.json"), "w"))
+    open(os.path.join(root, "tokenizer", "merges.txt"), "w").write("#version: 0.2\n" + "\n".join(a + " " + b for a, b in merges) + "\n")
+    json.dump({"pad_token": "<|endoftext|>"}, open(os.path.join(root, "tokenizer", "special_tokens_map.json"), "w"))
+    eos = len(vocab) - 1
+    torch.manual_seed(3)
+    ccfg = CLIPTextConfig(vocab_size=len(vocab), hidden_size=TINY_SD_CONFIG["cross_attention_dim"], intermediate_size=128, num_hidden_layers=2,
+                          num_attention_heads=2, max_position_embeddings=77, hidden_act="quick_gelu", eos_token_id=eos, bos_token_id=eos - 1, pad_token_id=eos)
+    enc = CLIPTextModel(ccfg).eval()
+    json.dump(ccfg.to_dict(), open(os.path.join(root, "text_encoder", "config.json"), "w"))
+    save_file({("text_model." + k if not k.startswith("text_model.") else k): v.contiguous() for k, v in enc.state_dict().items()},
+              os.path.join(root, "text_encoder", "model.safetensors"))      # transformers-4.x key layout, as on the hub
+    return enc
+
+
+def test_load_pipeline_and_generate_from_disk(tmp_path):
+    from rich_text_to_image_amd.checkpoint import load_pipeline
+    from rich_text_to_image_amd.sample import generate
+    enc = _write_dir(str(tmp_path))
+    m = load_pipeline(str(tmp_path), "SD", device=0, latent_hw=(64, 64))
+    assert m.unet.config_dict["block_out_channels"] == tuple(TINY_SD_CONFIG["block_out_channels"])
+    # text embeddings through tokenizer + HIP text encoder vs the transformers module the weights came from
+    emb = m.get_text_embeds(["a night sky above a barn"], [""])
+    ids = m.tokenizer(["a night sky above a barn"], padding="max_length", max_length=77, truncation=True, return_tensors="pt").input_ids
+    with torch.no_grad():
+        ref = enc(ids)[0]
+    err = ((emb[1:].cpu() - ref).pow(2).sum() / ref.pow(2).sum()).sqrt().item()
+    print("text embeddings vs transformers rel-L2", err)
+    assert emb.shape == (2, 77, TINY_SD_CONFIG["cross_attention_dim"]) and err < 2e-2
+    js = {"ops": [{"insert": "a "}, {"attributes": {"font": "slabo"}, "insert": "night sky"}, {"insert": " above a "},
+                  {"attributes": {"color": "#ff0000"}, "insert": "barn"}, {"insert": " and a fence\n"}]}
+    param = {"text_input": js, "height": 512, "width": 512, "guidance_weight": 7.5, "steps": 12, "noise_index": 1, "negative_prompt": ""}
+    lat = torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(0))
+    plain, rich, _ = generate(m, param, "SD", None, color_guidance_weight=0.5, inject_selfattn=0.3, num_segments=5, latents=lat.clone())
+    assert plain.shape == rich.shape == (1, 512, 512, 3) and rich.dtype == np.uint8 and len(m.masks) == 3
+    assert np.isfinite(rich.astype(np.float32)).all() and (rich != plain).any()
+
+
+def test_load_sdxl_pipeline_from_disk(tmp_path):
+    """SDXL layout: two tokenizers / text encoders (the second with projection), text_time conditioning, prompts as strings."""
+    from safetensors.torch import save_file
+    from transformers import CLIPTextConfig, CLIPTextModel, CLIPTextModelWithProjection
+    from oracle.unet import TINY_XL_CONFIG
+    from rich_text_to_image_amd import clip_tokenizer as ct
+    from rich_text_to_image_amd.checkpoint import load_pipeline
+    root = str(tmp_path)
+    for sub in ("unet", "vae", "tokenizer", "tokenizer_2", "text_encoder", "text_encoder_2"):
+        os.makedirs(os.path.join(root, sub))
+    lst = lambda d: {k: (list(v) if isinstance(v, tuple) else v) for k, v in d.items()}
+    json.dump(lst(TINY_XL_CONFIG), open(os.path.join(root, "unet", "config.json"), "w"))
+    save_file({k: v.contiguous() for k, v in random_state_dict(TINY_XL_CONFIG, seed=4).items()}, os.path.join(root, "unet", "diffusion_pytorch_model.safetensors"))
+    json.dump(lst(TINY_VAE_CONFIG), open(os.path.join(root, "vae", "config.json"), "w"))
+    save_file({k: v.contiguous() for k, v in random_vae_state_dict(TINY_VAE_CONFIG, seed=5).items()}, os.path.join(root, "vae", "diffusion_pytorch_model.safetensors"))
+    json.dump({"force_zeros_for_empty_prompt": True}, open(os.path.join(root, "model_index.json"), "w"))
+    alpha = list(ct._byte_alphabet().values())
+    vocab = alpha + [a + "</w>" for a in alpha] + ["<|startoftext|>", "<|endoftext|>"]
+    for t in ("tokenizer", "tokenizer_2"):
+        json.dump({tk: i for i, tk in enumerate(vocab)}, open(os.path.join(root, t, "vocab.json"), "w"))
+        open(os.path.join(root, t, "merges.txt"), "w").write("#version: 0.2\n")
+    json.dump({"pad_token": "!"}, open(os.path.join(root, "tokenizer_2", "special_tokens_map.json"), "w"))     # SDXL's second tokenizer pads with "!"
+    eos = len(vocab) - 1
+    torch.manual_seed(6)
+    base = dict(vocab_size=len(vocab), intermediate_size=64, num_hidden_layers=2, num_attention_heads=2, max_position_embeddings=77,
+                eos_token_id=eos, bos_token_id=eos - 1, pad_token_id=eos)
+    c1 = CLIPTextConfig(hidden_size=32, hidden_act="quick_gelu", **base)
+    c2 = CLIPTextConfig(hidden_size=32, hidden_act="gelu", projection_dim=32, **base)
+    e1, e2 = CLIPTextModel(c1).eval(), CLIPTextModelWithProjection(c2).eval()
+    for sub, cfg, enc in (("text_encoder", c1, e1), ("text_encoder_2", c2, e2)):
+        json.dump(cfg.to_dict(), open(os.path.join(root, sub, "config.json"), "w"))
+        save_file({("text_model." + k if not (k.startswith("text_model.") or k.startswith("text_projection")) else k): v.contiguous()
+                   for k, v in enc.state_dict().items()}, os.path.join(root, sub, "model.safetensors"))
+    m = load_pipeline(root, "SDXL", device=0, latent_hw=(128, 128))
+    pe, ne, pp, npool = m.encode_prompt(["a night sky", "a red barn"], None)
+    ids = m.tokenizer(["a night sky"], padding="max_length", max_length=77, truncation=True, return_tensors="pt").input_ids
+    ids2 = m.text_encoders.tokenizers[1](["a night sky"], padding="max_length", max_length=77, truncation=True, return_tensors="pt").input_ids
+    assert not torch.equal(ids, ids2)                     # the second tokenizer pads with "!" (xl.py:318-334 tokenises per encoder)
+    with torch.no_grad():
+        o1, o2 = e1(ids, output_hidden_states=True), e2(ids2, output_hidden_states=True)
+    ref = torch.cat([o1.hidden_states[-2], o2.hidden_states[-2]], -1)
+    err = ((pe[:1].cpu() - ref).pow(2).sum() / ref.pow(2).sum()).sqrt().item()
+    errp = ((pp[:1].cpu() - o2[0]).pow(2).sum() / o2[0].pow(2).sum()).sqrt().item()
+    print("SDXL prompt embeds vs transformers rel-L2", err, "pooled", errp)
+    assert pe.shape == (2, 77, 64) and pp.shape == (2, 32) and not ne.any() and err < 2e-2 and errp < 3e-2
+    m.masks = [torch.full((1, 4, 128, 128), 0.5), torch.full((1, 4, 128, 128), 0.5)]
+    img = m.sample(["a night sky", "a red barn"], negative_prompt=[""], height=1024, width=1024, num_inference_steps=3, guidance_scale=5.0,
+                   run_rich_text=True, latents=torch.randn(1, 4, 128, 128, generator=torch.Generator().manual_seed(0)), output_type="np").images
+    assert img.shape == (1, 1024, 1024, 3) and img.dtype == np.uint8
