@@ -73,7 +73,7 @@ struct GemmArgs {
     int lda, ldw, ldo, ldres, temb_ld;
     int rows_per_batch;              // Hout*Wout (conv and temb)
     int Hin, Win, Cin, Hout, Wout;   // conv geometry (Cin padded to a multiple of 8; K = 9*Cin)
-    int debug;                       // ablation probes only (tools/overhead_probe.py): 1 = no DMA in the k loop, 2 = no MFMA
+    int debug;                       // unused by the product kernels (kept so probe builds can pass flags without changing the ABI of the struct)
 };
 void launch_gemm(const GemmArgs& a, hipStream_t st);
 void gemm_force_config(int cfg);
