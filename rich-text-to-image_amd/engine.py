@@ -438,14 +438,20 @@ class VaeDecoder:
                        want_grad=False):
         """In-place update of `latents` (tensor [1,4,h,w] or raw device pointer) exactly as rd.py:151-168."""
         import torch
-        masks = torch.cat([m[:, 0].reshape(1, -1) for m in color_obj_atten]).contiguous().float().to(f"cuda:{self.device}")
-        tgt = [float(v) for t in target_rgb for v in t.flatten().tolist()]
-        mall = color_obj_atten_all.contiguous().float().to(f"cuda:{self.device}")
+        # the masks / targets are the same objects on every step of a loop (sample.py:87-88 builds them once): stage them on the
+        # device once instead of per step (image-resolution masks from pageable host memory are a synchronous multi-MB copy)
+        key = (id(color_obj_atten), id(target_rgb), id(color_obj_atten_all), len(color_obj_atten))
+        if getattr(self, "_cg_key", None) != key:
+            masks = torch.cat([m[:, 0].reshape(1, -1) for m in color_obj_atten]).contiguous().float().to(f"cuda:{self.device}")
+            tgt = [float(v) for t in target_rgb for v in t.flatten().tolist()]
+            mall = color_obj_atten_all.contiguous().float().to(f"cuda:{self.device}")
+            self._cg_key, self._cg_val = key, (masks, (C.c_float * len(tgt))(*tgt), mall, (color_obj_atten, target_rgb, color_obj_atten_all))
+        masks, tgt_arr, mall, _ = self._cg_val
         grad = torch.empty(1, 4, h, w, device=f"cuda:{self.device}") if want_grad else None
         loss = C.c_float()
         lp = latents_ptr_or_tensor if isinstance(latents_ptr_or_tensor, int) else latents_ptr_or_tensor.data_ptr()
         npp = noise_pred if isinstance(noise_pred, int) else noise_pred.data_ptr()
         self._chk(self.lib.rt_vae_color_guidance(self.h, C.c_void_p(lp), C.c_void_p(npp), C.c_float(float(alpha_t)), h, w, _ptr(masks),
-                                                 (C.c_float * len(tgt))(*tgt), len(color_obj_atten), C.c_float(float(weight)), _ptr(mall),
+                                                 tgt_arr, len(color_obj_atten), C.c_float(float(weight)), _ptr(mall),
                                                  _ptr(grad), C.byref(loss)))
         return loss.value, grad

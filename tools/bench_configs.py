@@ -71,7 +71,7 @@ def config1():
 def config2():
     from rich_text_to_image_amd.region_diffusion import RegionDiffusion
     g = torch.Generator().manual_seed(1)
-    R, hw, steps = 4, 64, 50
+    R, hw, steps = 4, 64, globals().get("STEPS_OVERRIDE", 50)
     vae = random_vae(SD_VAE_CONFIG, hw, hw)
     m = RegionDiffusion(0, unet_state_dict="random0", config=SD15_CONFIG, vae=vae)
     m.masks = masks_for(R, hw, g)
