@@ -86,3 +86,26 @@ def test_bpe_matches_the_hf_tokenizers_clip_recipe(tmp_path):
                 "  multiple   spaces\tand\nnewlines ", "A close-up 4k dslr photo of a cat riding a scooter. There are palm trees in the background."]:
         assert mine._tokenize(txt) == ref.encode(txt).tokens, txt
         assert mine.convert_tokens_to_ids(mine._tokenize(txt)) == ref.encode(txt).ids
+
+
+def test_checkpoint_config_readers(tmp_path):
+    """unet/config.json and vae/config.json of a diffusers-layout checkpoint -> engine config dicts (absent keys keep diffusers' defaults)."""
+    import os
+    from rich_text_to_image_amd.checkpoint import unet_config, vae_config
+    from rich_text_to_image_amd.engine import SD15_CONFIG, SD_VAE_CONFIG, SDXL_CONFIG
+    os.makedirs(tmp_path / "unet"); os.makedirs(tmp_path / "vae")
+    # SD-v1.5's config.json has no transformer_layers_per_block / use_linear_projection / addition_* keys
+    json.dump({"_class_name": "UNet2DConditionModel", "in_channels": 4, "out_channels": 4, "block_out_channels": [320, 640, 1280, 1280],
+               "down_block_types": ["CrossAttnDownBlock2D"] * 3 + ["DownBlock2D"], "up_block_types": ["UpBlock2D"] + ["CrossAttnUpBlock2D"] * 3,
+               "layers_per_block": 2, "attention_head_dim": 8, "cross_attention_dim": 768, "norm_num_groups": 32, "sample_size": 64},
+              open(tmp_path / "unet" / "config.json", "w"))
+    cfg = unet_config(str(tmp_path / "unet"), SDXL_CONFIG)          # a wrong default must be fully overridden
+    for k in ("block_out_channels", "down_block_types", "up_block_types", "cross_attention_dim", "layers_per_block", "norm_num_groups"):
+        assert cfg[k] == SD15_CONFIG[k], k
+    assert cfg["transformer_layers_per_block"] == 1 and cfg["use_linear_projection"] is False and cfg["addition_embed_type"] is None
+    assert cfg["attention_head_dim"] == 8
+    json.dump({"block_out_channels": [128, 256, 512, 512], "layers_per_block": 2, "norm_num_groups": 32, "scaling_factor": 0.13025},
+              open(tmp_path / "vae" / "config.json", "w"))
+    v = vae_config(str(tmp_path / "vae"), SD_VAE_CONFIG)
+    assert v["scaling_factor"] == 0.13025 and v["block_out_channels"] == (128, 256, 512, 512)
+    assert unet_config(str(tmp_path / "nowhere"), SD15_CONFIG) == SD15_CONFIG      # no config.json: the family default
