@@ -95,6 +95,13 @@ def unet_config(path, default):
     """`unet/config.json` (UNet2DConditionModel kwargs) over the defaults of the model family; absent keys keep diffusers' defaults."""
     cfg = dict(default)
     js = _component_config(path)
+    # options of UNet2DConditionModel that the engine does not implement (none of them is used by SD-v1.5 / SDXL-base): fail loudly
+    unsupported = {"resnet_time_scale_shift": ("default",), "class_embed_type": (None,), "dual_cross_attention": (False,),
+                   "only_cross_attention": (False,), "encoder_hid_dim": (None,), "time_embedding_type": ("positional",),
+                   "mid_block_type": ("UNetMidBlock2DCrossAttn",), "act_fn": ("silu",), "conv_in_kernel": (3,), "conv_out_kernel": (3,)}
+    for k, ok in unsupported.items():
+        if k in js and js[k] not in ok:
+            raise ValueError(f"unet/config.json: {k}={js[k]!r} is not supported by the engine (supported: {ok[0]!r})")
     if js:
         cfg.update({"transformer_layers_per_block": 1, "use_linear_projection": False, "norm_eps": 1e-5, "addition_embed_type": None,
                     "addition_time_embed_dim": None, "projection_class_embeddings_input_dim": None})

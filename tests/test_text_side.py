@@ -109,3 +109,6 @@ def test_checkpoint_config_readers(tmp_path):
     v = vae_config(str(tmp_path / "vae"), SD_VAE_CONFIG)
     assert v["scaling_factor"] == 0.13025 and v["block_out_channels"] == (128, 256, 512, 512)
     assert unet_config(str(tmp_path / "nowhere"), SD15_CONFIG) == SD15_CONFIG      # no config.json: the family default
+    json.dump({"resnet_time_scale_shift": "scale_shift"}, open(tmp_path / "unet" / "config.json", "w"))
+    with pytest.raises(ValueError):
+        unet_config(str(tmp_path / "unet"), SD15_CONFIG)
