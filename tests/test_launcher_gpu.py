@@ -48,3 +48,31 @@ def test_arena_view_and_rccl_broadcast_single_rank():
     port = 29600 + os.getpid() % 300
     r = subprocess.run([sys.executable, "-c", _SCRIPT % (ROOT, port)], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0 and "LAUNCHER_GPU_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_receiving_rank_path_arena_copy_then_mark_bound():
+    """What a non-zero rank does: it never binds weights, receives the packed arena bytes (here: a device copy from a second engine
+    standing in for the RCCL broadcast), marks it bound, and must then compute exactly what the sending engine computes."""
+    import torch
+    from oracle.unet import TINY_XL_CONFIG, random_state_dict
+    from rich_text_to_image_amd import launcher
+    from rich_text_to_image_amd.engine import Engine, RtError
+    src = Engine(TINY_XL_CONFIG, 32, 32, device=0)
+    src.load_state_dict(random_state_dict(TINY_XL_CONFIG, seed=9))
+    dst = Engine(TINY_XL_CONFIG, 32, 32, device=0)
+    assert dst.weights_missing()[0] > 0
+    a, b = launcher.arena_tensor(src), launcher.arena_tensor(dst)
+    assert a.numel() == b.numel()
+    b.copy_(a)
+    torch.cuda.synchronize()
+    dst.arena_mark_bound()
+    assert dst.weights_missing()[0] == 0
+    g = torch.Generator().manual_seed(1)
+    emb, pooled = torch.randn(2, 77, TINY_XL_CONFIG["cross_attention_dim"], generator=g).cuda(), torch.randn(2, 32, generator=g).cuda()
+    tid = torch.tensor([[256., 256, 0, 0, 256, 256]])
+    x = torch.randn(2, 4, 32, 32, generator=g).cuda()
+    outs = []
+    for e in (src, dst):
+        e.set_prompts(emb, pooled, tid)
+        outs.append(e.unet_forward(x, 300.0, [0, 1]))
+    assert torch.equal(outs[0], outs[1])
