@@ -130,13 +130,18 @@ def load_text_encoder(path, device=0, with_projection=False):
     return HipCLIPTextEncoder(load_state_dict_dir(path), _component_config(path), device=device, with_projection=with_projection)
 
 
-def load_pipeline(load_path, kind="SD", device=0, latent_hw=None):
+def load_pipeline(load_path, kind="SD", device=0, latent_hw=None, lora_path=None, lora_scale=1.0):
     """kind 'SD' -> RegionDiffusion, 'SDXL' -> RegionDiffusionXL, from a diffusers-layout directory
-    (unet/, vae/, tokenizer[_2]/, text_encoder[_2]/).  `latent_hw` sizes the VAE plan (default: the model's native size)."""
+    (unet/, vae/, tokenizer[_2]/, text_encoder[_2]/).  `latent_hw` sizes the VAE plan (default: the model's native size).
+    `lora_path`: a LoRA .safetensors file merged into the UNet weights before they are bound (lora.merge_lora)."""
     from .engine import SD15_CONFIG, SD_VAE_CONFIG, SDXL_CONFIG, SDXL_VAE_CONFIG, VaeDecoder
     dev = torch.device(f"cuda:{device}")
     unet_sd = load_state_dict_dir(os.path.join(load_path, "unet"))
     vae_sd = load_state_dict_dir(os.path.join(load_path, "vae"))
+    if lora_path:
+        from safetensors.torch import load_file
+        from .lora import merge_lora
+        unet_sd, _ = merge_lora(unet_sd, load_file(lora_path), lora_scale)
     unet_cfg = unet_config(os.path.join(load_path, "unet"), SD15_CONFIG if kind == "SD" else SDXL_CONFIG)
     vae_cfg = vae_config(os.path.join(load_path, "vae"), SD_VAE_CONFIG if kind == "SD" else SDXL_VAE_CONFIG)
     hw = latent_hw or ((64, 64) if kind == "SD" else (128, 128))
