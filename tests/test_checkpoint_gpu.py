@@ -117,3 +117,14 @@ def test_load_sdxl_pipeline_from_disk(tmp_path):
     img = m.sample(["a night sky", "a red barn"], negative_prompt=[""], height=1024, width=1024, num_inference_steps=3, guidance_scale=5.0,
                    run_rich_text=True, latents=torch.randn(1, 4, 128, 128, generator=torch.Generator().manual_seed(0)), output_type="np").images
     assert img.shape == (1, 1024, 1024, 3) and img.dtype == np.uint8
+
+
+def test_sample_cli_main_from_disk(tmp_path):
+    """The command line of the reference's sample.py (flags :118-133) on a synthetic checkpoint directory."""
+    from rich_text_to_image_amd import sample
+    _write_dir(str(tmp_path / "ckpt"))
+    js = json.dumps({"ops": [{"insert": "a "}, {"attributes": {"link": "a wooden fence covered in snow"}, "insert": "fence"},
+                             {"insert": " under a night sky\n"}]})
+    plain, rich = sample.main(["--load_path", str(tmp_path / "ckpt"), "--model", "SD", "--rich_text_json", js, "--sample_steps", "12",
+                               "--seed", "3", "--num_segments", "4", "--run_dir", str(tmp_path / "out"), "--inject_selfattn", "0.2"])
+    assert plain.shape == rich.shape == (1, 512, 512, 3)
