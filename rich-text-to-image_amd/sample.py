@@ -113,6 +113,11 @@ def main(argv=None):
     plain, rich, t = generate(model, param, 'SD' if a.model == 'SD' else 'SDXL', a.run_dir, a.color_guidance_weight, a.inject_selfattn,
                               a.segment_threshold, a.num_segments, a.inject_background)
     print('time lapses: plain %.3f s, token maps %.3f s, rich %.3f s' % (t['plain'], t['token_maps'], t['rich']))
+    # seed%d_plain.jpg / seed%d_rich.jpg in run_dir, as sample.py:62-76,97-112 writes them (imageio there, PIL here)
+    from PIL import Image
+    for name, img in (('plain', plain), ('rich', rich)):
+        arr = img.images[0] if hasattr(img, 'images') else img[0]
+        (arr if isinstance(arr, Image.Image) else Image.fromarray(arr)).save(os.path.join(a.run_dir, 'seed%d_%s.jpg' % (a.seed, name)))
     return plain, rich
 
 

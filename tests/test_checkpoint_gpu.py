@@ -128,3 +128,4 @@ def test_sample_cli_main_from_disk(tmp_path):
     plain, rich = sample.main(["--load_path", str(tmp_path / "ckpt"), "--model", "SD", "--rich_text_json", js, "--sample_steps", "12",
                                "--seed", "3", "--num_segments", "4", "--run_dir", str(tmp_path / "out"), "--inject_selfattn", "0.2"])
     assert plain.shape == rich.shape == (1, 512, 512, 3)
+    assert os.path.exists(tmp_path / "out" / "seed3_plain.jpg") and os.path.exists(tmp_path / "out" / "seed3_rich.jpg")
