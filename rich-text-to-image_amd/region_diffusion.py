@@ -50,7 +50,8 @@ class RegionDiffusion:
         n_styles = text_embeddings.shape[0] - 1
         assert n_styles == len(self.masks)                                  # rd.py:97
         h, w = latents.shape[2], latents.shape[3]
-        eng = self.unet.engine(h, w)
+        n_prompts = text_embeddings.shape[0]
+        eng = self.unet.engine(h, w, streams=n_prompts + 2, prompts=n_prompts)      # R+1 forwards, +2 reference forwards
         self.scheduler.set_timesteps(num_inference_steps)
         eng.set_prompts(text_embeddings.to(self.device))
         eng.set_masks([m.to(self.device) for m in self.masks])
@@ -88,7 +89,8 @@ class RegionDiffusion:
         if latents is None:
             latents = torch.randn((1, self.unet.in_channels, height // 8, width // 8), device=self.device)
         h, w = latents.shape[2], latents.shape[3]
-        eng = self.unet.engine(h, w)
+        n_prompts = text_embeddings.shape[0]
+        eng = self.unet.engine(h, w, streams=n_prompts + 2, prompts=n_prompts)      # R+1 forwards, +2 reference forwards
         self.scheduler.set_timesteps(num_inference_steps)
         eng.set_prompts(text_embeddings.to(self.device))
         eng.set_schedule(1, self.scheduler.timesteps.tolist(), self.scheduler.table(), num_inference_steps)

@@ -83,7 +83,7 @@ class RegionDiffusionXL:
         add_time_ids = self._get_add_time_ids(tuple(original_size), tuple(crops_coords_top_left), tuple(target_size))
         embeds = torch.cat([negative_prompt_embeds, prompt_embeds], 0).to(self.device).float()    # xl.py:760
         pooled = torch.cat([negative_pooled_prompt_embeds, pooled_prompt_embeds], 0).to(self.device).float()
-        eng = self.unet.engine(h, w)
+        eng = self.unet.engine(h, w, streams=embeds.shape[0] + 2 if run_rich_text else 2, prompts=embeds.shape[0])
         eng.set_prompts(embeds, pooled, add_time_ids)
         eng.set_schedule(0, self.scheduler.timesteps.tolist(), self.scheduler.table(), num_inference_steps)
         eng.set_latents(latents)

@@ -24,7 +24,20 @@ class HipUNet2DConditionModel:
         for e in self._engines.values():
             e.load_state_dict(sd)
 
-    def engine(self, h, w):
+    def engine(self, h, w, streams=None, prompts=None):
+        """Engine for latent size (h, w).  `streams` / `prompts`: what the caller is about to use (F batched forwards per step,
+        P prompts in the K/V cache); an engine sized for fewer is rebuilt once with room for them (<= 16 streams)."""
+        grow = False
+        if streams and streams > self.max_streams:
+            if streams > 16:
+                raise ValueError(f"{streams} batched UNet forwards per step exceed the engine limit of 16 (at most 13 regions with injection)")
+            self.max_streams, grow = min(16, max(streams, 2 * self.max_streams)), True
+        if prompts and prompts > self.max_prompts:
+            self.max_prompts, grow = max(prompts, 2 * self.max_prompts), True
+        if grow:
+            for e in self._engines.values():
+                e.close()
+            self._engines = {}
         key = (h, w)
         if key not in self._engines:
             e = Engine(self.config_dict, h, w, device=self.device_index, max_streams=self.max_streams,

@@ -126,3 +126,34 @@ def test_colour_guided_loop_matches_oracle_loop(xl):
     r = rel_l2(out, ref)
     print(f"colour-guided rich loop ({'xl' if xl else 'sd'}) vs oracle: rel-L2 {r:.3e}")
     assert r < 3e-2
+
+
+def test_many_regions_grow_the_engine():
+    """Seven attributed spans + base = 8 region prompts => 11 batched forwards per injected step: the facade rebuilds its engine
+    with room for them (the default holds 8 streams / 8 prompts) and still matches the oracle loop."""
+    from oracle import region_loop
+    from oracle.schedulers import OracleEuler
+    from oracle.unet import OracleUNet
+    from rich_text_to_image_amd.region_diffusion_sdxl import RegionDiffusionXL
+    cfg, hw, R, steps = TINY_XL_CONFIG, 128, 8, 2
+    sd = random_state_dict(cfg, seed=21)
+    g = torch.Generator().manual_seed(3)
+    emb = torch.randn(R + 1, 77, cfg["cross_attention_dim"], generator=g)
+    pooled = torch.randn(R + 1, 32, generator=g)
+    lat = torch.randn(1, 4, hw, hw, generator=g)
+    m = torch.softmax(torch.randn(R, 1, hw, hw, generator=g) * 2, 0).repeat(1, 4, 1, 1)
+    masks = [m[r:r + 1] for r in range(R)]
+    tfd = {"word_pos": torch.tensor([2, 3]), "font_size": torch.tensor([2.0, -1.5])}
+    sched = OracleEuler(); sched.set_timesteps(steps)
+    tid = torch.tensor([[hw * 8.0, hw * 8.0, 0, 0, hw * 8.0, hw * 8.0]])
+    ref = region_loop.rich_loop_xl(OracleUNet(cfg, sd), OracleEuler(), emb, pooled, tid, masks, lat * sched.init_noise_sigma, steps, 5.0, tfd, 1.0, 0.0)
+    mdl = RegionDiffusionXL(device=0, unet_state_dict=sd, config=cfg)
+    assert mdl.unet.max_streams == 8
+    mdl.masks = masks
+    out = mdl.sample(prompt=None, height=8 * hw, width=8 * hw, num_inference_steps=steps, guidance_scale=5.0, latents=lat.clone(),
+                     prompt_embeds=emb[1:], negative_prompt_embeds=emb[:1], pooled_prompt_embeds=pooled[1:], negative_pooled_prompt_embeds=pooled[:1],
+                     output_type="latent", run_rich_text=True, text_format_dict=tfd, inject_selfattn=1.0, inject_background=0.0).images
+    assert mdl.unet.max_streams >= R + 3 and mdl.unet.max_prompts >= R + 1
+    r = rel_l2(out, ref)
+    print("8 regions (11 streams) vs oracle rel-L2", r)
+    assert r < 3e-2
