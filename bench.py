@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 
 SDXL_FWD_GFLOP = 6761.2          # SURVEY.md section 8 [probe]: FLOPs of one batch-1 SDXL UNet forward at 128x128
 PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+PARITY_TOL = 1.5e-2              # rel-L2 of one full-architecture UNet forward vs the fp32 oracle (tests/test_fullsize_gpu.py)
 
 
 def synth_inputs(seed, R, hw, device):
@@ -55,10 +56,21 @@ def euler_tables(n):
     return ts.tolist(), sig.tolist(), float((sig.max() ** 2 + 1) ** 0.5)
 
 
-def cpu_baseline(sd_cpu, threads):
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(sd_cpu, threads, x, ctx, pooled, tid, t):
     """Reference-equivalent CPU path: the fp32 oracle restatement of the reference UNet (oracle/unet.py, pinned
     against the unmodified reference) timed on the host cores of this box.  Bounded sample: ONE batch-1 SDXL
-    UNet forward at 128x128 (the step is 7 such forwards + negligible elementwise work)."""
+    UNet forward at 128x128 (the step is 7 such forwards + negligible elementwise work), on the SAME latents /
+    prompt / timestep as one stream of the engine, so its output doubles as the full-architecture parity check."""
     from oracle.unet import SDXL_CONFIG, OracleUNet
     # pick the thread count on a cheap proxy (one GEGLU-sized fp32 matmul): oversubscribed NUMA boxes are
     # slower with every hardware thread than with a subset
@@ -73,17 +85,14 @@ def cpu_baseline(sd_cpu, threads):
     threads = best[1]
     torch.set_num_threads(threads)
     o = OracleUNet(SDXL_CONFIG, sd_cpu)
-    g = torch.Generator().manual_seed(0)
-    x = torch.randn(1, 4, 128, 128, generator=g)
-    ctx = torch.randn(1, 77, 2048, generator=g)
-    added = {"text_embeds": torch.randn(1, 1280, generator=g), "time_ids": torch.tensor([[1024.0, 1024, 0, 0, 1024, 1024]])}
+    added = {"text_embeds": pooled, "time_ids": tid}
     with torch.no_grad():
         t0 = time.perf_counter()
-        o.forward(x, 801.0, ctx, added)
+        ref = o.forward(x, t, ctx, added)
         dt = time.perf_counter() - t0
-    return dict(value=1.0 / (7 * dt), unit="steps/s", cores=threads, kind="port",
+    return dict(value=1.0 / (7 * dt), unit="steps/s", cores=threads, kind="port", cpu=cpu_model_name(),
                 sample=f"1 batch-1 SDXL UNet forward (fp32 oracle, {dt:.2f} s) x 7 forwards/step extrapolated",
-                forward_seconds=dt)
+                forward_seconds=dt), ref
 
 
 def cross_attention_block(dev, F=7):
@@ -127,14 +136,43 @@ def cross_attention_block(dev, F=7):
     return out
 
 
+def other_config(args):
+    """BASELINE.json configs 1, 2 and 5 (SURVEY 8d numbering) through the drop-in facade classes (tools/bench_configs.py holds the
+    workloads): same JSON contract, N = 1 only.  `--steps K` = K scheduler steps of the named loop (PLMS runs K+1 iterations)."""
+    assert args.gpus == 1, "configs 1/2/5 are single-GPU measurements"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_configs as bc
+    torch.cuda.set_device(0)
+    bc.STEPS_OVERRIDE = args.steps
+    bc.WARM_STEPS = max(1, args.warmup)
+    r = {1: bc.config1, 2: bc.config2, 5: bc.config5}[args.config]()
+    tf = r["tflop_per_iteration"] * r["value"]
+    line = {"metric": "denoising steps/sec (" + r["workload"].split(",")[0] + ")", "value": r["value"], "unit": "steps/s", "n_gpus": 1,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 / r["value"], "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": r["workload"], "baseline_config": args.config, "iterations_timed": r["iterations"]},
+            "finite": r["finite"],
+            "roofline": {"bound": "mfma", "kernel": "whole step (UNet forwards + VAE guidance where configured)", "achieved": tf,
+                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_BF16_TFLOPS, "traffic": None},
+            "cpu_baseline": None}
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 50; 20 for --config 1, BASELINE's 20-step case)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--elide", action="store_true", help="skip reference forwards that cannot influence the output")
+    ap.add_argument("--config", type=int, default=3, choices=[1, 2, 3, 5],
+                    help="BASELINE.json configuration (SURVEY 8d numbering): 3 = the headline SDXL workload (default); "
+                         "1 / 2 = SD-v1.5 (R=2 plain; R=4 + colour guidance); 5 = SDXL + colour guidance + background blend")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 20 if args.config == 1 else 50
+    if args.config != 3:
+        return other_config(args)
 
     from rich_text_to_image_amd import launcher
     from rich_text_to_image_amd.engine import Engine, SDXL_CONFIG
@@ -182,9 +220,14 @@ def main():
         eng.set_schedule(0, ts, sig, nsched)
         eng.set_latents(lat0)
 
+    def sched_index(i, k):
+        # fewer timed steps than the schedule has: stride over it so that injected (t > 500) and non-injected steps are timed
+        # in the schedule's own proportion; otherwise walk it cyclically
+        return (i * nsched) // k if k < nsched else i % nsched
+
     def run(k):
         for i in range(k):
-            eng.region_step(i % nsched, gs, isa, ibg, xl=True, elide=args.elide)
+            eng.region_step(sched_index(i, k), gs, isa, ibg, xl=True, elide=args.elide)
 
     reset()
     run(max(0, args.warmup - 1))
@@ -222,14 +265,15 @@ def main():
         # (FETCH_SIZE / WRITE_SIZE cannot be read from inside the process); tools/pmc_traffic.py writes the file
         traffic = None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+            tfile = next(f for f in ("r2_pmc_traffic.json", "r1_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            tj = json.load(open(os.path.join(ROOT, "profiles", tfile)))
             cls = {"gemm_kernel<A_DENSE>": "gemm_dense", "gemm_kernel<A_CONV3*>": "gemm_conv", "attn_kernel<self>": "attn_self",
                    "attn_kernel<cross>": "attn_cross"}[dom]
             traffic = tj["classes"][cls]["hbm_bytes_per_launch"]
         except Exception:
             pass
         roof = dict(bound="mfma", kernel=dom, achieved=achieved, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
-                    frac=achieved / PEAK_BF16_TFLOPS, traffic=traffic, traffic_source="profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 FETCH correction)" if traffic else None,
+                    frac=achieved / PEAK_BF16_TFLOPS, traffic=traffic, traffic_source=f"profiles/{tfile} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 FETCH correction)" if traffic else None,
                     launches=p["launches"],
                     avg_launch_us=p["total_ms"] * 1e3 / max(1, p["launches"]),
                     flops_per_launch=p["total_flops"] / max(1, p["launches"]),
@@ -250,7 +294,7 @@ def main():
         launcher.barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            eng.region_step(i % nsched, gs, isa, ibg, xl=True, elide=True)
+            eng.region_step(sched_index(i, args.steps), gs, isa, ibg, xl=True, elide=True)
         eng.synchronize(); torch.cuda.synchronize()
         dt_e = launcher.max_over_ranks(time.perf_counter() - t0, device=dev if world > 1 else "cpu")
         same = bool(torch.allclose(eng.read_latents(hw, hw), final, rtol=0, atol=0)) if args.steps <= nsched else None
@@ -264,6 +308,7 @@ def main():
             xblock = {"error": repr(ex)}
 
     cpu = None
+    parity = None
     if rank == 0 and not args.no_cpu_baseline and sd_cpu is not None:
         threads = max(1, min(os.cpu_count() or 1, 256))
         try:
@@ -273,7 +318,15 @@ def main():
                 threads = min(threads, phys)
         except Exception:
             pass
-        cpu = cpu_baseline(sd_cpu, threads)
+        # one engine stream on the oracle's inputs: prompt 0 (negative), t = 801, unscaled latents
+        gp = torch.Generator().manual_seed(4242)
+        px = torch.randn(1, 4, hw, hw, generator=gp)
+        eng.set_fontsize(None, None)
+        got = eng.unet_forward(px.to(dev), 801.0, [0]).cpu()
+        cpu, ref = cpu_baseline(sd_cpu, threads, px, inp["emb"][:1].cpu(), inp["pooled"][:1].cpu(), inp["tid"], 801.0)
+        rel = float(((got - ref).pow(2).sum() / ref.pow(2).sum()).sqrt())
+        parity = dict(rel_l2=rel, tol=PARITY_TOL, ok=bool(rel <= PARITY_TOL),
+                      config="SDXL-base full architecture, 1 UNet forward (latent 128x128, t=801, negative-prompt stream) vs the fp32 CPU oracle")
 
     if rank == 0:
         value = world * args.steps / dt
@@ -289,10 +342,13 @@ def main():
                        "elide_dead_forwards": bool(args.elide)},
             "whole_step_tflops_per_gpu": step_tflop / (dt / args.steps),
             "whole_step_mfma_frac": step_tflop / (dt / args.steps) / PEAK_BF16_TFLOPS,
-            "weight_broadcast_s": bcast_s, "finite": finite,
-            "roofline": roof, "cpu_baseline": cpu, "cross_attention_block": xblock, "elide_dead_forwards_timing": elided,
+            "weight_broadcast_s": bcast_s, "weight_broadcast_calls": launcher.LAST_BROADCAST_CALLS, "finite": finite,
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "cross_attention_block": xblock, "elide_dead_forwards_timing": elided,
+            "timed_schedule_indices": [sched_index(i, args.steps) for i in range(min(args.steps, nsched))],
         }
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
+        if parity is not None and not parity["ok"]:
+            sys.exit(f"bench: full-architecture parity FAILED: rel-L2 {parity['rel_l2']:.3e} > {PARITY_TOL}")
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -92,7 +92,10 @@ int rt_get_latents(rt_engine* e, float* latents_out, float* latents_ref_out /* m
 /* hot path ---------------------------------------------------------------------------------------- */
 /* one iteration of the rich-text loop (rd.py:99-173 / xl.py:779-872 without colour guidance):
  * all R+1 / R+3 UNet forwards batched, mask combine, CFG, scheduler step, background blend */
-int rt_region_step(rt_engine* e, int step_index, float guidance_scale, float inject_selfattn, float inject_background,
+/* inject_selfattn / inject_background are DOUBLES: the reference evaluates `t > (1-inject_selfattn)*1000` and
+ * `int(inject_background*len(timesteps))` on Python floats (rd.py:103-104, xl.py:783-784); float32 would move the blend step
+ * by one for e.g. 0.7 x 50 steps */
+int rt_region_step(rt_engine* e, int step_index, float guidance_scale, double inject_selfattn, double inject_background,
                    int xl_semantics, int flags /* bit 0: elide reference forwards that cannot influence the output;
                                                   bit 1: defer the background blend to rt_background_blend() */);
 /* the deferred blend of the last step (colour guidance sits between the scheduler step and the blend: rd.py:151-173) */
@@ -152,7 +155,8 @@ int rt_op_causal_attention(const void* q, const void* k, const void* v, int ld, 
                            void* stream);
 /* Head-averaged attention probabilities of ONE batch entry (the `attention_probs_avg` the reference processor returns,
  * attention_processor.py:541-545, reshape_batch_dim_to_heads_and_average): out[N, NK] (=|+=) mean_h softmax(Q_h K_h^T).
- * Q rows q_row0+[0,N), K rows k_row0+[0,NKrows) in the rt_op_attention layouts; NK valid keys (<= 1024), NKpad = padded key count. */
+ * Q rows q_row0+[0,N), K rows k_row0+[0,NKrows) in the rt_op_attention layouts; NK valid keys (any count: processed in chunks of
+ * 1024), NKpad = key count padded to a multiple of 32. */
 int rt_op_attention_probs_avg(const void* Q, int ldq, long long q_row0, const void* K, int ldk, long long k_row0, float* out,
                               int H, int N, int NK, int NKpad, int NKrows, int DP, int accumulate, void* stream);
 const char* rt_op_last_error(void);
@@ -180,6 +184,9 @@ int rt_vae_weight_count(rt_vae* v);
 int rt_vae_weight_info(rt_vae* v, int idx, char* name, int name_cap, int64_t* shape4, int* ndim);
 int rt_vae_bind_weight(rt_vae* v, const char* name, const void* dev_ptr, int dtype, const int64_t* shape, int ndim);
 int rt_vae_synchronize(rt_vae* v);
+/* packed decoder weights (forward + backward-data copies), for the start-up broadcast next to rt_arena_info */
+int rt_vae_arena_info(rt_vae* v, void** dev_ptr, uint64_t* bytes);
+int rt_vae_arena_mark_bound(rt_vae* v);
 /* img_out [3, 8h, 8w] f32 in [-1,1] = decode(latents [4,h,w] / scaling_factor if divide_by_scaling) */
 int rt_vae_decode(rt_vae* v, const float* latents, int h, int w, int divide_by_scaling, float* img_out);
 /* one guidance update, in place on `latents` [4,h,w]:

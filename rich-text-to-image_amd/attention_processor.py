@@ -8,8 +8,10 @@ attention_mask=None, temb=None) -> (hidden_states, [probs_avg, probs])`.
   Q/K the probabilities are a function of; handing it back as `real_attn_probs` (what the reference's injection hooks do,
   rd.py:331,366,382) runs attention with (Q_ref, K_ref, V_current), which equals `bmm(P_ref, V)`.
   It answers `.shape` / `.detach()` like the tensor the hooks expect (rd.py:326-331).
-* element [1][0] (head-averaged probabilities, consumed only by the token-map hooks rd.py:414-426) is computed lazily
-  on first tensor use (`rt_op_attention_probs_avg`).
+  A caller that passes a REAL probability tensor [B*H, N, K] instead (attention_processor.py:522-524 accepts any tensor) gets
+  `bmm(P, V)` per (batch entry, head) through `rt_op_gemm` on the bf16-cast probabilities, and the tensor itself back as [1][1].
+* element [1][0] (head-averaged probabilities, consumed only by the token-map hooks rd.py:414-426, xl.py:980-992) is computed
+  lazily on first tensor use (`rt_op_attention_probs_avg`, any key count: 64x64 SDXL self-attention maps included).
 No torch arithmetic on the activation path: casts, projections, softmax, PV and the residual are library calls; torch
 allocates buffers and reshapes views.  Weights are packed once per module (head padding, softmax scale folded into to_q).
 """
@@ -65,6 +67,30 @@ class LazyProbsAvg:
         return self.tensor()
 
     def __getattr__(self, name):             # .cpu(), indexing helpers ... forward to the real tensor
+        return getattr(self.tensor(), name)
+
+    def __getitem__(self, idx):
+        return self.tensor()[idx]
+
+
+class HeadMeanOfTensor:
+    """probs_avg when the caller supplied the probabilities itself: `reshape_batch_dim_to_heads_and_average`
+    (attention_processor.py:166-171) of that tensor, evaluated only if somebody reads it (nobody does on the injection path)."""
+
+    def __init__(self, probs, B, H):
+        self._p, self._B, self._H, self._t = probs, B, H, None
+        self.shape = torch.Size((B, probs.shape[1], probs.shape[2]))
+
+    def tensor(self):
+        if self._t is None:
+            p = self._p
+            self._t = p.reshape(self._B, self._H, p.shape[1], p.shape[2]).float().mean(1)
+        return self._t
+
+    def detach(self):
+        return self.tensor()
+
+    def __getattr__(self, name):
         return getattr(self.tensor(), name)
 
     def __getitem__(self, idx):
@@ -155,10 +181,15 @@ class HipAttnProcessor:
                 raise NotImplementedError("self-attention needs a token count that is a multiple of 8")
             NK = NKp = N
             kv_in = x
+        real_tensor = None
         if isinstance(real_attn_probs, AttnMapHandle):
             Q, K = real_attn_probs.Q, real_attn_probs.K                   # injection: attend with the captured Q/K
         elif real_attn_probs is not None:
-            raise TypeError("real_attn_probs must be the AttnMapHandle a previous call of this processor returned")
+            if not torch.is_tensor(real_attn_probs) or tuple(real_attn_probs.shape) != (B * H, N, NK):
+                raise TypeError(f"real_attn_probs must be a [{B * H}, {N}, {NK}] probability tensor (attention_processor.py:522-524) "
+                                "or the AttnMapHandle a previous call of this processor returned")
+            real_tensor = real_attn_probs
+            Q = K = None
         else:
             Q = torch.empty(B * N, HD, device=dev, dtype=torch.bfloat16)
             K = torch.empty(B * NKp, HD, device=dev, dtype=torch.bfloat16)
@@ -183,8 +214,23 @@ class HipAttnProcessor:
         O = torch.empty(B * N, HD, device=dev, dtype=torch.bfloat16)
         ia = lambda v: (C.c_int * B)(*v)
         idx = list(range(B))
-        self._chk(self.lib.rt_op_attention(_ptr(Q), Q.stride(0), _ptr(K), K.stride(0), _ptr(VT), VT.stride(0), _ptr(O), O.stride(0),
-                                           ia(idx), ia(idx), ia(idx), ia(wset), _ptr(wabs), _ptr(wsgn), B, H, N, NKp, NK, DP, int(cross), None))
+        if real_tensor is not None:
+            # hidden = bmm(P, V) with the caller's probabilities (attention_processor.py:522-527): one MFMA GEMM per (b, h),
+            # A = P[b*H+h] (bf16, keys zero-padded to NKp), W = the head's rows of V^T restricted to batch entry b's keys
+            pf = torch.zeros(B * H, N, NKp, device=dev, dtype=torch.float32)
+            pf[:, :, :NK].copy_(real_tensor)
+            pb = self._bf16(pf.reshape(B * H * N, NKp))
+            eb = 2                                                     # bytes per bf16
+            for b in range(B):
+                for h in range(H):
+                    a_ptr = C.c_void_p(pb.data_ptr() + (b * H + h) * N * NKp * eb)
+                    w_ptr = C.c_void_p(VT.data_ptr() + (h * DP * VT.stride(0) + b * NKp) * eb)
+                    o_ptr = C.c_void_p(O.data_ptr() + (b * N * HD + h * DP) * eb)
+                    self._chk(self.lib.rt_op_gemm(a_ptr, w_ptr, None, o_ptr, None, None, 0, 0, N, DP, NKp, NKp, VT.stride(0), HD,
+                                                  0, 0, 0, 0, 0, 0, 0, 0, None))
+        else:
+            self._chk(self.lib.rt_op_attention(_ptr(Q), Q.stride(0), _ptr(K), K.stride(0), _ptr(VT), VT.stride(0), _ptr(O), O.stride(0),
+                                               ia(idx), ia(idx), ia(idx), ia(wset), _ptr(wabs), _ptr(wsgn), B, H, N, NKp, NK, DP, int(cross), None))
         out = torch.empty(B * N, Cc, device=dev, dtype=torch.float32)
         res = None
         if getattr(attn, "residual_connection", False) and input_ndim != 4:
@@ -199,8 +245,10 @@ class HipAttnProcessor:
         if rof != 1.0:
             hs = hs / rof
         hs = hs.to(residual.dtype)
+        if real_tensor is not None:
+            return hs, [HeadMeanOfTensor(real_tensor, B, H), real_tensor]
         if cross and attn_weights is not None:
             avg = None                                                    # font-size maps are never captured by the reference hooks
         else:
-            avg = LazyProbsAvg(self, Q, K, B, H, N, NK, NKp, DP, cross) if NK <= 1024 else None
+            avg = LazyProbsAvg(self, Q, K, B, H, N, NK, NKp, DP, cross)
         return hs, [avg, AttnMapHandle(Q, K, B, H, N, NK)]

@@ -50,6 +50,17 @@ class HipCLIPTextEncoder:
         self.wproj = b16(sd["text_projection.weight"].float()) if with_projection else None
         self.dtype = torch.float32
 
+    def parameter_tensors(self):
+        """Every device-resident weight in a fixed order (launcher.broadcast_pipeline)."""
+        out = [self.tok, self.pos]
+        for ly in self.layers:
+            out += [ly["ln1"][0], ly["ln1"][1], ly["ln2"][0], ly["ln2"][1], ly["wqkv"], ly["bqkv"], ly["wo"], ly["bo"], ly["w1"], ly["b1"],
+                    ly["w2"], ly["b2"]]
+        out += [self.lnf[0], self.lnf[1]]
+        if self.wproj is not None:
+            out.append(self.wproj)
+        return out
+
     def _chk(self, rc):
         if rc != 0:
             raise RtError(rc, self.lib.rt_op_last_error().decode())

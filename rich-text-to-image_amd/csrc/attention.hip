@@ -43,7 +43,20 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
+    // XCD-aware work mapping.  Workgroups are dealt to the 8 XCDs round-robin by linear id; the query blocks of one (batch entry,
+    // head) all stream the same K / V^T, so they must share an L2: give every XCD a contiguous run of the (h, b, query block)
+    // space, query block fastest (bijective for any grid size).  Before this the 8 query blocks of a 1024-token head sat on 8
+    // different XCDs and every XCD fetched every head's K/V: 4.2x the algorithmic HBM traffic (profiles/r1_pmc_traffic.json).
+    int b, h, q0;
+    {
+        const int nwg = gridDim.x;
+        int bid = blockIdx.x;
+        const int qq = nwg >> 3, rr = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+        const int qb = bid % p.nqb; bid /= p.nqb;          // order (head, batch entry, query block): streams that attend with the
+        b = bid % p.B; h = bid / p.B;                          // same Q/K source (injection) are neighbours and share K in L2 too
+        q0 = qb * 128;
+    }
     const int qb = p.q_src[b], kb = p.k_src[b], vb = p.v_src[b];
 
     float* wl = (float*)(smem + 2 * STAGE);    // cross: [2][KT] multipliers
@@ -238,8 +251,10 @@ static void launch_t(const AttnArgs& a, hipStream_t st) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
-    dim3 grid(cdiv(a.N, 128), a.H, a.B), block(256);
-    hipLaunchKernelGGL((attn_kernel<DP, KT, CROSS, RAGGED>), grid, block, lds, st, a);
+    AttnArgs aa = a;
+    aa.nqb = cdiv(a.N, 128);
+    dim3 grid(aa.nqb * a.H * a.B), block(256);
+    hipLaunchKernelGGL((attn_kernel<DP, KT, CROSS, RAGGED>), grid, block, lds, st, aa);
     HIP_CHECK(hipGetLastError());
 }
 

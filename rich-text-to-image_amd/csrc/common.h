@@ -94,6 +94,7 @@ struct AttnArgs {
     int nk_valid;                // cross: keys >= nk_valid are masked out
     int DP;                      // padded head dim (multiple of 32)
     int cross;
+    int nqb;                     // set by launch_attention: 128-query blocks per (batch entry, head)
 };
 void launch_attention(const AttnArgs& a, hipStream_t st);
 

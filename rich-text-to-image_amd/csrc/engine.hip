@@ -433,21 +433,31 @@ struct rt_engine {
             groupnorm(x1.p, x2 ? x2->p : nullptr, false, c1, c2, B, HW, r.n1, cfg.norm_eps, true, h1, raw);
             float* tp = ws.f32((size_t)B * r.cout);
             if (!dry()) launch_small_linear(emb, temb_dim, r.temb.w, r.temb.K, r.temb.b, tp, r.cout, B, r.cout, temb_dim, 1, 0, stream);
-            bf16_t* h2 = ws.b16((size_t)M * r.cout);
-            conv3(h1, A_CONV3, r.c1, B, Hh, Ww, r.cin, h2, EPI_BF16_TEMB, nullptr, tp);
-            bf16_t* h3 = ws.b16((size_t)M * r.cout);
-            groupnorm(h2, nullptr, true, r.cout, 0, B, HW, r.n2, cfg.norm_eps, true, h3, nullptr);
+            // rich-text feature injection (resnet.py:639-643): out[b] = shortcut(x[b]) + hidden[res_src[b]].  The residual branch
+            // (conv1 / norm2 / conv2) of an injected stream is never used, so the trailing run of injected streams is not computed
+            // at all (the region streams of a rich-text step are the last ones): Bk streams keep their branch.
+            int Bk = B;
+            bool any_inject = false;
+            if (inject_here) {
+                for (int b = 0; b < B; ++b) any_inject |= in.res_src[b] >= 0;
+                while (Bk > 1 && in.res_src[Bk - 1] >= 0) --Bk;
+                for (int b = 0; b < B; ++b)
+                    if (in.res_src[b] >= 0) RT_REQUIRE(in.res_src[b] < Bk && in.res_src[in.res_src[b]] < 0, "resnet: a feature source stream must compute its own residual branch");
+            }
+            if (dry()) Bk = B;                       // the workspace is sized for the case without injection
+            const int Mk = Bk * HW;
+            bf16_t* h2 = ws.b16((size_t)Mk * r.cout);
+            conv3(h1, A_CONV3, r.c1, Bk, Hh, Ww, r.cin, h2, EPI_BF16_TEMB, nullptr, tp);
+            bf16_t* h3 = ws.b16((size_t)Mk * r.cout);
+            groupnorm(h2, nullptr, true, r.cout, 0, Bk, HW, r.n2, cfg.norm_eps, true, h3, nullptr);
             const float* resid = x1.p;
             if (r.has_sc) { gemm(raw, r.cin, r.sc, M, out, r.cout, EPI_F32); resid = out; }
             else RT_REQUIRE(!x2, "resnet without shortcut cannot take a concat input");
-            bool any_inject = false;
-            if (inject_here) for (int b = 0; b < B; ++b) any_inject |= in.res_src[b] >= 0;
             if (!any_inject) {
                 conv3(h3, A_CONV3, r.c2, B, Hh, Ww, r.cout, out, EPI_F32, resid);
             } else {
-                // rich-text feature injection (resnet.py:639-643): out[b] = shortcut(x[b]) + hidden[res_src[b]]
-                float* hres = ws.f32((size_t)M * r.cout);
-                conv3(h3, A_CONV3, r.c2, B, Hh, Ww, r.cout, hres, EPI_F32, nullptr);
+                float* hres = ws.f32((size_t)Mk * r.cout);
+                conv3(h3, A_CONV3, r.c2, Bk, Hh, Ww, r.cout, hres, EPI_F32, nullptr);
                 int src[RT_MAXB];
                 for (int b = 0; b < B; ++b) src[b] = in.res_src[b] >= 0 ? in.res_src[b] : b;
                 if (!dry()) launch_inject_add(out, resid, hres, src, B, (size_t)HW * r.cout, stream);
@@ -727,7 +737,7 @@ struct rt_engine {
     }
 
     // ---------------------------------------------------------------------------- step drivers
-    void region_step(int i, float g, float inject_selfattn, float inject_background, bool xl, bool elide, bool defer_blend);
+    void region_step(int i, float g, double inject_selfattn, double inject_background, bool xl, bool elide, bool defer_blend);
     bool pending_blend = false;
     void plain_step(int i, float g);
 };
@@ -894,7 +904,7 @@ int rt_get_latents(rt_engine* e, float* out, float* out_ref) {
 int rt_get_state_ptrs(rt_engine* e, float** latents, float** noise_pred) {
     RT_TRY(e, { need_device(e); HIP_CHECK(hipStreamSynchronize(e->stream)); *latents = e->lat; *noise_pred = e->noise_pred; })
 }
-int rt_region_step(rt_engine* e, int i, float g, float isa, float ibg, int xl, int elide) {
+int rt_region_step(rt_engine* e, int i, float g, double isa, double ibg, int xl, int elide) {
     RT_TRY(e, { need_device(e); e->region_step(i, g, isa, ibg, xl != 0, (elide & 1) != 0, (elide & 2) != 0); })
 }
 int rt_background_blend(rt_engine* e) {

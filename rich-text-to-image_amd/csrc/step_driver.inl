@@ -32,7 +32,7 @@ static void pndm_coeffs(rt_engine* e, int i, StepArgs& a) {
     e->pndm_counter++;
 }
 
-void rt_engine::region_step(int i, float g, float isa, float ibg, bool xl, bool elide, bool defer_blend) {
+void rt_engine::region_step(int i, float g, double isa, double ibg, bool xl, bool elide, bool defer_blend) {
     require_bound();
     const int n = (int)timesteps.size(), R = n_regions;
     RT_REQUIRE(i >= 0 && i < n, "region_step: step index out of range");
@@ -41,13 +41,14 @@ void rt_engine::region_step(int i, float g, float isa, float ibg, bool xl, bool 
     RT_REQUIRE((sched_kind == RT_SCHED_EULER) == xl, "region_step: SD uses PNDM, SDXL uses Euler");
     const float t = timesteps[i];
     const bool use_ref = isa > 0 || ibg > 0;
-    const double thr = (1.0 - (double)isa) * 1000.0;
-    auto feat_at = [&](int j) { return (double)timesteps[j] > thr; };
+    // `t > (1-inject_selfattn)*1000`: torch compares a float32 / int64 tensor element with a Python float in float32
+    const float thr = (float)((1.0 - isa) * 1000.0);
+    auto feat_at = [&](int j) { return timesteps[j] > thr; };
     const bool feat = feat_at(i);
-    const int bg_index = (int)((double)ibg * n);
+    const int bg_index = (int)(ibg * (double)n);                   // int(inject_background * len(timesteps)) on Python floats
     const bool blend = (i == bg_index) && ibg > 0;
     bool step_ref = use_ref;
-    if (xl) step_ref = isa > 0 || ((double)i < (double)ibg * n);
+    if (xl) step_ref = isa > 0 || ((double)i < ibg * (double)n);
     bool run_ref = use_ref;
     if (use_ref && elide) {
         // the reference pair can only influence the output through injection at this step, or through

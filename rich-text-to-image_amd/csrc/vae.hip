@@ -427,6 +427,8 @@ int rt_vae_bind_weight(rt_vae* v, const char* name, const void* ptr, int dtype, 
     })
 }
 int rt_vae_synchronize(rt_vae* v) { VAE_TRY(v, { vae_need_device(v); HIP_CHECK(hipStreamSynchronize(v->stream)); }) }
+int rt_vae_arena_info(rt_vae* v, void** p, uint64_t* bytes) { VAE_TRY(v, { vae_need_device(v); *p = v->arena_base; *bytes = v->arena_bytes; }) }
+int rt_vae_arena_mark_bound(rt_vae* v) { for (auto& s : v->slots) s.bound = true; return RT_OK; }
 
 int rt_vae_decode(rt_vae* v, const float* latents, int h, int w, int divide_by_scaling, float* img_out) {
     VAE_TRY(v, {

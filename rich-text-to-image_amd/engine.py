@@ -69,7 +69,7 @@ _SYMBOLS = [
     "rt_profile_read", "rt_op_gemm_force_config", "rt_op_gemm_debug", "rt_attn_store_enable", "rt_attn_store_reset",
     "rt_attn_store_read", "rt_attn_module_count", "rt_attn_module_info", "rt_get_state_ptrs", "rt_background_blend", "rt_vae_create", "rt_vae_destroy",
     "rt_vae_last_error", "rt_vae_weight_count", "rt_vae_weight_info", "rt_vae_bind_weight", "rt_vae_synchronize", "rt_vae_decode",
-    "rt_vae_color_guidance", "rt_op_cast_bf16", "rt_op_attention_probs_avg", "rt_op_embed", "rt_op_activation", "rt_op_causal_attention",
+    "rt_vae_color_guidance", "rt_vae_arena_info", "rt_vae_arena_mark_bound", "rt_op_cast_bf16", "rt_op_attention_probs_avg", "rt_op_embed", "rt_op_activation", "rt_op_causal_attention",
 ]
 
 
@@ -332,8 +332,8 @@ class Engine:
 
     # ---- hot path
     def region_step(self, i, guidance_scale, inject_selfattn=0.0, inject_background=0.0, xl=True, elide=False, defer_blend=False):
-        self._chk(self.lib.rt_region_step(self.h, i, C.c_float(guidance_scale), C.c_float(inject_selfattn),
-                                          C.c_float(inject_background), int(xl), int(bool(elide)) | (2 if defer_blend else 0)))
+        self._chk(self.lib.rt_region_step(self.h, i, C.c_float(guidance_scale), C.c_double(inject_selfattn),
+                                          C.c_double(inject_background), int(xl), int(bool(elide)) | (2 if defer_blend else 0)))
 
     def background_blend(self):
         self._chk(self.lib.rt_background_blend(self.h))
@@ -425,6 +425,17 @@ class VaeDecoder:
             self._chk(self.lib.rt_vae_bind_weight(self.h, name.encode(), _ptr(t), dt, shape, t.dim()))
         self._chk(self.lib.rt_vae_synchronize(self.h))
 
+    def arena(self):
+        p, b = C.c_void_p(), C.c_uint64()
+        self._chk(self.lib.rt_vae_arena_info(self.h, C.byref(p), C.byref(b)))
+        return p.value, b.value
+
+    def arena_mark_bound(self):
+        self._chk(self.lib.rt_vae_arena_mark_bound(self.h))
+
+    def synchronize(self):
+        self._chk(self.lib.rt_vae_synchronize(self.h))
+
     def decode(self, z, divide_by_scaling=False):
         """z [1,4,h,w] -> image [1,3,8h,8w] in [-1,1]"""
         import torch
@@ -440,10 +451,17 @@ class VaeDecoder:
         import torch
         # the masks / targets are the same objects on every step of a loop (sample.py:87-88 builds them once): stage them on the
         # device once instead of per step (image-resolution masks from pageable host memory are a synchronous multi-MB copy)
-        key = (id(color_obj_atten), id(target_rgb), id(color_obj_atten_all), len(color_obj_atten))
+        # the reference pairs masks and targets with zip() (rd.py:158): sample.py hands over n_color + 1 masks (get_token_maps
+        # appends the background mask) but n_color targets, so the surplus mask is silently dropped.  Same here.
+        n = min(len(color_obj_atten), len(target_rgb))
+        if n == 0:
+            raise RtError(-1, "color_guidance: no (mask, target RGB) pair")
+        key = (id(color_obj_atten), id(target_rgb), id(color_obj_atten_all), n)
         if getattr(self, "_cg_key", None) != key:
-            masks = torch.cat([m[:, 0].reshape(1, -1) for m in color_obj_atten]).contiguous().float().to(f"cuda:{self.device}")
-            tgt = [float(v) for t in target_rgb for v in t.flatten().tolist()]
+            masks = torch.cat([m[:, 0].reshape(1, -1) for m in color_obj_atten[:n]]).contiguous().float().to(f"cuda:{self.device}")
+            tgt = [float(v) for t in target_rgb[:n] for v in t.flatten().tolist()]
+            if len(tgt) != 3 * n or masks.shape != (n, 64 * h * w):
+                raise RtError(-1, f"color_guidance: need {n} RGB triples and [{n}, {64 * h * w}] masks, got {len(tgt)} values / {tuple(masks.shape)}")
             mall = color_obj_atten_all.contiguous().float().to(f"cuda:{self.device}")
             self._cg_key, self._cg_val = key, (masks, (C.c_float * len(tgt))(*tgt), mall, (color_obj_atten, target_rgb, color_obj_atten_all))
         masks, tgt_arr, mall, _ = self._cg_val
@@ -452,6 +470,6 @@ class VaeDecoder:
         lp = latents_ptr_or_tensor if isinstance(latents_ptr_or_tensor, int) else latents_ptr_or_tensor.data_ptr()
         npp = noise_pred if isinstance(noise_pred, int) else noise_pred.data_ptr()
         self._chk(self.lib.rt_vae_color_guidance(self.h, C.c_void_p(lp), C.c_void_p(npp), C.c_float(float(alpha_t)), h, w, _ptr(masks),
-                                                 tgt_arr, len(color_obj_atten), C.c_float(float(weight)), _ptr(mall),
+                                                 tgt_arr, n, C.c_float(float(weight)), _ptr(mall),
                                                  _ptr(grad), C.byref(loss)))
         return loss.value, grad

@@ -40,15 +40,26 @@ class _DevicePointer:
 
 
 def arena_tensor(engine):
+    """Packed weight arena of an Engine or a VaeDecoder as a flat uint8 tensor (no copy)."""
     ptr, nbytes = engine.arena()
     return torch.as_tensor(_DevicePointer(ptr, nbytes), device=f"cuda:{engine.device}")
 
 
-def broadcast_tensor(t, src=0, chunk_bytes=1 << 30):
-    """Broadcast a flat byte tensor in <= 1 GiB pieces (xGMI is per-link bound; a few large messages are ideal)."""
+LAST_BROADCAST_CALLS = 0      # dist.broadcast calls issued by the last broadcast_weights / broadcast_pipeline (bench line)
+
+
+def broadcast_tensor(t, src=0, chunk_bytes=None):
+    """Broadcast a flat byte tensor.  Default: ONE collective - the bytes are viewed as int64 words when length and address
+    allow, so a 5 GB arena is a 0.64 G-element message (xGMI is per-link bound: one large message is ideal).  `chunk_bytes`
+    splits it into pieces instead (returns the number of collectives issued)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return 0
     flat = t.view(-1)
+    if chunk_bytes is None:
+        if flat.dtype == torch.uint8 and flat.numel() % 8 == 0 and flat.data_ptr() % 8 == 0:
+            flat = flat.view(torch.int64)
+        dist.broadcast(flat, src=src)
+        return 1
     n = 0
     for off in range(0, flat.numel(), chunk_bytes):
         dist.broadcast(flat[off:off + chunk_bytes], src=src)
@@ -56,19 +67,66 @@ def broadcast_tensor(t, src=0, chunk_bytes=1 << 30):
     return n
 
 
+def broadcast_tensors(tensors, src=0):
+    """ONE collective for a list of tensors of mixed dtypes (text-encoder weights): rank `src` packs their bytes into a staging
+    buffer, everyone receives it and the other ranks unpack in place.  Every rank passes same-shaped tensors."""
+    if not dist.is_initialized() or dist.get_world_size() == 1 or not tensors:
+        return 0
+    sizes = [t.numel() * t.element_size() for t in tensors]
+    offs, total = [], 0
+    for sz in sizes:
+        offs.append(total)
+        total += (sz + 15) & ~15
+    buf = torch.zeros(total, dtype=torch.uint8, device=tensors[0].device)
+    is_src = dist.get_rank() == src
+    if is_src:
+        for t, o, sz in zip(tensors, offs, sizes):
+            buf[o:o + sz].copy_(t.contiguous().view(-1).view(torch.uint8))
+    n = broadcast_tensor(buf, src)
+    if not is_src:
+        for t, o, sz in zip(tensors, offs, sizes):
+            t.view(-1).view(torch.uint8).copy_(buf[o:o + sz])
+    return n
+
+
 def broadcast_weights(engine, src=0):
-    """Rank `src` has bound (packed) all weights; every other rank receives the packed bf16 arena."""
+    """Rank `src` has bound (packed) all weights; every other rank receives the packed bf16 arena (one collective)."""
+    global LAST_BROADCAST_CALLS
+    LAST_BROADCAST_CALLS = 0
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return 0.0
     import time
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     engine.synchronize()
-    broadcast_tensor(arena_tensor(engine), src)
+    LAST_BROADCAST_CALLS = broadcast_tensor(arena_tensor(engine), src)
     torch.cuda.synchronize()
     if dist.get_rank() != src:
         engine.arena_mark_bound()
     return time.perf_counter() - t0
+
+
+def broadcast_pipeline(unet_engine, vae=None, text_encoders=(), src=0):
+    """Everything a rank needs to sample without touching the checkpoint files: the UNet arena, the VAE decoder arena and the
+    text-encoder weights (HipCLIPTextEncoder.parameter_tensors()), three collectives in total.  Ranks != src construct the same
+    objects from the configs alone (checkpoint.load_pipeline(..., weights=False))."""
+    global LAST_BROADCAST_CALLS
+    t = broadcast_weights(unet_engine, src)
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return t
+    import time
+    t0 = time.perf_counter()
+    n = 0
+    if vae is not None:
+        vae.synchronize()
+        n += broadcast_tensor(arena_tensor(vae), src)
+        if dist.get_rank() != src:
+            vae.arena_mark_bound()
+    tens = [p for enc in text_encoders for p in enc.parameter_tensors()]
+    n += broadcast_tensors(tens, src)
+    torch.cuda.synchronize()
+    LAST_BROADCAST_CALLS += n
+    return t + time.perf_counter() - t0
 
 
 def max_over_ranks(value, device="cpu"):

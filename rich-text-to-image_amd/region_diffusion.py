@@ -39,6 +39,27 @@ class RegionDiffusion:
             ue = self.text_encoder(ui.input_ids.to(self.device))[0]
         return torch.cat([ue, te])
 
+    # rd.py:72-84
+    def get_text_embeds_list(self, prompts):
+        if self.tokenizer is None or self.text_encoder is None:
+            raise RuntimeError("RegionDiffusion.get_text_embeds_list needs a CLIP tokenizer + text encoder (not available offline)")
+        out = []
+        for prompt in prompts:
+            ti = self.tokenizer([prompt], padding="max_length", max_length=self.tokenizer.model_max_length, truncation=True,
+                                return_tensors="pt")
+            with torch.no_grad():
+                out.append(self.text_encoder(ti.input_ids.to(self.device))[0])
+        return out
+
+    # rd.py:238-246 - the VAE *encoder* is not on the rich-text path (nothing in the reference calls encode_imgs; only the
+    # decoder is built here): callers that pass a VAE object with `.encode` still get the reference behaviour
+    def encode_imgs(self, imgs):
+        if not hasattr(self.vae, "encode"):
+            raise NotImplementedError("encode_imgs needs a VAE with an encoder (diffusers AutoencoderKL call surface); the engine's "
+                                      "VaeDecoder covers decode + colour guidance only - encode_imgs is unused by the rich-text flow")
+        imgs = 2 * imgs - 1
+        return self.vae.encode(imgs).latent_dist.sample() * 0.18215
+
     # rd.py:86-174
     def produce_latents(self, text_embeddings, height=512, width=512, num_inference_steps=50, guidance_scale=7.5,
                         latents=None, use_guidance=False, text_format_dict={}, inject_selfattn=0, inject_background=0,

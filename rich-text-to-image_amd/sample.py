@@ -106,8 +106,10 @@ def main(argv=None):
     p.add_argument('--load_path', type=str, required=True)
     a = p.parse_args(argv)
     from .checkpoint import load_pipeline
-    model = load_pipeline(a.load_path, 'SD' if a.model == 'SD' else 'SDXL')
     res = 512 if a.model == 'SD' else 1024
+    # the VAE plan (decode + colour guidance workspace) is sized for the requested image, like the UNet engine
+    model = load_pipeline(a.load_path, 'SD' if a.model == 'SD' else 'SDXL',
+                          latent_hw=((a.height or res) // 8, (a.width or res) // 8))
     param = {'text_input': json.loads(a.rich_text_json), 'height': a.height or res, 'width': a.width or res,
              'guidance_weight': a.guidance_weight, 'steps': a.sample_steps, 'noise_index': a.seed, 'negative_prompt': a.negative_prompt}
     plain, rich, t = generate(model, param, 'SD' if a.model == 'SD' else 'SDXL', a.run_dir, a.color_guidance_weight, a.inject_selfattn,

@@ -59,11 +59,20 @@ def test_load_pipeline_and_generate_from_disk(tmp_path):
     err = ((emb[1:].cpu() - ref).pow(2).sum() / ref.pow(2).sum()).sqrt().item()
     print("text embeddings vs transformers rel-L2", err)
     assert emb.shape == (2, 77, TINY_SD_CONFIG["cross_attention_dim"]) and err < 2e-2
+    lst = m.get_text_embeds_list(["a night sky above a barn", "a fence"])              # rd.py:72-84
+    assert len(lst) == 2 and lst[0].shape == (1, 77, TINY_SD_CONFIG["cross_attention_dim"]) and torch.equal(lst[0], emb[1:])
+    with pytest.raises(NotImplementedError):                                             # rd.py:238-246: decoder-only VAE engine
+        m.encode_imgs(torch.zeros(1, 3, 64, 64))
     js = {"ops": [{"insert": "a "}, {"attributes": {"font": "slabo"}, "insert": "night sky"}, {"insert": " above a "},
                   {"attributes": {"color": "#ff0000"}, "insert": "barn"}, {"insert": " and a fence\n"}]}
     param = {"text_input": js, "height": 512, "width": 512, "guidance_weight": 7.5, "steps": 12, "noise_index": 1, "negative_prompt": ""}
     lat = torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(0))
-    plain, rich, _ = generate(m, param, "SD", None, color_guidance_weight=0.5, inject_selfattn=0.3, num_segments=5, latents=lat.clone())
+    import warnings
+    with warnings.catch_warnings():
+        # a NaN image shows up as "invalid value encountered in cast" when it is quantised to uint8: the colour span hands
+        # n_color + 1 masks but n_color targets to the guidance step (the reference's zip drops the surplus mask)
+        warnings.simplefilter("error", RuntimeWarning)
+        plain, rich, _ = generate(m, param, "SD", None, color_guidance_weight=0.5, inject_selfattn=0.3, num_segments=5, latents=lat.clone())
     assert plain.shape == rich.shape == (1, 512, 512, 3) and rich.dtype == np.uint8 and len(m.masks) == 3
     assert np.isfinite(rich.astype(np.float32)).all() and (rich != plain).any()
 
@@ -129,3 +138,40 @@ def test_sample_cli_main_from_disk(tmp_path):
                                "--seed", "3", "--num_segments", "4", "--run_dir", str(tmp_path / "out"), "--inject_selfattn", "0.2"])
     assert plain.shape == rich.shape == (1, 512, 512, 3)
     assert os.path.exists(tmp_path / "out" / "seed3_plain.jpg") and os.path.exists(tmp_path / "out" / "seed3_rich.jpg")
+
+
+def test_lora_checkpoint_merged_at_load_matches_oracle_on_merged_weights(tmp_path):
+    """SURVEY 8f row f4 (sample.py:29-30 AnimeXL / README.md:21-22 LoRA checkpoints): a kohya-layout LoRA file merged by
+    `load_pipeline(lora_path=...)` must make the ENGINE compute what the oracle computes on explicitly merged weights, and must
+    differ from the un-adapted model."""
+    from safetensors.torch import save_file
+    from oracle.unet import OracleUNet
+    from rich_text_to_image_amd.checkpoint import load_pipeline
+    _write_dir(str(tmp_path))
+    sd = random_state_dict(TINY_SD_CONFIG, seed=1)                               # what _write_dir stored under unet/
+    g = torch.Generator().manual_seed(3)
+    lora, merged = {}, dict(sd)
+    targets = ["down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q", "down_blocks.1.attentions.1.transformer_blocks.0.attn2.to_k",
+               "mid_block.attentions.0.transformer_blocks.0.attn2.to_out.0", "up_blocks.1.attentions.1.transformer_blocks.0.ff.net.2",
+               "up_blocks.2.attentions.0.transformer_blocks.0.ff.net.0.proj", "down_blocks.1.attentions.0.proj_in"]
+    scale, rank, alpha = 0.8, 4, 2.0
+    for t in targets:
+        w = sd[t + ".weight"]
+        down = torch.randn(rank, w.shape[1], *w.shape[2:], generator=g) * 0.3
+        up = torch.randn(w.shape[0], rank, *w.shape[2:], generator=g) * 0.3
+        name = "lora_unet_" + t.replace(".", "_")
+        lora[name + ".lora_down.weight"], lora[name + ".lora_up.weight"], lora[name + ".alpha"] = down, up, torch.tensor(alpha)
+        merged[t + ".weight"] = w + scale * (alpha / rank) * (up.flatten(1) @ down.flatten(1)).reshape(w.shape)
+    path = os.path.join(str(tmp_path), "adapter.safetensors")
+    save_file({k: v.contiguous() for k, v in lora.items()}, path)
+    m = load_pipeline(str(tmp_path), "SD", device=0, latent_hw=(64, 64), lora_path=path, lora_scale=scale)
+    x = torch.randn(2, 4, 64, 64, generator=g)
+    ctx = torch.randn(2, 77, TINY_SD_CONFIG["cross_attention_dim"], generator=g)
+    got = m.unet(x.cuda(), 401.0, ctx.cuda())["sample"].cpu()
+    with torch.no_grad():
+        ref = OracleUNet(TINY_SD_CONFIG, merged).forward(x, 401.0, ctx)
+        base = OracleUNet(TINY_SD_CONFIG, sd).forward(x, 401.0, ctx)
+    rel = lambda a, b: ((a - b).pow(2).sum() / b.pow(2).sum()).sqrt().item()
+    print(f"LoRA-merged engine vs oracle on merged weights: rel-L2 {rel(got, ref):.3e}; adapter effect {rel(base, ref):.3e}")
+    assert rel(base, ref) > 5 * 1.5e-2            # the adapter changes the model by much more than the tolerance ...
+    assert rel(got, ref) < 1.5e-2                 # ... and the engine follows it

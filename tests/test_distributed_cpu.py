@@ -18,6 +18,12 @@ def _worker(rank, world, port, q):
     arena = torch.arange(10_000, dtype=torch.uint8) if rank == 0 else torch.zeros(10_000, dtype=torch.uint8)
     nchunks = launcher.broadcast_tensor(arena, src=0, chunk_bytes=4096)
     ok_bcast = bool(torch.equal(arena, torch.arange(10_000, dtype=torch.uint8))) and nchunks == 3
+    # default: ONE collective for the whole arena (int64 view), and one for a packed list of mixed-dtype tensors
+    arena2 = torch.arange(4096, dtype=torch.uint8) if rank == 0 else torch.zeros(4096, dtype=torch.uint8)
+    ok_bcast &= launcher.broadcast_tensor(arena2, src=0) == 1 and bool(torch.equal(arena2, torch.arange(4096, dtype=torch.uint8)))
+    want = [torch.arange(7, dtype=torch.float32), torch.arange(5, dtype=torch.bfloat16), torch.arange(3, dtype=torch.int32).reshape(3, 1)]
+    have = [w.clone() if rank == 0 else torch.zeros_like(w) for w in want]
+    ok_bcast &= launcher.broadcast_tensors(have, src=0) == 1 and all(torch.equal(a, b) for a, b in zip(have, want))
     mine = launcher.shard_round_robin(list(range(7)), rank, world)
     tmax = launcher.max_over_ranks(1.0 + rank)
     launcher.barrier()

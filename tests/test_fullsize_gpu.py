@@ -1,0 +1,216 @@
+"""GPU parity at the ARCHITECTURES BASELINE.json names (not the tiny trace configs): SDXL-base (config 3: latent 128x128,
+10-layer 1280-channel transformers, 20 heads x 64, N=4096 / 1024 self-attention, 1920/2560-channel concat resnets) and
+SD-v1.5 (configs 1/2: latent 64x64, 8 heads x 40/80/160, N=4096..64), random-init weights with the reference's
+state_dict names, against the CPU fp32 oracle (oracle/unet.py, oracle/region_loop.py, oracle/vae.py - pinned against
+the unmodified reference at the trace configs, tests/test_oracle_vs_reference.py).
+
+  * one batched rt_unet_forward with every stream mode word of a rich-text step
+      [uncond, base + font-size softmax, text_ref, region(qk_src / res_src -> text_ref)]
+    vs four oracle forwards (capture -> inject of the per-head attn1 probabilities and the resnet feature, exactly the
+    tensors the reference hooks move: models/region_diffusion_sdxl.py:1018-1106, models/unet_2d_condition.py:703-983)
+  * the rich-text loop itself (rt_region_step) at full size: config 3 (SDXL, R=4, inject_selfattn=0.5) and config 1
+    (SD-v1.5, R=2, PLMS) for a 2-step schedule (one injected + one non-injected iteration for SDXL; 3 PLMS iterations
+    for SD) vs oracle.region_loop
+  * the AutoencoderKL decoder at the real VAE width (128-256-512-512) on a 64x64 latent: decode and the colour-guidance
+    input gradient vs torch autograd through oracle/vae.py
+
+Tolerances (same scale as tests/test_engine_gpu.py): single forward rel-L2 <= 1.5e-2 per stream, loops <= 3e-2 on the
+final latents, VAE decode <= 2e-2, guidance gradient <= 5e-2.  Wall time on the GPU box is dominated by the CPU oracle
+(about 10 s per SDXL forward, 2.5 s per SD-v1.5 forward).
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle.region_loop import rich_loop_sd, rich_loop_xl  # noqa: E402
+from oracle.schedulers import OracleEuler, OraclePNDM  # noqa: E402
+from oracle.unet import INJECT_RESNET, SD15_CONFIG, SDXL_CONFIG, OracleUNet  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def rel_l2(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).pow(2).sum() / b.pow(2).sum()).sqrt().item()
+
+
+def _build(cfg, hw, seed, max_streams, max_prompts):
+    """Engine + oracle on the same random weights.  The weights are drawn on the GPU (seconds instead of a minute for
+    2.6 G parameters on the host) with the init family of oracle.unet.random_state_dict and copied to the host for the oracle."""
+    from rich_text_to_image_amd.engine import Engine
+    eng = Engine(cfg, hw, hw, device=0, max_streams=max_streams, max_prompts=max_prompts)
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    sd = {}
+    for name, shape in eng.weight_table():
+        if name.endswith(".weight") and len(shape) >= 2:
+            t = (torch.rand(shape, generator=g, device=DEV) * 2 - 1) / math.sqrt(math.prod(shape[1:]))
+        elif name.endswith(".weight"):
+            t = 1.0 + 0.1 * (torch.rand(shape, generator=g, device=DEV) * 2 - 1)
+        else:
+            t = 0.05 * (torch.rand(shape, generator=g, device=DEV) * 2 - 1)
+        eng.bind_weight(name, t)
+        sd[name] = t.cpu()
+        eng.synchronize()
+        del t
+    assert eng.weights_missing()[0] == 0
+    return eng, OracleUNet(cfg, sd)
+
+
+@pytest.fixture(scope="module")
+def sdxl():
+    eng, o = _build(SDXL_CONFIG, 128, 21, max_streams=8, max_prompts=8)
+    yield eng, o
+    eng.close()
+
+
+@pytest.fixture(scope="module")
+def sd15():
+    eng, o = _build(SD15_CONFIG, 64, 22, max_streams=8, max_prompts=8)
+    yield eng, o
+    eng.close()
+
+
+def _stream_mode_forward(eng, o, cfg, hw, xl, t):
+    g = torch.Generator().manual_seed(123)
+    P, D = 3, cfg["cross_attention_dim"]
+    emb = torch.randn(P, 77, D, generator=g)
+    pooled = torch.randn(P, 1280, generator=g) if xl else None
+    tid = torch.tensor([[hw * 8.0, hw * 8.0, 0, 0, hw * 8.0, hw * 8.0]]) if xl else None
+    lat, lat_ref = torch.randn(1, 4, hw, hw, generator=g), torch.randn(1, 4, hw, hw, generator=g)
+    wp, fs = torch.tensor([3, 5, 9]), torch.tensor([4.0, -2.0, 0.5])
+
+    def added(k):
+        return {"text_embeds": pooled[k:k + 1], "time_ids": tid} if xl else None
+    with torch.no_grad():
+        r0 = o.forward(lat, t, emb[:1], added(0))
+        r1 = o.forward(lat, t, emb[2:3], added(2), ctl={"fontsize": {"word_pos": wp, "font_size": fs}})
+        cap = {}
+        r2 = o.forward(lat_ref, t, emb[2:3], added(2), ctl={"capture": cap})
+        inj = {k: v for k, v in cap.items() if k.endswith("attn1") or k == INJECT_RESNET}
+        assert INJECT_RESNET in inj and sum(k.endswith("attn1") for k in inj) == (70 if xl else 16)
+        r3 = o.forward(lat, t, emb[1:2], added(1), ctl={"inject": inj})
+        del cap, inj
+    if xl:
+        eng.set_prompts(emb.to(DEV), pooled.to(DEV), tid)
+    else:
+        eng.set_prompts(emb.to(DEV))
+    eng.set_fontsize(wp, fs)
+    x = torch.cat([lat, lat, lat_ref, lat]).to(DEV)
+    out = eng.unet_forward(x, t, [0, 2, 2, 1], fontsize=[0, 1, 0, 0], qk_src=[0, 1, 2, 2], res_src=[-1, -1, -1, 2])
+    res = {}
+    for name, got, ref in (("uncond", out[0], r0[0]), ("base+fontsize", out[1], r1[0]), ("text_ref", out[2], r2[0]),
+                           ("region injected", out[3], r3[0])):
+        res[name] = rel_l2(got, ref)
+        print(f"{'SDXL' if xl else 'SD-v1.5'} full arch, stream {name}: rel-L2 {res[name]:.3e} (ref rms {ref.pow(2).mean().sqrt():.3f})")
+    plain = eng.unet_forward(x, t, [0, 2, 2, 1])          # the mode words must matter at this size too
+    assert rel_l2(plain[1], out[1]) > 1e-3 and rel_l2(plain[3], out[3]) > 1e-3
+    return res
+
+
+def test_sdxl_full_architecture_stream_modes_match_oracle(sdxl):
+    eng, o = sdxl
+    res = _stream_mode_forward(eng, o, SDXL_CONFIG, 128, True, 801.0)
+    for name, r in res.items():
+        assert r < 1.5e-2, (name, r)
+
+
+def test_sd15_full_architecture_stream_modes_match_oracle(sd15):
+    eng, o = sd15
+    res = _stream_mode_forward(eng, o, SD15_CONFIG, 64, False, 701.0)
+    for name, r in res.items():
+        assert r < 1.5e-2, (name, r)
+
+
+def _masks(R, hw, g):
+    m = torch.softmax(torch.randn(R, 1, hw // 4, hw // 4, generator=g) * 4, dim=0)
+    m = torch.nn.functional.interpolate(m, size=(hw, hw), mode="bilinear", align_corners=False)
+    return (m / (m.sum(0, keepdim=True) + 1e-8)).repeat(1, 4, 1, 1)
+
+
+def test_sdxl_config3_rich_loop_matches_oracle(sdxl):
+    """BASELINE config 3 (the benched workload) for a 2-step Euler schedule: t = 501 (injected: 7 streams with
+    qk_src/res_src -> text_ref) then t = 1 (not injected)."""
+    eng, o = sdxl
+    hw, R, steps, gs, isa = 128, 4, 2, 5.0, 0.5
+    g = torch.Generator().manual_seed(7)
+    emb = torch.randn(R + 1, 77, 2048, generator=g)
+    pooled = torch.randn(R + 1, 1280, generator=g)
+    tid = torch.tensor([[1024.0, 1024.0, 0, 0, 1024.0, 1024.0]])
+    m = _masks(R, hw, g)
+    masks = [m[r:r + 1] for r in range(R)]
+    sched = OracleEuler(); sched.set_timesteps(steps)
+    assert [float(t) > 500 for t in sched.timesteps] == [True, False]
+    lat0 = torch.randn(1, 4, hw, hw, generator=g) * sched.init_noise_sigma
+    tfd = {"word_pos": torch.tensor([5, 6]), "font_size": torch.tensor([20.0, 20.0])}
+    eng.set_prompts(emb.to(DEV), pooled.to(DEV), tid)
+    eng.set_masks(m.to(DEV))
+    eng.set_fontsize(tfd["word_pos"], tfd["font_size"])
+    eng.set_schedule(0, sched.timesteps.tolist(), sched.sigmas.tolist(), steps)
+    eng.set_latents(lat0.to(DEV))
+    for i in range(steps):
+        eng.region_step(i, gs, isa, 0.0, xl=True, elide=False)
+    got = eng.read_latents(hw, hw).cpu()
+    ref = rich_loop_xl(o, OracleEuler(), emb, pooled, tid, masks, lat0, steps, gs, tfd, isa, 0.0)
+    r = rel_l2(got, ref)
+    print(f"SDXL config 3, 2 rich steps (R=4, inject_selfattn=0.5): final latents rel-L2 {r:.3e} (ref std {ref.std():.3f})")
+    assert r < 3e-2
+
+
+def test_sd15_config1_rich_loop_matches_oracle(sd15):
+    """BASELINE config 1 shape (SD-v1.5 512x512, 2 regions, PLMS) for a 2-step schedule = 3 PLMS iterations."""
+    eng, o = sd15
+    hw, R, steps, gs = 64, 2, 2, 7.5
+    g = torch.Generator().manual_seed(8)
+    emb = torch.randn(R + 1, 77, 768, generator=g)
+    m = _masks(R, hw, g)
+    masks = [m[r:r + 1] for r in range(R)]
+    sched = OraclePNDM(); sched.set_timesteps(steps)
+    lat0 = torch.randn(1, 4, hw, hw, generator=g)
+    tfd = {"word_pos": torch.tensor([2]), "font_size": torch.tensor([3.0])}
+    eng.set_prompts(emb.to(DEV))
+    eng.set_masks(m.to(DEV))
+    eng.set_fontsize(tfd["word_pos"], tfd["font_size"])
+    eng.set_schedule(1, sched.timesteps.tolist(), sched.alphas_cumprod.tolist(), steps)
+    eng.set_latents(lat0.to(DEV))
+    for i in range(len(sched.timesteps)):
+        eng.region_step(i, gs, 0.0, 0.0, xl=False, elide=False)
+    got = eng.read_latents(hw, hw).cpu()
+    ref = rich_loop_sd(o, OraclePNDM(), emb, masks, lat0, steps, gs, tfd, 0, 0)
+    r = rel_l2(got, ref)
+    print(f"SD-v1.5 config 1, {len(sched.timesteps)} PLMS iterations (R=2): final latents rel-L2 {r:.3e} (ref std {ref.std():.3f})")
+    assert r < 3e-2
+
+
+def test_full_width_vae_decode_and_guidance_gradient_match_oracle():
+    """AutoencoderKL decoder at the real width (128-256-512-512, 2+1 resnets per block) on the SD latent size."""
+    from oracle.vae import SD_VAE_CONFIG, OracleVAEDecoder, color_guidance_update, random_vae_state_dict
+    from rich_text_to_image_amd.engine import VaeDecoder
+    hw = 64
+    sd = random_vae_state_dict(SD_VAE_CONFIG, seed=5)
+    v = VaeDecoder(SD_VAE_CONFIG, hw, hw, device=0, state_dict=sd)
+    o = OracleVAEDecoder(SD_VAE_CONFIG, sd)
+    g = torch.Generator().manual_seed(2)
+    z = torch.randn(1, 4, hw, hw, generator=g) * 3
+    with torch.no_grad():
+        ref = o.decode(z)
+    out = v.decode(z.to(DEV))
+    r = rel_l2(out, ref)
+    print(f"full-width VAE decode 64x64 -> 512x512: rel-L2 {r:.3e} (ref rms {ref.pow(2).mean().sqrt():.3f})")
+    assert r < 2e-2
+    lat, eps = torch.randn(1, 4, hw, hw, generator=g), torch.randn(1, 4, hw, hw, generator=g)
+    # n_color + 1 masks for n_color targets, as sample.py hands them over (the reference's zip drops the last mask)
+    masks = [(torch.rand(1, 1, 8 * hw, 8 * hw, generator=g) ** 2).repeat(1, 4, 1, 1) for _ in range(3)]
+    rgb = [torch.rand(1, 3, 1, 1, generator=g) for _ in range(2)]
+    mall = torch.rand(1, 4, hw, hw, generator=g)
+    alpha, sc, wgt = 0.37, SD_VAE_CONFIG["scaling_factor"], 0.5
+    new_ref, grad_ref, loss_ref = color_guidance_update(o, lat, eps, alpha, sc, masks, rgb, wgt, mall)
+    lat_g = lat.clone().to(DEV)
+    loss, grad = v.color_guidance(lat_g, eps.to(DEV), alpha, hw, hw, masks, rgb, wgt, mall, want_grad=True)
+    rg, ru = rel_l2(grad, grad_ref), rel_l2(lat_g.cpu() - lat, new_ref - lat)
+    print(f"full-width colour guidance: loss {loss:.4f} vs {loss_ref:.4f}; grad rel-L2 {rg:.3e}; update rel-L2 {ru:.3e}")
+    assert abs(loss - loss_ref) < 2e-2 * abs(loss_ref)
+    assert rg < 5e-2 and ru < 5e-2
+    v.close()

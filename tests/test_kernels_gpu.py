@@ -414,5 +414,39 @@ def test_attn_processor_seam_matches_reference_module_golden():
     report("processor probs_avg", maps[0].detach().cpu(), g["p_self_avg"], atol=2e-3, rtol=5e-2)
     y, _ = proc(selfa, x2, real_attn_probs=maps[1])                                            # injection hook path (rd.py:366,382)
     report("processor self injected", y, g["y_inj"], atol=3e-2, rtol=3e-2)
+    # a REAL probability tensor (what attention_processor.py:522-524 accepts): the reference module's own per-head probabilities of
+    # `x`, recomputed in fp32 here, injected into the forward of `x2` must reproduce the same golden
+    sd = g["self_sd"]
+    q = F.linear(x.float().cpu(), sd["to_q.weight"]).reshape(2, 256, 2, -1).permute(0, 2, 1, 3).reshape(4, 256, -1)
+    k = F.linear(x.float().cpu(), sd["to_k.weight"]).reshape(2, 256, 2, -1).permute(0, 2, 1, 3).reshape(4, 256, -1)
+    probs = torch.softmax(q @ k.transpose(1, 2) * q.shape[-1] ** -0.5, -1).to(DEV)
+    y, maps_r = proc(selfa, x2, real_attn_probs=probs)
+    report("processor self injected (real probability tensor)", y, g["y_inj"], atol=3e-2, rtol=3e-2)
+    assert maps_r[1] is probs
+    report("processor probs_avg of a real tensor", maps_r[0].detach().cpu(), g["p_self_avg"], atol=2e-3, rtol=5e-2)
     with pytest.raises(TypeError):
-        proc(selfa, x2, real_attn_probs=torch.zeros(4, 256, 256, device=DEV))
+        proc(selfa, x2, real_attn_probs=torch.zeros(4, 128, 256, device=DEV))
+
+
+def test_attn_processor_probs_avg_at_4096_tokens():
+    """SDXL's first attention level has 64x64 = 4096 tokens and the XL token-map hook reads probs_avg of EVERY attn1 layer
+    (region_diffusion_sdxl.py:980-992): the averaged map must exist there too (keys are processed in 1024-key chunks)."""
+    from rich_text_to_image_amd.attention_processor import HipAttnProcessor
+    H, d, N, Cc = 2, 64, 4096, 128
+    g = torch.Generator().manual_seed(5)
+    sd = {"to_q.weight": torch.randn(H * d, Cc, generator=g) * Cc ** -0.5 * 2, "to_k.weight": torch.randn(H * d, Cc, generator=g) * Cc ** -0.5 * 2,
+          "to_v.weight": torch.randn(H * d, Cc, generator=g) * Cc ** -0.5, "to_out.0.weight": torch.randn(Cc, H * d, generator=g) * (H * d) ** -0.5,
+          "to_out.0.bias": torch.zeros(Cc)}
+    x = torch.randn(1, N, Cc, generator=g)
+    proc = HipAttnProcessor()
+    y, maps = proc(_StubAttention(sd, H), x.to(DEV))
+    assert maps[0] is not None and maps[0].shape == (1, N, N)
+    got = maps[0].detach().cpu()
+    xb = x.to(torch.bfloat16).float()
+    q = F.linear(xb, sd["to_q.weight"].to(torch.bfloat16).float()).reshape(1, N, H, d).permute(0, 2, 1, 3)
+    k = F.linear(xb, sd["to_k.weight"].to(torch.bfloat16).float()).reshape(1, N, H, d).permute(0, 2, 1, 3)
+    ref = torch.softmax(q @ k.transpose(-1, -2) * d ** -0.5, -1).mean(1)
+    assert torch.allclose(got.sum(-1), torch.ones(1, N), atol=2e-2)
+    rel = ((got - ref).pow(2).sum() / ref.pow(2).sum()).sqrt().item()
+    print(f"probs_avg 4096x4096: rel-L2 {rel:.3e}")
+    assert rel < 3e-2

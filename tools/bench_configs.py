@@ -44,6 +44,10 @@ def guidance_dict(hw, g, n_colors=2, weight=1.0):
             "color_obj_atten_all": torch.rand(1, 4, hw, hw, generator=g).clamp(0, 1)}
 
 
+STEPS_OVERRIDE = 0     # bench.py --config N --steps K
+WARM_STEPS = 3
+
+
 def timed(fn, warm):
     warm()
     torch.cuda.synchronize()
@@ -56,22 +60,22 @@ def timed(fn, warm):
 def config1():
     from rich_text_to_image_amd.region_diffusion import RegionDiffusion
     g = torch.Generator().manual_seed(0)
-    R, hw, steps = 2, 64, 20
+    R, hw, steps = 2, 64, STEPS_OVERRIDE or 20
     m = RegionDiffusion(0, unet_state_dict="random0", config=SD15_CONFIG)
     m.masks = masks_for(R, hw, g)
     emb = torch.randn(R + 1, 77, 768, generator=g)
     lat = torch.randn(1, 4, hw, hw, generator=g)
     run = lambda n: m.produce_latents(emb, num_inference_steps=n, guidance_scale=8.5, latents=lat.clone())
-    out, dt = timed(lambda: run(steps), lambda: run(3))
+    out, dt = timed(lambda: run(steps), lambda: run(WARM_STEPS))
     it = steps + 1
-    return dict(config=1, workload="SD-v1.5 RegionDiffusion 512^2, R=2, 20-step PLMS (21 iterations), CFG 8.5, 3 forwards/iteration",
+    return dict(config=1, workload=f"SD-v1.5 RegionDiffusion 512^2, R=2, {steps}-step PLMS ({steps + 1} iterations), CFG 8.5, 3 forwards/iteration",
                 iterations=it, seconds=dt, value=it / dt, unit="steps/s", tflop_per_iteration=3 * 0.8033, finite=bool(torch.isfinite(out).all()))
 
 
 def config2():
     from rich_text_to_image_amd.region_diffusion import RegionDiffusion
     g = torch.Generator().manual_seed(1)
-    R, hw, steps = 4, 64, globals().get("STEPS_OVERRIDE", 50)
+    R, hw, steps = 4, 64, STEPS_OVERRIDE or 50
     vae = random_vae(SD_VAE_CONFIG, hw, hw)
     m = RegionDiffusion(0, unet_state_dict="random0", config=SD15_CONFIG, vae=vae)
     m.masks = masks_for(R, hw, g)
@@ -79,16 +83,16 @@ def config2():
     lat = torch.randn(1, 4, hw, hw, generator=g)
     tfd = guidance_dict(hw, g, 2, 1.0)
     run = lambda n: m.produce_latents(emb, num_inference_steps=n, guidance_scale=7.5, latents=lat.clone(), text_format_dict=tfd, use_guidance=True)
-    out, dt = timed(lambda: run(steps), lambda: run(3))
+    out, dt = timed(lambda: run(steps), lambda: run(WARM_STEPS))
     it = steps + 1
-    return dict(config=2, workload="SD-v1.5 512^2, R=4, 50-step PLMS (51 iterations), colour guidance weight 1 on 2 regions (VAE decoder forward + input gradient every iteration)",
+    return dict(config=2, workload=f"SD-v1.5 512^2, R=4, {steps}-step PLMS ({steps + 1} iterations), colour guidance weight 1 on 2 regions (VAE decoder forward + input gradient every iteration)",
                 iterations=it, seconds=dt, value=it / dt, unit="steps/s", tflop_per_iteration=5 * 0.8033 + 5.0, finite=bool(torch.isfinite(out).all()))
 
 
 def config5():
     from rich_text_to_image_amd.region_diffusion_sdxl import RegionDiffusionXL
     g = torch.Generator().manual_seed(2)
-    R, hw, steps = 4, 128, globals().get("STEPS_OVERRIDE", 50)
+    R, hw, steps = 4, 128, STEPS_OVERRIDE or 50
     vae = random_vae(SDXL_VAE_CONFIG, hw, hw)
     m = RegionDiffusionXL(device=0, unet_state_dict="random0", config=SDXL_CONFIG, vae=vae, vae_scaling_factor=SDXL_VAE_CONFIG["scaling_factor"])
     m.masks = masks_for(R, hw, g)
@@ -99,8 +103,8 @@ def config5():
                              prompt_embeds=emb[1:], negative_prompt_embeds=emb[:1], pooled_prompt_embeds=pooled[1:],
                              negative_pooled_prompt_embeds=pooled[:1], output_type="latent", run_rich_text=True, text_format_dict=tfd,
                              use_guidance=True, inject_selfattn=0.0, inject_background=0.5).images
-    out, dt = timed(lambda: run(steps), lambda: run(3))
-    return dict(config=5, workload="SDXL 1024^2, R=4 (footnote+style+colour+base), 50-step Euler, CFG 7.5, colour guidance on 1 region, inject_background=0.5, 7 forwards/step",
+    out, dt = timed(lambda: run(steps), lambda: run(WARM_STEPS))
+    return dict(config=5, workload=f"SDXL 1024^2, R=4 (footnote+style+colour+base), {steps}-step Euler, CFG 7.5, colour guidance on 1 region, inject_background=0.5, 7 forwards/step",
                 iterations=steps, seconds=dt, value=steps / dt, unit="steps/s", tflop_per_iteration=7 * 6.7612 + 21.2, finite=bool(torch.isfinite(out).all()))
 
 
@@ -110,7 +114,7 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=0, help="override the step count (profiling runs)")
     a = ap.parse_args()
     if a.steps:
-        globals()["STEPS_OVERRIDE"] = a.steps
+        STEPS_OVERRIDE = a.steps
     for c in a.configs.split(","):
         r = {"1": config1, "2": config2, "5": config5}[c]()
         r["tflops"] = r["tflop_per_iteration"] * r["value"]
