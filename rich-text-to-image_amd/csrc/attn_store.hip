@@ -104,14 +104,14 @@ __global__ __launch_bounds__(64) void attn_store_kernel(AttnStoreArgs p) {
 }
 
 void launch_attn_store(const AttnStoreArgs& a, hipStream_t st) {
-    RT_REQUIRE(a.NKpad % 32 == 0 && a.NK >= 1 && a.NK <= a.NKpad && a.NKrows >= 1 && a.H >= 1 && a.H <= 64, "attn_store: keys are padded to a multiple of 32; at most 64 heads");
+    RT_REQUIRE(a.NKpad % 32 == 0 && a.NK >= 1 && a.NK <= a.NKpad && a.NKrows >= 1 && a.H >= 1 && a.H <= 32, "attn_store: keys are padded to a multiple of 32; at most 32 heads");
     const int chunk = a.NKpad < RT_STORE_CHUNK ? a.NKpad : RT_STORE_CHUNK;
     const size_t lds = (size_t)32 * (chunk + 1) * 4 + (size_t)a.H * 64 * 2 * 4;
     dim3 grid(cdiv(a.N, 32)), block(64);
 #define LAUNCH(D)                                                                                                   \
     {                                                                                                               \
         static bool attr = false;                                                                                   \
-        if (!attr) { HIP_CHECK(hipFuncSetAttribute((const void*)attn_store_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * (RT_STORE_CHUNK + 1) * 4 + 64 * 64 * 2 * 4)); attr = true; } \
+        if (!attr) { HIP_CHECK(hipFuncSetAttribute((const void*)attn_store_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * (RT_STORE_CHUNK + 1) * 4 + 32 * 64 * 2 * 4)); attr = true; } \
         hipLaunchKernelGGL(attn_store_kernel<D>, grid, block, lds, st, a);                                         \
     }
     switch (a.DP) {

@@ -8,9 +8,9 @@ the unmodified reference at the trace configs, tests/test_oracle_vs_reference.py
       [uncond, base + font-size softmax, text_ref, region(qk_src / res_src -> text_ref)]
     vs four oracle forwards (capture -> inject of the per-head attn1 probabilities and the resnet feature, exactly the
     tensors the reference hooks move: models/region_diffusion_sdxl.py:1018-1106, models/unet_2d_condition.py:703-983)
-  * the rich-text loop itself (rt_region_step) at full size: config 3 (SDXL, R=4, inject_selfattn=0.5) and config 1
-    (SD-v1.5, R=2, PLMS) for a 2-step schedule (one injected + one non-injected iteration for SDXL; 3 PLMS iterations
-    for SD) vs oracle.region_loop
+  * the rich-text loop itself (rt_region_step) at full size: config 3 (SDXL, R=4, inject_selfattn=0.5: the injected first
+    iteration, compared on the latent UPDATE of both latent streams) and config 1 (SD-v1.5, R=2, PLMS: a 2-step schedule =
+    3 PLMS iterations) vs oracle.region_loop
   * the AutoencoderKL decoder at the real VAE width (128-256-512-512) on a 64x64 latent: decode and the colour-guidance
     input gradient vs torch autograd through oracle/vae.py
 
@@ -19,6 +19,7 @@ final latents, VAE decode <= 2e-2, guidance gradient <= 5e-2.  Wall time on the 
 (about 10 s per SDXL forward, 2.5 s per SD-v1.5 forward).
 """
 import math
+import os
 
 import pytest
 import torch
@@ -30,6 +31,7 @@ from oracle.schedulers import OracleEuler, OraclePNDM  # noqa: E402
 from oracle.unet import INJECT_RESNET, SD15_CONFIG, SDXL_CONFIG, OracleUNet  # noqa: E402
 
 DEV = "cuda:0"
+torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))     # the fp32 oracle is the clock here; more threads oversubscribe the host
 
 
 def rel_l2(a, b):
@@ -130,9 +132,12 @@ def _masks(R, hw, g):
     return (m / (m.sum(0, keepdim=True) + 1e-8)).repeat(1, 4, 1, 1)
 
 
-def test_sdxl_config3_rich_loop_matches_oracle(sdxl):
-    """BASELINE config 3 (the benched workload) for a 2-step Euler schedule: t = 501 (injected: 7 streams with
-    qk_src/res_src -> text_ref) then t = 1 (not injected)."""
+def test_sdxl_config3_rich_step_matches_oracle(sdxl):
+    """BASELINE config 3 (the benched workload): the FIRST iteration of a 2-step Euler schedule (t = 501 > 500: injected - 7 streams,
+    the three region streams with qk_src / res_src -> text_ref), both latent streams after the scheduler step.  The non-injected
+    iteration of the loop is covered at full size by the SD-v1.5 loop below and, for SDXL, by the stream-mode forward above; the
+    oracle costs ~0.5 min per SDXL forward on the GPU box's host, which is what bounds this file."""
+    from oracle.region_loop import rich_step_forwards
     eng, o = sdxl
     hw, R, steps, gs, isa = 128, 4, 2, 5.0, 0.5
     g = torch.Generator().manual_seed(7)
@@ -150,13 +155,21 @@ def test_sdxl_config3_rich_loop_matches_oracle(sdxl):
     eng.set_fontsize(tfd["word_pos"], tfd["font_size"])
     eng.set_schedule(0, sched.timesteps.tolist(), sched.sigmas.tolist(), steps)
     eng.set_latents(lat0.to(DEV))
-    for i in range(steps):
-        eng.region_step(i, gs, isa, 0.0, xl=True, elide=False)
-    got = eng.read_latents(hw, hw).cpu()
-    ref = rich_loop_xl(o, OracleEuler(), emb, pooled, tid, masks, lat0, steps, gs, tfd, isa, 0.0)
-    r = rel_l2(got, ref)
-    print(f"SDXL config 3, 2 rich steps (R=4, inject_selfattn=0.5): final latents rel-L2 {r:.3e} (ref std {ref.std():.3f})")
-    assert r < 3e-2
+    eng.region_step(0, gs, isa, 0.0, xl=True, elide=False)
+    got, got_ref = (t.cpu() for t in eng.read_latents(hw, hw, with_ref=True))
+
+    # the same iteration on the oracle, written out like xl.py:779-846 (oracle.region_loop.rich_loop_xl's loop body)
+    def added_fn(k):
+        k = k if k >= 0 else pooled.shape[0] + k
+        return {"text_embeds": pooled[k:k + 1], "time_ids": tid}
+    t = sched.timesteps[0]
+    lat_in = sched.scale_model_input(lat0, t)
+    eu, et, eur, etr = rich_step_forwards(o, lat_in, lat_in.clone(), t, emb, added_fn, masks, tfd, True, True)
+    out = sched.step(torch.cat([eu + gs * (et - eu), eur + gs * (etr - eur)]), t, torch.cat([lat0, lat0]))["prev_sample"]
+    ref, ref_ref = torch.chunk(out, 2, dim=0)
+    r, rr = rel_l2(got - lat0, ref - lat0), rel_l2(got_ref - lat0, ref_ref - lat0)
+    print(f"SDXL config 3, injected rich step (R=4, inject_selfattn=0.5): latent UPDATE rel-L2 {r:.3e} (reference stream {rr:.3e})")
+    assert r < 3e-2 and rr < 3e-2
 
 
 def test_sd15_config1_rich_loop_matches_oracle(sd15):
