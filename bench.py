@@ -77,11 +77,11 @@ def cpu_baseline(sd_cpu, threads, x, ctx, pooled, tid, t):
     a, b = torch.randn(4096, 1280), torch.randn(1280, 10240)
     best = (1e9, threads)
     cand = sorted({t for t in (16, 32, 64, 96, 128, threads) if t <= threads})
-    for t in cand:
-        torch.set_num_threads(t)
+    for nt in cand:
+        torch.set_num_threads(nt)
         a @ b
         t0 = time.perf_counter(); a @ b; a @ b
-        best = min(best, (time.perf_counter() - t0, t))
+        best = min(best, (time.perf_counter() - t0, nt))
     threads = best[1]
     torch.set_num_threads(threads)
     o = OracleUNet(SDXL_CONFIG, sd_cpu)

@@ -132,17 +132,6 @@ int rt_unet_forward(rt_engine* e, const float* x, int B, int h, int w, float tim
 int rt_op_gemm(const void* A, const void* W, const float* bias, void* out, const float* res, const float* temb,
                int mode, int epi, int M, int N, int K, int lda, int ldw, int ldo, int ldres, int temb_ld,
                int rows_per_batch, int Hin, int Win, int Cin, int Hout, int Wout, void* stream);
-/* LayerNorm folded into the projections around it (models/attention.py:84,103,119 nn.LayerNorm + the nn.Linear that follows):
- *   LN(x) W^T + b = rstd * ((x*gamma) W^T - mean * s) + c,   s[n] = sum_k gamma_k W[n,k],  c[n] = sum_k beta_k W[n,k] + b[n]  (rt_op_ln_fold)
- * producer (epi = 1, fp32 out (+res)): aux_out [M, ld_aux] <- bf16(out * aux_gamma) and stat_out [M, N/32, 2] <- (sum, sumsq) per row and
- *   32-column group (N % 32 == 0); either may be NULL.
- * consumer: ln_mode 1 = the statistics ln_stat [rows of A, ln_ng, 2] belong to the rows of A (ln_s / ln_c indexed by output column),
- *   ln_mode 2 = to the rows of W (output columns; ln_s / ln_c indexed by output row; bf16 epilogue only); bias must be NULL. */
-int rt_op_gemm_ln(const void* A, const void* W, const float* bias, void* out, const float* res, int epi, int M, int N, int K, int lda, int ldw,
-                  int ldo, int ldres, void* aux_out_bf16, const float* aux_gamma, int ld_aux, float* stat_out, int ln_mode,
-                  const float* ln_stat, int ln_ng, int ln_C, float ln_eps, const float* ln_s, const float* ln_c, void* stream);
-int rt_op_ln_fold(const void* W_bf16, int ldw, const float* gamma, const float* beta, const float* bias, float* s, float* c, int N, int K,
-                  void* stream);
 int rt_op_attention(const void* Q, int ldq, const void* K, int ldk, const void* VT, int ldvt, void* O, int ldo,
                     const int* q_src_host, const int* k_src_host, const int* v_src_host, const int* wset_host,
                     const float* wabs, const float* wsgn, int B, int H, int N, int NK, int nk_valid, int DP, int cross,

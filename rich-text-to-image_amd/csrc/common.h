@@ -74,24 +74,7 @@ struct GemmArgs {
     int rows_per_batch;              // Hout*Wout (conv and temb)
     int Hin, Win, Cin, Hout, Wout;   // conv geometry (Cin padded to a multiple of 8; K = 9*Cin)
     int debug;                       // unused by the product kernels (kept so probe builds can pass flags without changing the ABI of the struct)
-    // ---- LayerNorm fusion: LN(x) W^T = rstd * ( (x*gamma) W^T - mean * s ) + c,  s[n] = sum_k gamma_k W[n,k],
-    //      c[n] = sum_k beta_k W[n,k] + bias[n].  The GEMM that PRODUCES the fp32 trunk x also emits the bf16 operand x*gamma and
-    //      per-row partial (sum, sumsq) of every 32-column group; the GEMMs that CONSUME LN(x) run on that operand and apply the
-    //      affine correction in their epilogue, so no LayerNorm kernel (read 4 B + write 2 B per element) runs in between.
-    // producer (EPI_F32 only):
-    bf16_t* aux_out;                 // [M, ld_aux] <- bf16(out * aux_gamma[col])   (aux_gamma null: plain bf16 copy); null = off
-    const float* aux_gamma;          // [N]
-    int ld_aux;
-    float* stat_out;                 // [M, N/32, 2] <- (sum, sumsq) of out over each 32-column group (N % 32 == 0); null = off
-    // consumer:
-    int ln_mode;                     // 0 off; 1: statistics belong to the rows of A (output rows); 2: to the rows of W (output columns)
-    const float* ln_stat;            // [rows, ln_ng, 2] partials written by the producer
-    int ln_ng, ln_C;                 // 32-column groups per row, channels the statistics run over
-    float ln_eps;
-    const float* ln_s;               // mode 1: [N] (per output column); mode 2: [M] (per output row)
-    const float* ln_c;               // same indexing; includes the projection bias (GemmArgs.bias must be null)
 };
-#define RT_LN_LDS_BYTES 2048         // (mean, rstd) of the 256 rows / columns of a tile, placed behind the operand ring
 void launch_gemm(const GemmArgs& a, hipStream_t st);
 void gemm_force_config(int cfg);
 void gemm_set_debug(int d);   // -1 auto-tune, 0..3 fixed tile configuration
@@ -143,8 +126,6 @@ int groupnorm_nchunk(int HW);
 
 void launch_layernorm(const float* x, const float* gamma, const float* beta, bf16_t* out, int rows, int C,
                       float eps, hipStream_t st);
-void launch_ln_fold(const bf16_t* W, int ldw, const float* gamma, const float* beta, const float* bias, float* s, float* c, int N, int K,
-                    hipStream_t st);
 void launch_cast_f32_bf16(const float* x, bf16_t* out, size_t n, hipStream_t st);
 // out[b][n] (+)= sum_k act(a[b][k]) * W[n][k] + bias[n];  B <= 8
 void launch_small_linear(const float* a, int lda, const bf16_t* W, int ldw, const float* bias, float* out, int ldo,

@@ -74,8 +74,6 @@ struct ResnetP {
 struct TBlockP {
     NormW ln1, ln2, ln3;
     MatW qk1, v1, out1, q2, k2, v2, out2, ff1, ff2;
-    // LayerNorm fusion (GemmArgs in common.h): s / c of (norm1 | [to_q;to_k]), (norm1 | to_v), (norm2 | attn2.to_q), (norm3 | ff.net.0.proj)
-    float *s_qk = nullptr, *c_qk = nullptr, *s_v = nullptr, *c_v = nullptr, *s_q2 = nullptr, *c_q2 = nullptr, *s_ff = nullptr, *c_ff = nullptr;
     bf16_t* kcache = nullptr;    // [maxP*96, H*DP]
     bf16_t* vtcache = nullptr;   // [H*DP, maxP*96]
     // token-map attention store: index 0 = attn1, 1 = attn2
@@ -303,10 +301,6 @@ struct rt_engine {
             { PackArgs p = pk_matrix(k.ff1.w, 8 * C, C, C, C); p.row_map = PACK_ROWS_GEGLU; add_slot(b + ".ff.net.0.proj.weight", {8 * C, C}, p); }
             { PackArgs p = pk_vec(k.ff1.b, 8 * C); p.row_map = PACK_ROWS_GEGLU; add_slot(b + ".ff.net.0.proj.bias", {8 * C}, p); }
             k.ff2 = mk_linear(b + ".ff.net.2", 4 * C, C, true);
-            k.s_qk = (float*)sarena.alloc((size_t)2 * HD * 4); k.c_qk = (float*)sarena.alloc((size_t)2 * HD * 4);
-            k.s_v = (float*)sarena.alloc((size_t)HD * 4); k.c_v = (float*)sarena.alloc((size_t)HD * 4);
-            k.s_q2 = (float*)sarena.alloc((size_t)HD * 4); k.c_q2 = (float*)sarena.alloc((size_t)HD * 4);
-            k.s_ff = (float*)sarena.alloc((size_t)8 * C * 4); k.c_ff = (float*)sarena.alloc((size_t)8 * C * 4);
             k.kcache = (bf16_t*)sarena.alloc((size_t)cfg.max_prompts * 96 * HD * 2);
             k.vtcache = (bf16_t*)sarena.alloc((size_t)cfg.max_prompts * 96 * HD * 2);
             t.blocks.push_back(k);
@@ -374,43 +368,24 @@ struct rt_engine {
 
     // ---------------------------------------------------------------------------- launch helpers
     bool dry() const { return ws.dry; }
-    // LayerNorm fusion plumbing (GemmArgs in common.h).  LnOut: what an fp32-trunk producer emits for the LayerNorm that follows;
-    // LnIn: what a consumer of that LayerNorm needs.
-    struct LnOut { bf16_t* aux = nullptr; const float* gamma = nullptr; float* stat = nullptr; };
-    struct LnIn { const float* stat = nullptr; const float* s = nullptr; const float* c = nullptr; int C = 0; };
     void gemm(const bf16_t* A, int lda, const MatW& W, int M, void* out, int ldo, int epi, const float* res = nullptr,
-              int ldres = 0, const float* temb = nullptr, int rows_per_batch = 0, const LnOut* lo = nullptr, const LnIn* li = nullptr) {
+              int ldres = 0, const float* temb = nullptr, int rows_per_batch = 0) {
         if (dry()) return;
         GemmArgs g{}; g.A = A; g.W = W.w; g.bias = W.b; g.out = out; g.res = res; g.temb = temb; g.zero = zero;
         g.mode = A_DENSE; g.epi = epi; g.M = M; g.N = W.N; g.K = W.K; g.lda = lda; g.ldw = W.K; g.ldo = ldo;
         g.ldres = ldres; g.temb_ld = W.N; g.rows_per_batch = rows_per_batch;
-        if (lo) { g.aux_out = lo->aux; g.aux_gamma = lo->gamma; g.ld_aux = W.N; g.stat_out = lo->stat; }
-        if (li) { g.ln_mode = 1; g.ln_stat = li->stat; g.ln_ng = li->C / 32; g.ln_C = li->C; g.ln_eps = 1e-5f; g.ln_s = li->s; g.ln_c = li->c; g.bias = nullptr; }
         prof_begin(RT_PROF_GEMM_DENSE, 2.0 * M * W.N * W.K);
         launch_gemm(g, stream);
         prof_end();
     }
     // V^T = Wv [HD, K] x X[M, K]^T -> [HD, M]
-    void gemm_vt(const MatW& Wv, const bf16_t* X, int ldx, int M, bf16_t* out, int ldo, const LnIn* li = nullptr) {
+    void gemm_vt(const MatW& Wv, const bf16_t* X, int ldx, int M, bf16_t* out, int ldo) {
         if (dry()) return;
         GemmArgs g{}; g.A = Wv.w; g.W = X; g.bias = nullptr; g.out = out; g.zero = zero;
         g.mode = A_DENSE; g.epi = EPI_BF16; g.M = Wv.N; g.N = M; g.K = Wv.K; g.lda = Wv.K; g.ldw = ldx; g.ldo = ldo;
-        if (li) { g.ln_mode = 2; g.ln_stat = li->stat; g.ln_ng = li->C / 32; g.ln_C = li->C; g.ln_eps = 1e-5f; g.ln_s = li->s; g.ln_c = li->c; }
         prof_begin(RT_PROF_GEMM_DENSE, 2.0 * M * Wv.N * Wv.K);
         launch_gemm(g, stream);
         prof_end();
-    }
-    // one-time fold of every BasicTransformerBlock's LayerNorm affine parameters against the packed projection it feeds
-    bool ln_folded = false;
-    void fold_layernorms() {
-        if (ln_folded) return;
-        for_each_tblock([&](TransformerP& t, TBlockP& k) {
-            launch_ln_fold(k.qk1.w, k.qk1.K, k.ln1.g, k.ln1.b, nullptr, k.s_qk, k.c_qk, k.qk1.N, k.qk1.K, stream);
-            launch_ln_fold(k.v1.w, k.v1.K, k.ln1.g, k.ln1.b, nullptr, k.s_v, k.c_v, k.v1.N, k.v1.K, stream);
-            launch_ln_fold(k.q2.w, k.q2.K, k.ln2.g, k.ln2.b, nullptr, k.s_q2, k.c_q2, k.q2.N, k.q2.K, stream);
-            launch_ln_fold(k.ff1.w, k.ff1.K, k.ln3.g, k.ln3.b, k.ff1.b, k.s_ff, k.c_ff, k.ff1.N, k.ff1.K, stream);
-        });
-        ln_folded = true;
     }
     void conv3(const bf16_t* in, int mode, const MatW& W, int B, int Hin, int Win, int CinP, void* out, int epi,
                const float* res = nullptr, const float* temb = nullptr) {
@@ -500,26 +475,17 @@ struct rt_engine {
         {
             Scope sc(ws);
             float* hcur = ws.f32((size_t)M * C);
-            // LayerNorm fusion (common.h): every GEMM that writes the fp32 trunk also writes `n` = bf16(trunk * gamma of the NEXT
-            // LayerNorm) and the per-row partial statistics; the projections that follow correct for mean / rstd in their epilogue.
-            // Needs C % 32 == 0 (true for every SD / SDXL level); otherwise the stand-alone LayerNorm kernel runs.
-            const bool fuse = C % 32 == 0;
-            bf16_t* n = ws.b16((size_t)M * C);
-            float* stat = ws.f32((size_t)M * (C / 32 + 1) * 2);
-            bf16_t* hb = ws.b16((size_t)M * C);
-            const size_t nb = t.blocks.size();
             {
                 Scope s2(ws);
                 bf16_t* g = ws.b16((size_t)M * C);
                 groupnorm(x.p, nullptr, false, C, 0, B, HW, t.gn, 1e-6f, false, g, nullptr);
-                LnOut lo; lo.aux = nb ? n : hb; lo.gamma = nb ? t.blocks[0].ln1.g : nullptr; lo.stat = nb ? stat : nullptr;
-                gemm(g, C, t.pin, M, hcur, C, EPI_F32, nullptr, 0, nullptr, 0, fuse ? &lo : nullptr);
+                gemm(g, C, t.pin, M, hcur, C, EPI_F32);
             }
-            for (size_t bi = 0; bi < nb; ++bi) {
-                TBlockP& k = t.blocks[bi];
+            for (TBlockP& k : t.blocks) {
                 Scope s2(ws);
+                bf16_t* n = ws.b16((size_t)M * C);
                 // --- attn1 (self; attention_processor.py:476-545)
-                if (!fuse) layernorm(hcur, k.ln1, n, M);
+                layernorm(hcur, k.ln1, n, M);
                 bf16_t* qk = ws.b16((size_t)M * 2 * HD);
                 bf16_t* vt = ws.b16((size_t)HD * M);
                 bf16_t* o = ws.b16((size_t)M * HD);
@@ -527,9 +493,8 @@ struct rt_engine {
                 // text_ref stream's Q,K: attention_processor.py:522-524 discards their own scores)
                 int nqk = 0;
                 for (int b = 0; b < B; ++b) nqk = std::max(nqk, in.qk_src[b] + 1);
-                LnIn li_qk{stat, k.s_qk, k.c_qk, C}, li_v{stat, k.s_v, k.c_v, C}, li_q2{stat, k.s_q2, k.c_q2, C}, li_ff{stat, k.s_ff, k.c_ff, C};
-                gemm(n, C, k.qk1, nqk * HW, qk, 2 * HD, EPI_BF16, nullptr, 0, nullptr, 0, nullptr, fuse ? &li_qk : nullptr);
-                gemm_vt(k.v1, n, C, M, vt, M, fuse ? &li_v : nullptr);
+                gemm(n, C, k.qk1, nqk * HW, qk, 2 * HD, EPI_BF16);
+                gemm_vt(k.v1, n, C, M, vt, M);
                 if (!dry()) {
                     AttnArgs a{}; a.Q = qk; a.ldq = 2 * HD; a.K = qk + HD; a.ldk = 2 * HD; a.VT = vt; a.ldvt = M; a.O = o; a.ldo = HD;
                     for (int b = 0; b < B; ++b) { a.q_src[b] = in.qk_src[b]; a.k_src[b] = in.qk_src[b]; a.v_src[b] = b; a.wset[b] = 0; }
@@ -547,11 +512,10 @@ struct rt_engine {
                         k.store_rows[0] = HW; k.store_cols[0] = HW;
                     }
                 }
-                LnOut lo2{n, k.ln2.g, stat}, lo3{n, k.ln3.g, stat};
-                gemm(o, HD, k.out1, M, hcur, C, EPI_F32, hcur, C, nullptr, 0, fuse ? &lo2 : nullptr);
+                gemm(o, HD, k.out1, M, hcur, C, EPI_F32, hcur, C);
                 // --- attn2 (cross, K/V from the per-prompt cache; font-size softmax on flagged streams)
-                if (!fuse) layernorm(hcur, k.ln2, n, M);
-                gemm(n, C, k.q2, M, qk, HD, EPI_BF16, nullptr, 0, nullptr, 0, nullptr, fuse ? &li_q2 : nullptr);
+                layernorm(hcur, k.ln2, n, M);
+                gemm(n, C, k.q2, M, qk, HD, EPI_BF16);
                 if (!dry()) {
                     AttnArgs a{}; a.Q = qk; a.ldq = HD; a.K = k.kcache; a.ldk = HD; a.VT = k.vtcache; a.ldvt = cfg.max_prompts * 96;
                     a.O = o; a.ldo = HD;
@@ -571,17 +535,15 @@ struct rt_engine {
                         k.store_rows[1] = HW; k.store_cols[1] = 77;
                     }
                 }
-                gemm(o, HD, k.out2, M, hcur, C, EPI_F32, hcur, C, nullptr, 0, fuse ? &lo3 : nullptr);
+                gemm(o, HD, k.out2, M, hcur, C, EPI_F32, hcur, C);
                 // --- GEGLU feed-forward (attention.py:209-304)
-                if (!fuse) layernorm(hcur, k.ln3, n, M);
+                layernorm(hcur, k.ln3, n, M);
                 bf16_t* gg = ws.b16((size_t)M * 4 * C);
-                gemm(n, C, k.ff1, M, gg, 4 * C, EPI_GEGLU, nullptr, 0, nullptr, 0, nullptr, fuse ? &li_ff : nullptr);
-                // the trunk after this block feeds the next block's norm1, or (last block) proj_out as a plain bf16 copy
-                const bool last = bi + 1 == nb;
-                LnOut lo1; lo1.aux = last ? hb : n; lo1.gamma = last ? nullptr : t.blocks[bi + 1].ln1.g; lo1.stat = last ? nullptr : stat;
-                gemm(gg, 4 * C, k.ff2, M, hcur, C, EPI_F32, hcur, C, nullptr, 0, fuse ? &lo1 : nullptr);
+                gemm(n, C, k.ff1, M, gg, 4 * C, EPI_GEGLU);
+                gemm(gg, 4 * C, k.ff2, M, hcur, C, EPI_F32, hcur, C);
             }
-            if (!fuse && !dry()) launch_cast_f32_bf16(hcur, hb, (size_t)M * C, stream);
+            bf16_t* hb = ws.b16((size_t)M * C);
+            if (!dry()) launch_cast_f32_bf16(hcur, hb, (size_t)M * C, stream);
             gemm(hb, C, t.pout, M, out, C, EPI_F32, x.p, C);
         }
         return Tensor{out, C};
@@ -594,7 +556,6 @@ struct rt_engine {
         RT_REQUIRE(Hh <= cfg.latent_h && Ww <= cfg.latent_w, "forward: latent larger than configured");
         RT_REQUIRE((Hh % (1 << (cfg.n_levels - 1))) == 0 && (Ww % (1 << (cfg.n_levels - 1))) == 0, "forward: latent size not divisible");
         const size_t m0 = ws.mark();
-        if (!dry()) fold_layernorms();
         // time / addition embeddings (unet_2d_condition.py:784-877)
         float* emb = ws.f32((size_t)B * temb_dim);
         {
@@ -889,7 +850,6 @@ int rt_bind_weight(rt_engine* e, const char* name, const void* ptr, int dtype, c
         PackArgs p = s.pack; p.src = ptr; p.src_dtype = dtype;
         launch_pack(p, e->stream);
         s.bound = true;
-        e->ln_folded = false;
     })
 }
 int rt_weights_missing(rt_engine* e, char* buf, int cap) {
@@ -899,7 +859,7 @@ int rt_weights_missing(rt_engine* e, char* buf, int cap) {
     return n;
 }
 int rt_arena_info(rt_engine* e, void** p, uint64_t* bytes) { RT_TRY(e, { need_device(e); *p = e->arena_base; *bytes = e->arena_bytes; }) }
-int rt_arena_mark_bound(rt_engine* e) { for (auto& s : e->slots) s.bound = true; e->ln_folded = false; return RT_OK; }
+int rt_arena_mark_bound(rt_engine* e) { for (auto& s : e->slots) s.bound = true; return RT_OK; }
 
 int rt_set_prompts(rt_engine* e, const float* pe, const float* pooled, const float* tids, int P, int pooled_dim) {
     RT_TRY(e, { need_device(e); e->set_prompts(pe, pooled, tids, P, pooled_dim); })
@@ -1063,20 +1023,6 @@ int rt_op_gemm(const void* A, const void* W, const float* bias, void* out, const
         g.Hout = Hout; g.Wout = Wout;
         launch_gemm(g, (hipStream_t)stream);
     })
-}
-int rt_op_gemm_ln(const void* A, const void* W, const float* bias, void* out, const float* res, int epi, int M, int N, int K, int lda, int ldw,
-                  int ldo, int ldres, void* aux_out, const float* aux_gamma, int ld_aux, float* stat_out, int ln_mode, const float* ln_stat,
-                  int ln_ng, int ln_C, float ln_eps, const float* ln_s, const float* ln_c, void* stream) {
-    OP_TRY({
-        GemmArgs g{}; g.A = (const bf16_t*)A; g.W = (const bf16_t*)W; g.bias = bias; g.out = out; g.res = res; g.zero = op_zero_page();
-        g.mode = A_DENSE; g.epi = epi; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldo = ldo; g.ldres = ldres;
-        g.aux_out = (bf16_t*)aux_out; g.aux_gamma = aux_gamma; g.ld_aux = ld_aux; g.stat_out = stat_out;
-        g.ln_mode = ln_mode; g.ln_stat = ln_stat; g.ln_ng = ln_ng; g.ln_C = ln_C; g.ln_eps = ln_eps; g.ln_s = ln_s; g.ln_c = ln_c;
-        launch_gemm(g, (hipStream_t)stream);
-    })
-}
-int rt_op_ln_fold(const void* W, int ldw, const float* gamma, const float* beta, const float* bias, float* s, float* c, int N, int K, void* stream) {
-    OP_TRY({ launch_ln_fold((const bf16_t*)W, ldw, gamma, beta, bias, s, c, N, K, (hipStream_t)stream); })
 }
 int rt_op_attention(const void* Q, int ldq, const void* K, int ldk, const void* VT, int ldvt, void* O, int ldo, const int* q_src,
                     const int* k_src, const int* v_src, const int* wset, const float* wabs, const float* wsgn, int B, int H,

@@ -48,25 +48,6 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x + 0.5f * fabsf(x) * er;                                                   // x * 0.5 * (1 + sign(x) * er)
 }
 
-// (mean, rstd) of `count` consecutive rows starting at `origin` (clamped to `limit` rows) from the producer's per-group partials,
-// two threads per row, fixed summation order: [0, ceil(ng/2)) + [ceil(ng/2), ng).  Called by every thread of the block before
-// the main loop (the first barrier of the loop publishes the table).
-__device__ __forceinline__ void ln_prologue(const GemmArgs& p, float2* lnst, int origin, int count, int limit, int tid, int nthr) {
-    const float invC = 1.f / (float)p.ln_C;
-    const int h0 = (p.ln_ng + 1) >> 1;
-    for (int idx = tid; idx < 2 * count; idx += nthr) {           // nthr is even: a row's two threads are neighbouring lanes
-        int row = origin + (idx >> 1); if (row >= limit) row = limit - 1;
-        const int half = idx & 1;
-        const float2* pp = (const float2*)p.ln_stat + (size_t)row * p.ln_ng;
-        float sm = 0.f, sq = 0.f;
-        for (int j = half ? h0 : 0; j < (half ? p.ln_ng : h0); ++j) { const float2 v = pp[j]; sm += v.x; sq += v.y; }
-        sm += __shfl_xor(sm, 1); sq += __shfl_xor(sq, 1);
-        const float mean = sm * invC;
-        float var = sq * invC - mean * mean; if (var < 0.f) var = 0.f;
-        if (!half) lnst[idx >> 1] = make_float2(mean, rsqrtf(var + p.ln_eps));
-    }
-}
-
 // ---- epilogue (shared by both main-loop variants), specialised at compile time on the epilogue kind.
 // With swapped operands the 32x32 accumulator tile is D[n][m]: m = lane&31 (row of C), n = (r&3) + 8*(r>>2) +
 // 4*(lane>>5) (column of C), i.e. a lane owns ONE output row and 4 consecutive columns per register quad.
@@ -76,15 +57,9 @@ __device__ __forceinline__ void ln_prologue(const GemmArgs& p, float2* lnst, int
 // (and the fp32 residual reads) move whole cache lines.  N % 4 == 0 (fp32) / N % 8 == 0 (bf16) is required.
 // PATCH (3x3-conv patch kernel): the tile's 256 rows are a 16x16 pixel patch, local row r -> output row
 // prow_base + (r>>4)*pW + (r&15); wrow0 is then the wave's first LOCAL row.
-// LayerNorm fusion (GemmArgs comment in common.h).  Consumer side: `lnst` = (mean, rstd) of the tile's rows (ln_mode 1) or columns
-// (ln_mode 2) in LDS, indexed relative to the tile origin (m0t, n0t); the affine correction replaces the bias add.  Producer side
-// (EPI_F32): the slab -> HBM pass also writes bf16(out * gamma) and the (sum, sumsq) of every (row, 32-column group): the eight
-// lanes that move one group's eight 16-B chunks reduce with a fixed xor tree, so the partials - and the statistics the consumers
-// derive from them in ln_prologue - do not depend on the tile configuration.
 template <int EPI, int TM, int TN, int NWC, int LDS_BYTES, bool PATCH = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[TM][TN], int wrow0, int wcol0, int lane, int wave_c,
-                                              char* smem, int prow_base = 0, int pW = 0, const float2* lnst = nullptr, int m0t = 0,
-                                              int n0t = 0) {
+                                              char* smem, int prow_base = 0, int pW = 0) {
     auto grow = [&](int r) { return PATCH ? prow_base + (r >> 4) * pW + (r & 15) : r; };
     constexpr bool F32 = EPI == EPI_F32;
     constexpr int ES = F32 ? 4 : 2;
@@ -102,13 +77,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
     const int NO = EPI == EPI_GEGLU ? (p.N >> 1) : p.N;                 // output columns
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        // LayerNorm fusion: mode 1 -> (mean, rstd) of this lane's row; mode 2 -> (s, c) of this lane's row (statistics are per column)
-        float ln_mu = 0.f, ln_rs = 1.f;
-        if (!PATCH && p.ln_mode == 1) { const float2 st = lnst[wrow0 - m0t + i * 32 + l31]; ln_mu = st.x; ln_rs = st.y; }
-        else if (!PATCH && p.ln_mode == 2) {
-            int row = wrow0 + i * 32 + l31; if (row >= p.M) row = p.M - 1;
-            ln_mu = p.ln_s[row]; ln_rs = p.ln_c[row];
-        }
 #pragma unroll
         for (int t0 = 0; t0 < TO; t0 += TS) {
             // ---- registers -> slab (this wave's 32 rows x up to TS*32 columns)
@@ -127,18 +95,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
                             const float4 b0 = *(const float4*)(p.bias + cb + cl), b1 = *(const float4*)(p.bias + cb + 32 + cl);
                             bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bg[0] = b1.x; bg[1] = b1.y; bg[2] = b1.z; bg[3] = b1.w;
                         }
-                        float sv[4] = {0, 0, 0, 0}, sg[4] = {0, 0, 0, 0};
-                        if (!PATCH && p.ln_mode == 1 && cb + 64 <= p.N) {
-                            const float4 a0 = *(const float4*)(p.ln_s + cb + cl), a1 = *(const float4*)(p.ln_s + cb + 32 + cl);
-                            const float4 c0 = *(const float4*)(p.ln_c + cb + cl), c1 = *(const float4*)(p.ln_c + cb + 32 + cl);
-                            sv[0] = a0.x; sv[1] = a0.y; sv[2] = a0.z; sv[3] = a0.w; sg[0] = a1.x; sg[1] = a1.y; sg[2] = a1.z; sg[3] = a1.w;
-                            bv[0] = c0.x; bv[1] = c0.y; bv[2] = c0.z; bv[3] = c0.w; bg[0] = c1.x; bg[1] = c1.y; bg[2] = c1.z; bg[3] = c1.w;
-                        }
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            float val = acc[i][2 * t][4 * g + e], gt = acc[i][2 * t + 1][4 * g + e];
-                            if (!PATCH && p.ln_mode == 1) { val = ln_rs * (val - ln_mu * sv[e]); gt = ln_rs * (gt - ln_mu * sg[e]); }
-                            val += bv[e]; gt += bg[e];
+                            const float val = acc[i][2 * t][4 * g + e] + bv[e], gt = acc[i][2 * t + 1][4 * g + e] + bg[e];
                             v[e] = val * gelu_erf(gt);
                         }
                     } else {
@@ -147,19 +106,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
                         if (p.bias && col < p.N) { const float4 b0 = *(const float4*)(p.bias + col); bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; }
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = acc[i][t][4 * g + e] + bv[e];
-                        if (!PATCH && p.ln_mode == 1) {
-                            if (col < p.N) {
-                                const float4 s4 = *(const float4*)(p.ln_s + col), c4 = *(const float4*)(p.ln_c + col);
-                                v[0] = ln_rs * (acc[i][t][4 * g + 0] - ln_mu * s4.x) + c4.x; v[1] = ln_rs * (acc[i][t][4 * g + 1] - ln_mu * s4.y) + c4.y;
-                                v[2] = ln_rs * (acc[i][t][4 * g + 2] - ln_mu * s4.z) + c4.z; v[3] = ln_rs * (acc[i][t][4 * g + 3] - ln_mu * s4.w) + c4.w;
-                            }
-                        } else if (!PATCH && p.ln_mode == 2) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float2 st = lnst[col - n0t + e];          // local column < BN: always inside the table
-                                v[e] = st.y * (acc[i][t][4 * g + e] - st.x * ln_mu) + ln_rs;   // (ln_mu, ln_rs) hold (s, c) of this lane's row here
-                            }
-                        }
                         if constexpr (EPI == EPI_BF16_TEMB) {
                             int row = grow(wrow0 + i * 32 + l31); if (row >= p.M) row = p.M - 1;
                             if (col < p.N) {
@@ -180,37 +126,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
             for (int idx0 = 0; idx0 < 32 * CPR; idx0 += 64) {
                 const int idx = idx0 + lane;
                 const int r = idx / cpr_pass, ch = idx - r * cpr_pass;
+                if (r >= 32) continue;
+                const int row = grow(wrow0 + i * 32 + r);
+                const int col = ocol0 + t0 * 32 + ch * (16 / ES);
+                if (row >= p.M || col >= NO) continue;
+                const uint4 q = *(const uint4*)(slab + r * RS + ch * 16);
                 if constexpr (F32) {
-                    // no early exits: the eight lanes of a (row, 32-column group) reduce the LayerNorm partials together
-                    const int row = grow(wrow0 + i * 32 + (r < 32 ? r : 0));
-                    const int col = ocol0 + t0 * 32 + ch * 4;
-                    const bool ok = r < 32 && row < p.M && col < NO;
-                    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (ok) {
-                        const uint4 q = *(const uint4*)(slab + r * RS + ch * 16);
-                        o = make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w));
-                        if (p.res) { const float4 rv = *(const float4*)(p.res + (size_t)row * p.ldres + col); o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w; }
-                        *(float4*)((float*)p.out + (size_t)row * p.ldo + col) = o;
-                        if (!PATCH && p.aux_out) {
-                            float4 gm = make_float4(1.f, 1.f, 1.f, 1.f);
-                            if (p.aux_gamma) gm = *(const float4*)(p.aux_gamma + col);
-                            uint2 w; w.x = pack_bf16x2(o.x * gm.x, o.y * gm.y); w.y = pack_bf16x2(o.z * gm.z, o.w * gm.w);
-                            *(uint2*)(p.aux_out + (size_t)row * p.ld_aux + col) = w;
-                        }
-                    }
-                    if (!PATCH && p.stat_out) {
-                        float sm = (o.x + o.y) + (o.z + o.w), sq = (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
-                        sm += __shfl_xor(sm, 1); sq += __shfl_xor(sq, 1);
-                        sm += __shfl_xor(sm, 2); sq += __shfl_xor(sq, 2);
-                        sm += __shfl_xor(sm, 4); sq += __shfl_xor(sq, 4);
-                        if (ok && (lane & 7) == 0) *(float2*)(p.stat_out + ((size_t)row * (p.N >> 5) + (col >> 5)) * 2) = make_float2(sm, sq);
-                    }
+                    float4 o = make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w));
+                    if (p.res) { const float4 rv = *(const float4*)(p.res + (size_t)row * p.ldres + col); o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w; }
+                    *(float4*)((float*)p.out + (size_t)row * p.ldo + col) = o;
                 } else {
-                    if (r >= 32) continue;
-                    const int row = grow(wrow0 + i * 32 + r);
-                    const int col = ocol0 + t0 * 32 + ch * (16 / ES);
-                    if (row >= p.M || col >= NO) continue;
-                    *(uint4*)((bf16_t*)p.out + (size_t)row * p.ldo + col) = *(const uint4*)(slab + r * RS + ch * 16);
+                    *(uint4*)((bf16_t*)p.out + (size_t)row * p.ldo + col) = q;
                 }
             }
         }
@@ -351,9 +277,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
 #pragma unroll
     for (int s = 0; s < S - 1; ++s)
         if (s < nk) stage(s, KMAP(s), -1);
-    float2* const lnst = (float2*)(smem + S * STAGE);        // LayerNorm fusion: (mean, rstd) table behind the ring
-    if (p.ln_mode == 1) ln_prologue(p, lnst, m0, BM, p.M, tid, NW * 64);
-    else if (p.ln_mode == 2) ln_prologue(p, lnst, n0, BN, p.N, tid, NW * 64);
 
     // one K tile: wait for it, barrier, then (reads ks+1 | DMA issue of tile kt+S-1 | MFMA ks) per k-step.
     // MORE / LAST are compile-time so the loop body is straight-line code (no control flow between MFMAs).
@@ -403,7 +326,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     for (; kt + 1 < nk; ++kt) ktile(kt, std::false_type{}, std::false_type{});
     for (; kt < nk; ++kt) ktile(kt, std::false_type{}, std::true_type{});
     __syncthreads();      // every wave is done with the LDS ring: it becomes the epilogue's transpose slabs
-    gemm_epilogue<EPI, TM, TN, NW, S * STAGE>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane, wave, smem, 0, 0, lnst, m0, n0);
+    gemm_epilogue<EPI, TM, TN, NW, S * STAGE>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane, wave, smem);
 }
 
 // ================================================================================================
@@ -548,9 +471,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pp_kernel(GemmArgs p) {
 
     const int nk = (p.K + BK - 1) / BK;
     stage_a(0, 0); stage_b(0, 0);
-    float2* const lnst = (float2*)(smem + S * STAGE);
-    if (p.ln_mode == 1) ln_prologue(p, lnst, m0, BM, p.M, tid, NW * 64);
-    else if (p.ln_mode == 2) ln_prologue(p, lnst, n0, BN, p.N, tid, NW * 64);
     if (nk > 1) {
         stage_a(1, BK); stage_b(1, BK);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory");
@@ -633,7 +553,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pp_kernel(GemmArgs p) {
 #endif
     if (!grp1) __builtin_amdgcn_s_barrier();       // pairs with group 1's last barrier
     __syncthreads();                               // the ring becomes the epilogue's transpose slabs
-    gemm_epilogue<EPI, TM, TN, NW, S * STAGE>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane, wave, smem, 0, 0, lnst, m0, n0);
+    gemm_epilogue<EPI, TM, TN, NW, S * STAGE>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane, wave, smem);
 }
 
 // ================================================================================================
@@ -672,9 +592,6 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void gemm_ws_kernel(GemmArgs p
     const int tm = first_m + (bid % gsz) % gm, tn = (bid % gsz) / gm;
     const int m0 = tm * BM, n0 = tn * BN;
     const int nk = (p.K + BK - 1) / BK;
-    float2* const lnst = (float2*)(smem + 3 * STAGE);
-    if (p.ln_mode == 1) ln_prologue(p, lnst, m0, BM, p.M, tid, (NWC + NL) * 64);
-    else if (p.ln_mode == 2) ln_prologue(p, lnst, n0, BN, p.N, tid, (NWC + NL) * 64);
 
     if (wave >= NWC) {
         // ------------------------------------------------------------------ loader wave
@@ -782,7 +699,7 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void gemm_ws_kernel(GemmArgs p
         }
     }
     __builtin_amdgcn_s_barrier();          // all compute waves left the ring (the loaders arrive here too)
-    gemm_epilogue<EPI, TM, TN, NWC, 3 * STAGE>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane, wave, smem, 0, 0, lnst, m0, n0);
+    gemm_epilogue<EPI, TM, TN, NWC, 3 * STAGE>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane, wave, smem);
 }
 
 // ================================================================================================
@@ -983,7 +900,7 @@ static void launch_cfg(const GemmArgs& a, hipStream_t st) {
     if constexpr (EPI == EPI_GEGLU && (BN / WN / 32) % 2 != 0) {
         throw rt_error(RT_E_INVALID, "gemm: this tile configuration cannot run the GEGLU epilogue");
     } else {
-        const size_t lds = (size_t)S * (BM + BN) * BK * 2 + RT_LN_LDS_BYTES;
+        const size_t lds = (size_t)S * (BM + BN) * BK * 2;
         static bool attr = false;
         if (!attr) {
             HIP_CHECK(hipFuncSetAttribute((const void*)gemm_kernel<MODE, EPI, BM, BN, WM, WN, S>,
@@ -1000,7 +917,7 @@ static void launch_ws(const GemmArgs& a, hipStream_t st) {
     if constexpr (EPI == EPI_GEGLU && (BN / WN / 32) % 2 != 0) {
         throw rt_error(RT_E_INVALID, "gemm: this tile configuration cannot run the GEGLU epilogue");
     } else {
-        const size_t lds = (size_t)3 * (BM + BN) * BK * 2 + RT_LN_LDS_BYTES;
+        const size_t lds = (size_t)3 * (BM + BN) * BK * 2;
         static bool attr = false;
         if (!attr) {
             HIP_CHECK(hipFuncSetAttribute((const void*)gemm_ws_kernel<MODE, EPI, BM, BN, WM, WN, NL>,
@@ -1017,7 +934,7 @@ static void launch_pp(const GemmArgs& a, hipStream_t st) {
     if constexpr (EPI == EPI_GEGLU && (BN / WN / 32) % 2 != 0) {
         throw rt_error(RT_E_INVALID, "gemm: this tile configuration cannot run the GEGLU epilogue");
     } else {
-        const size_t lds = (size_t)3 * (BM + BN) * BK * 2 + RT_LN_LDS_BYTES;
+        const size_t lds = (size_t)3 * (BM + BN) * BK * 2;
         static bool attr = false;
         if (!attr) {
             HIP_CHECK(hipFuncSetAttribute((const void*)gemm_pp_kernel<MODE, EPI, BM, BN, WM, WN>,
@@ -1158,18 +1075,6 @@ void launch_gemm(const GemmArgs& a, hipStream_t st) {
     if (a.res) RT_REQUIRE(a.ldres % 4 == 0 && ((uintptr_t)a.res & 15) == 0, "gemm: residual must be 16-B aligned");
     if (a.bias) RT_REQUIRE(((uintptr_t)a.bias & 15) == 0, "gemm: bias must be 16-B aligned");
     if (a.temb) RT_REQUIRE(a.temb_ld % 4 == 0 && ((uintptr_t)a.temb & 15) == 0, "gemm: temb must be 16-B aligned");
-    if (a.aux_out || a.stat_out) {
-        RT_REQUIRE(a.epi == EPI_F32 && a.mode == A_DENSE, "gemm: the LayerNorm producer outputs need the dense fp32 epilogue");
-        if (a.aux_out) RT_REQUIRE(a.ld_aux % 4 == 0 && ((uintptr_t)a.aux_out & 7) == 0 && (!a.aux_gamma || ((uintptr_t)a.aux_gamma & 15) == 0), "gemm: aux output alignment");
-        if (a.stat_out) RT_REQUIRE(a.N % 32 == 0 && ((uintptr_t)a.stat_out & 7) == 0, "gemm: row statistics need N % 32 == 0");
-    }
-    if (a.ln_mode) {
-        RT_REQUIRE(a.mode == A_DENSE && (a.ln_mode == 1 || a.ln_mode == 2) && !a.bias && a.ln_stat && a.ln_s && a.ln_c && a.ln_ng >= 1 && a.ln_C >= 1,
-                   "gemm: LayerNorm consumer arguments (the bias is folded into ln_c)");
-        RT_REQUIRE(((uintptr_t)a.ln_stat & 7) == 0 && ((uintptr_t)a.ln_s & 15) == 0 && ((uintptr_t)a.ln_c & 15) == 0, "gemm: LayerNorm vectors must be 16-B aligned");
-        RT_REQUIRE(a.ln_mode == 1 || a.epi == EPI_BF16, "gemm: column statistics are only wired for the bf16 epilogue (V^T projection)");
-        RT_REQUIRE(a.epi != EPI_BF16_TEMB, "gemm: LayerNorm consumer with a time-embedding epilogue is not built");
-    }
     // In-place residual (out == res) is safe: every element is read and written by the same thread.
     if (conv_patch_eligible(a)) {
         if (a.mode == A_CONV3_UP2) launch_conv3p<EPI_F32, true>(a, st);

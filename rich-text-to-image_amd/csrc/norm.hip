@@ -229,28 +229,3 @@ void launch_layernorm(const float* x, const float* gamma, const float* beta, bf1
     hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, gamma, beta, out, rows, C, eps);
     HIP_CHECK(hipGetLastError());
 }
-
-// ---------------------------------------------------------------- LayerNorm fusion: fold (gamma, beta, bias) against a packed weight matrix
-// s[n] = sum_k gamma[k] * W[n,k];  c[n] = sum_k beta[k] * W[n,k] + bias[n]   (W bf16 [N, ldw]; one wavefront per row; fp32; runs once
-// after the weights are bound).  See GemmArgs in common.h for how the GEMM epilogues use the two vectors.
-__global__ __launch_bounds__(256) void ln_fold_kernel(const bf16_t* __restrict__ W, int ldw, const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta, const float* __restrict__ bias, float* __restrict__ s,
-                                                      float* __restrict__ c, int N, int K) {
-    const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= N) return;
-    const bf16_t* w = W + (size_t)n * ldw;
-    float as = 0.f, ac = 0.f;
-    for (int k = lane; k < K; k += 64) {
-        const float wv = bf16_to_f32(w[k]);
-        as += gamma[k] * wv; ac += beta[k] * wv;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { as += __shfl_xor(as, o); ac += __shfl_xor(ac, o); }
-    if (lane == 0) { s[n] = as; c[n] = ac + (bias ? bias[n] : 0.f); }
-}
-void launch_ln_fold(const bf16_t* W, int ldw, const float* gamma, const float* beta, const float* bias, float* s, float* c, int N, int K,
-                    hipStream_t st) {
-    hipLaunchKernelGGL(ln_fold_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, W, ldw, gamma, beta, bias, s, c, N, K);
-    HIP_CHECK(hipGetLastError());
-}

@@ -333,86 +333,6 @@ def test_attention_against_reference_module_golden():
     report("reference Attention module y_inj (real_attn_probs)", y[B:], g["y_inj"], atol=3e-2, rtol=3e-2)
 
 
-# ----------------------------------------------------------------------------------------------- LayerNorm fusion
-def _gemm_ln(A, W, epi, out_dtype, out_cols, res=None, aux_gamma=None, want_aux=False, want_stat=False, ln=None, bias=None):
-    """rt_op_gemm_ln wrapper.  ln = (mode, stat [rows, ng, 2], C, s, c)."""
-    import ctypes as C
-    from hiputil import chk
-    from rich_text_to_image_amd.engine import _ptr, load_library
-    lib = load_library()
-    M, K = A.shape
-    N = W.shape[0]
-    out = torch.empty(M, out_cols, device=DEV, dtype=out_dtype)
-    aux = torch.empty(M, N, device=DEV, dtype=torch.bfloat16) if want_aux else None
-    stat = torch.zeros(M, N // 32, 2, device=DEV) if want_stat else None
-    mode, lstat, lC, ls, lc = ln if ln is not None else (0, None, 0, None, None)
-    chk(lib.rt_op_gemm_ln(_ptr(A), _ptr(W), _ptr(bias), _ptr(out), _ptr(res), epi, M, N, K, A.stride(0), W.stride(0), out.stride(0),
-                          res.stride(0) if res is not None else 0, _ptr(aux), _ptr(aux_gamma), N, _ptr(stat), mode, _ptr(lstat),
-                          lstat.shape[1] if lstat is not None else 0, lC, C.c_float(1e-5), _ptr(ls), _ptr(lc), None))
-    torch.cuda.synchronize()
-    return out, aux, stat
-
-
-def _fold(W, gamma, beta, bias):
-    from hiputil import chk
-    from rich_text_to_image_amd.engine import _ptr, load_library
-    N, K = W.shape
-    s, c = torch.empty(N, device=DEV), torch.empty(N, device=DEV)
-    chk(load_library().rt_op_ln_fold(_ptr(W), W.stride(0), _ptr(gamma), _ptr(beta), _ptr(bias), _ptr(s), _ptr(c), N, K, None))
-    torch.cuda.synchronize()
-    return s, c
-
-
-@pytest.mark.parametrize("M,N,K", [(200, 64, 96), (512, 320, 256), (4096, 1280, 1280), (1000, 640, 2560)])
-def test_gemm_layernorm_producer_outputs(M, N, K):
-    """fp32 trunk GEMM (+bias +residual) that also emits bf16(out * gamma) and the per-(row, 32-column group) (sum, sumsq)."""
-    A, W = bf(rnd(M, K, seed=31)), bf(rnd(N, K, seed=32, scale=K ** -0.5))
-    bias, res, gamma = rnd(N, seed=33).to(DEV), (rnd(M, N, seed=34) * 2 + 0.7).to(DEV), (1 + 0.2 * rnd(N, seed=35)).to(DEV)
-    out, aux, stat = _gemm_ln(A, W, 1, torch.float32, N, res=res, aux_gamma=gamma, want_aux=True, want_stat=True, bias=bias)
-    ref = A.float() @ W.float().t() + bias + res
-    report(f"ln-producer out {M}x{N}x{K}", out, ref, **F32_OUT)
-    report("ln-producer aux", aux, out * gamma, atol=1e-2, rtol=8e-3)          # bf16 rounding of the kernel's own fp32 result
-    g = out.reshape(M, N // 32, 32).double()
-    report("ln-producer sum", stat[..., 0], g.sum(-1), atol=2e-4, rtol=2e-5)
-    report("ln-producer sumsq", stat[..., 1], (g * g).sum(-1), atol=2e-4, rtol=2e-5)
-    out2, aux2, _ = _gemm_ln(A, W, 1, torch.float32, N, res=res, want_aux=True, bias=bias)    # gamma = NULL: plain bf16 copy, no statistics
-    assert torch.equal(out2, out)
-    report("ln-producer plain copy", aux2, out, atol=1e-2, rtol=8e-3)
-
-
-@pytest.mark.parametrize("M,C,N", [(256, 64, 128), (1000, 320, 640), (2048, 1280, 2560)])
-def test_gemm_layernorm_consumers_match_layer_norm_plus_linear(M, C, N):
-    """LN(x) W^T (+b) through the fused path = producer-style operands (bf16(x*gamma), group partials) + epilogue correction,
-    against F.layer_norm + F.linear in fp32: row statistics (bf16 and GEGLU epilogues) and column statistics (swapped V^T form)."""
-    x = (rnd(M, C, seed=41) * 2.5 + 0.8).to(DEV)                 # non-zero mean: the -mean*s correction must matter
-    gamma, beta = (1 + 0.2 * rnd(C, seed=42)).to(DEV), (0.3 * rnd(C, seed=43)).to(DEV)
-    xg = bf(x * gamma)
-    g = x.reshape(M, C // 32, 32)
-    stat = torch.stack([g.sum(-1), (g * g).sum(-1)], -1).contiguous()
-    W = bf(rnd(N, C, seed=44, scale=C ** -0.5))
-    bias = rnd(N, seed=45).to(DEV)
-    ln = F.layer_norm(x, (C,), gamma, beta, 1e-5)
-    # (a) row statistics, bf16 epilogue, with a projection bias folded into c
-    s, c = _fold(W, gamma, beta, bias)
-    report("ln_fold s", s, (W.float() * gamma).sum(-1), atol=1e-3, rtol=1e-4)
-    report("ln_fold c", c, (W.float() * beta).sum(-1) + bias, atol=1e-3, rtol=1e-4)
-    out, _, _ = _gemm_ln(xg, W, 0, torch.bfloat16, N, ln=(1, stat, C, s, c))
-    report(f"ln-consumer rows {M}x{C}->{N}", out, ln @ W.float().t() + bias, atol=4e-2, rtol=2e-2)
-    # (b) column statistics: out^T = W x^T  (the V^T projection: A = weights, "W" operand = the activations)
-    s0, c0 = _fold(W, gamma, beta, None)
-    outT, _, _ = _gemm_ln(W, xg, 0, torch.bfloat16, M, ln=(2, stat, C, s0, c0))
-    report("ln-consumer columns (V^T form)", outT, (ln @ W.float().t()).t(), atol=4e-2, rtol=2e-2)
-    # (c) GEGLU epilogue: rows interleaved per 64-block [32 value | 32 gate]
-    if N % 128 == 0:
-        half = N // 2
-        idx = torch.cat([torch.cat([torch.arange(b * 32, b * 32 + 32), half + torch.arange(b * 32, b * 32 + 32)]) for b in range(half // 32)])
-        Wp, bp = W[idx.to(DEV)].contiguous(), bias[idx.to(DEV)].contiguous()
-        sp, cp = _fold(Wp, gamma, beta, bp)
-        og, _, _ = _gemm_ln(xg, Wp, 3, torch.bfloat16, half, ln=(1, stat, C, sp, cp))
-        full = ln @ W.float().t() + bias
-        report("ln-consumer GEGLU", og, full[:, :half] * F.gelu(full[:, half:]), atol=4e-2, rtol=2e-2)
-
-
 # ----------------------------------------------------------------------------------------------- norms
 @pytest.mark.parametrize("B,HW,C1,C2,G,silu,bf16in", [(2, 256, 64, 0, 8, True, False), (3, 1024, 320, 0, 32, True, False),
                                                       (2, 64, 1280, 640, 32, True, False), (2, 4096, 640, 320, 32, True, False),

@@ -1,6 +1,7 @@
 """Per-kernel SQ counters from one rocprofv3 --pmc pass (rocpd sqlite): MFMA utilisation, LDS bank conflicts, wave stall split.
-    MfmaUtil     = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 256 CUs * 4 SIMDs)   (busy cycles are summed over SIMDs,
-                   GRBM_GUI_ACTIVE over the 8 XCDs; clock = GRBM_GUI_ACTIVE / 8 / duration)
+    MfmaUtil     = SQ_VALU_MFMA_BUSY_CYCLES / (cycles * 256 CUs * 4 SIMDs), cycles = min(GRBM_GUI_ACTIVE / 8 XCDs, 2.4 GHz * duration)
+                   (busy cycles are summed over SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs; rows with clock_capped = true had a
+                   GUI-active window longer than the dispatch: their utilisation is a lower bound)
     LDS conflict = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE                               (extra cycles / all LDS-array cycles)
     wait split   = SQ_WAIT_ANY, SQ_WAIT_INST_ANY as fractions of SQ_WAVE_CYCLES
 python tools/pmc_sq.py <results.db> <out.json>"""
@@ -25,9 +26,13 @@ def main(db_path, out):
         dur = max(v[2] for v in k.values())
         gui = g("GRBM_GUI_ACTIVE")
         r = dict(launches=n, avg_us=dur / n / 1e3)
-        if gui:
-            r["mfma_util"] = g("SQ_VALU_MFMA_BUSY_CYCLES") / (gui / 8 * 256 * 4)
-            r["clock_ghz"] = gui / 8 / dur if dur else None      # cycles per ns
+        if gui and dur:
+            # GRBM_GUI_ACTIVE spans more than the dispatch for short kernels (ramp-up / drain of the profiled pass): the derived
+            # clock then exceeds the part's 2.4 GHz maximum.  Cap the cycle budget at 2.4 GHz x duration and say so.
+            cyc = min(gui / 8, 2.4 * dur)
+            r["mfma_util"] = g("SQ_VALU_MFMA_BUSY_CYCLES") / (cyc * 256 * 4)
+            r["clock_ghz"] = cyc / dur                            # cycles per ns
+            r["clock_capped"] = bool(gui / 8 > 2.4 * dur)         # True: utilisation is a lower bound, not a measurement
         if g("SQ_LDS_IDX_ACTIVE"):
             r["lds_conflict_frac"] = g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE")
         if g("SQ_WAVE_CYCLES"):
