@@ -703,6 +703,170 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void gemm_ws_kernel(GemmArgs p
 }
 
 // ================================================================================================
+// 8-phase 256x256 kernel (cfg 7) for the wide-N dense GEMMs (GEGLU 7168x10240x1280, the stacked Q|K projection): the guide's
+// phase-interleaved schedule (cdna_hip_programming.md "256^2 8-phase template", T2-T5) on this file's 32x32x16 MFMA, swizzle
+// and epilogue, so results stay bit-identical with every other configuration.
+//   8 waves as 2 (M) x 4 (N), 128 x 64 outputs per wave (4 x 2 MFMA tiles: 24 ds_read_b128 per 32 MFMAs instead of 32 per 32
+//   in the 16-wave kernel).  A K tile is four 16-KB HALF tiles: A0/A1 = rows [0,64) / [64,128) of both M waves, B0/B1 = columns
+//   [0,32) / [32,64) of all four N waves.  LDS = 2 K tiles x 4 half tiles = 128 KB.
+//   A K tile is two sections of two C quadrants x K=64 each (16 MFMAs):  a = (A0,B0) (A0,B1),  b = (A1,B1) (A1,B0);  B0 / B1 stay
+//   in registers.  (Measured with one quadrant per section: load 350 | barrier 90 | MFMA 320 | barrier 105 cycles - the barrier
+//   pair was a quarter of the loop.)
+//   section:  ds_read what it needs | issue TWO half tiles (4 LDS-DMA pieces per wave) | counted vmcnt | lgkmcnt(0) | s_barrier |
+//             setprio 1 | 16 MFMA | setprio 0 | s_barrier
+//   The two M wave groups run ONE barrier apart: while one group is in its MFMA section the other issues reads and copies.
+// Pipeline: half tile h = 4*tile + j (j: A0,B0,B1,A1 = consumption order) is issued six half tiles ahead of its consumption,
+// i.e. three to four half tiles (48-64 KB per CU) are in flight behind every barrier; it lands in slot (tile&1, j), whose
+// previous occupant's reads were retired (lgkmcnt(0) in front of a barrier every wave has passed) at least one full section
+// earlier (WAR), and is first read >= 2 barriers after the counted s_waitcnt vmcnt that retires it (RAW, also across the two
+// staggered groups: every wave's wait precedes the barrier the reader has passed).
+#ifdef RT_G8_TIMING
+__device__ long long g_g8_times[8 * 4];
+#endif
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM = 256, BN = 256, HALF = 128 * BK * 2, KTILE = 4 * HALF;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM, nwg = ntm * ntn;
+    int bid = blockIdx.x;
+    if (!(p.debug & 1)) {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int GRP = (p.debug >> 4) ? (p.debug >> 4) : 4;
+    const int gsz = GRP * ntn;
+    const int first_m = (bid / gsz) * GRP;
+    const int gm = (ntm - first_m) < GRP ? (ntm - first_m) : GRP;
+    const int tm = first_m + (bid % gsz) % gm, tn = (bid % gsz) / gm;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- staging: per half tile this wave copies the 8-row pieces q = wave and wave + 8 (local rows 8q .. 8q+7 of the half)
+    const int lrow = lane >> 3, pslot = lane & 7;
+    int a_off[2][2], b_off[2][2], skey[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int lr = (wave + 8 * u) * 8 + lrow;                  // local row inside the half tile
+        skey[u] = (lr >> 1) & 7;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int ra = m0 + (lr >> 6) * 128 + h * 64 + (lr & 63); if (ra >= p.M) ra = p.M - 1;
+            int rb = n0 + (lr >> 5) * 64 + h * 32 + (lr & 31); if (rb >= p.N) rb = p.N - 1;
+            a_off[h][u] = ra * p.lda; b_off[h][u] = rb * p.ldw;
+        }
+    }
+    // half tile h = 4*tile + j; j: 0 = A0, 1 = B0, 2 = B1, 3 = A1
+    auto stage = [&](int h) {
+        const int t = h >> 2, j = h & 3;
+        char* dst = smem + (t & 1) * KTILE + j * HALF;
+        const bool isA = j == 0 || j == 3;
+        const int hh = j >> 1;                                      // A0, B0 -> half 0; B1, A1 -> half 1
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int k = t * BK + ((pslot ^ skey[u]) << 3);
+            const bf16_t* src = p.zero;
+            if (k < p.K) src = isA ? p.A + (hh ? a_off[1][u] : a_off[0][u]) + k : p.W + (hh ? b_off[1][u] : b_off[0][u]) + k;
+            glds16(src, dst + (wave + 8 * u) * 1024);
+        }
+    };
+
+    // ---- fragments: this lane's rows inside the half tiles
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int key = (l31 >> 1) & 7;                                 // local rows are 32*x + l31: the key depends on l31 only
+    int kx[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) kx[ks] = ((ks * 2 + hi) ^ key) << 4;
+    const int a_row = (wr * 64 + l31) * 128;                        // + i2 * 4096 for the second 32-row tile of the half
+    const int b_row = (wc * 32 + l31) * 128;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (p.K + BK - 1) / BK;
+#pragma unroll
+    for (int h = 0; h < 6; ++h) stage(h);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");               // A0, B0, B1 of tile 0 landed (this wave's pieces)
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();                     // group 1 runs one barrier behind group 0
+    __builtin_amdgcn_sched_barrier(0);
+
+    bf16x8 fa[2][4], fb0[4], fb1[4];
+#ifdef RT_G8_TIMING
+    long long tacc[4] = {0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#define G8_T(i) { const long long now_ = __builtin_readcyclecounter(); tacc[i] += now_ - tlast; tlast = now_; }
+#else
+#define G8_T(i)
+#endif
+    // The MFMA builtins are pure values to the compiler: nothing orders them against s_barrier / s_setprio (the instruction
+    // selector happily sinks a whole quadrant into the next phase's load section).  Two empty asm statements pin the group: the
+    // first makes the fragments opaque AFTER the barrier (no MFMA can be hoisted above it), the second consumes the accumulators
+    // BEFORE the closing barrier (no MFMA can sink below it) - guide 5.7 item 3.
+    // One MFMA section = two C quadrants (16 MFMAs): with one quadrant per section the two barriers cost ~200 of ~870 cycles.
+#define RT_G8_MFMA2(IA, J0, F0, J1, F1)                                                                              \
+    {                                                                                                                \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* also retires this section's reads before anyone re-stages */ \
+        G8_T(0)                                                                                                      \
+        __builtin_amdgcn_s_barrier();                                                                                \
+        G8_T(1)                                                                                                      \
+        asm volatile("" : "+v"(F0[0]), "+v"(F0[1]), "+v"(F0[2]), "+v"(F0[3]), "+v"(F1[0]), "+v"(F1[1]), "+v"(F1[2]), "+v"(F1[3]), \
+                          "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(fa[1][0]), "+v"(fa[1][1]),    \
+                          "+v"(fa[1][2]), "+v"(fa[1][3]));                                                           \
+        __builtin_amdgcn_s_setprio(1);                                                                               \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                           \
+            acc[IA][J0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F0[ks], fa[0][ks], acc[IA][J0], 0, 0, 0);          \
+            acc[IA + 1][J0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F0[ks], fa[1][ks], acc[IA + 1][J0], 0, 0, 0);  \
+            acc[IA][J1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F1[ks], fa[0][ks], acc[IA][J1], 0, 0, 0);          \
+            acc[IA + 1][J1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F1[ks], fa[1][ks], acc[IA + 1][J1], 0, 0, 0);  \
+        }                                                                                                            \
+        asm volatile("" : "+v"(acc[IA][J0]), "+v"(acc[IA + 1][J0]), "+v"(acc[IA][J1]), "+v"(acc[IA + 1][J1]));       \
+        __builtin_amdgcn_s_setprio(0);                                                                               \
+        G8_T(2)                                                                                                      \
+        __builtin_amdgcn_s_barrier();                                                                                \
+        G8_T(3)                                                                                                      \
+    }
+    for (int t = 0; t < nk; ++t) {
+        const char* base = smem + (t & 1) * KTILE;
+        const int h0 = 4 * t + 6;
+        // ---- section a: quadrants (A0, B0), (A0, B1)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) fb0[ks] = *(const bf16x8*)(base + 1 * HALF + b_row + kx[ks]);
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) fa[i2][ks] = *(const bf16x8*)(base + 0 * HALF + a_row + i2 * 4096 + kx[ks]);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) fb1[ks] = *(const bf16x8*)(base + 2 * HALF + b_row + kx[ks]);
+        stage(h0); stage(h0 + 1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");           // A1 of this tile landed
+        RT_G8_MFMA2(0, 0, fb0, 1, fb1)
+        // ---- section b: quadrants (A1, B1), (A1, B0); B0 / B1 still in registers
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) fa[i2][ks] = *(const bf16x8*)(base + 3 * HALF + a_row + i2 * 4096 + kx[ks]);
+        stage(h0 + 2); stage(h0 + 3);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");           // A0, B0, B1 of the next tile landed
+        RT_G8_MFMA2(2, 1, fb1, 0, fb0)
+    }
+#undef RT_G8_MFMA2
+#ifdef RT_G8_TIMING
+    if (blockIdx.x == 0 && lane == 0) for (int i = 0; i < 4; ++i) g_g8_times[wave * 4 + i] = tacc[i];
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the dummy copies behind the last tile
+    if (wr == 0) __builtin_amdgcn_s_barrier();                     // pairs with group 1's last barrier
+    __syncthreads();                                               // the ring becomes the epilogue's transpose slabs
+    gemm_epilogue<EPI, 4, 2, 8, 2 * KTILE>(p, acc, m0 + wr * 128, n0 + wc * 64, lane, wave, smem);
+}
+
+// ================================================================================================
 // 3x3 stride-1 convolution on 16x16 pixel patches (conv3p_kernel).  The implicit-GEMM kernels above fetch every input
 // pixel nine times (once per tap) through the L2 -> LDS copy path, which is what bounds them.  Here a
 // block owns a 16x16 output patch x 160 output channels; per 64-channel chunk the 18x18 input HALO is copied to LDS
@@ -891,9 +1055,9 @@ __global__ __launch_bounds__(512) void conv3p_kernel(GemmArgs p) {
 
 // ---------------------------------------------------------------------------------------------- launch
 struct TileCfg { int BM, BN, threads, stages, geglu_ok; };
-#define RT_NCFG 7
+#define RT_NCFG 8
 static const TileCfg kCfg[RT_NCFG] = {{128, 128, 256, 2, 1}, {256, 128, 512, 3, 1}, {256, 160, 512, 3, 0}, {256, 256, 1024, 2, 1},
-                                       {256, 160, 768, 3, 0}, {256, 128, 768, 3, 1}, {256, 160, 512, 3, 0}};
+                                       {256, 160, 768, 3, 0}, {256, 128, 768, 3, 1}, {256, 160, 512, 3, 0}, {256, 256, 512, 2, 1}};
 
 template <int MODE, int EPI, int BM, int BN, int WM, int WN, int S>
 static void launch_cfg(const GemmArgs& a, hipStream_t st) {
@@ -946,6 +1110,17 @@ static void launch_pp(const GemmArgs& a, hipStream_t st) {
     }
 }
 
+template <int EPI>
+static void launch_g8(const GemmArgs& a, hipStream_t st) {
+    constexpr int LDS = 2 * 4 * 128 * BK * 2;
+    static bool attr = false;
+    if (!attr) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)gemm8_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemm8_kernel<EPI>), dim3(cdiv(a.M, 256) * cdiv(a.N, 256)), dim3(512), LDS, st, a);
+}
+
 template <int MODE, int EPI>
 static void launch_me(const GemmArgs& a, int cfg, hipStream_t st) {
     switch (cfg) {
@@ -956,9 +1131,13 @@ static void launch_me(const GemmArgs& a, int cfg, hipStream_t st) {
         case 4: launch_ws<MODE, EPI, 256, 160, 8, 1, 4>(a, st); break;
         case 5: launch_ws<MODE, EPI, 256, 128, 4, 2, 4>(a, st); break;
         case 6: launch_pp<MODE, EPI, 256, 160, 8, 1>(a, st); break;
+        case 7:
+            if constexpr (MODE == A_DENSE) launch_g8<EPI>(a, st);
+            else throw rt_error(RT_E_INVALID, "gemm: the 8-phase configuration is dense-only");
+            break;
 #ifdef RT_PROBE
-        case 7: launch_cfg<MODE, EPI, 256, 256, 2, 4, 2>(a, st); break;      // 8 waves, 128x64 per wave (ties cfg 3)
-        case 8: launch_cfg<MODE, EPI, 256, 320, 4, 2, 2>(a, st); break;      // 64x160 per wave, 142 flop/B through the copy path
+        case 8: launch_cfg<MODE, EPI, 256, 256, 2, 4, 2>(a, st); break;      // 8 waves, 128x64 per wave (ties cfg 3)
+        case 9: launch_cfg<MODE, EPI, 256, 320, 4, 2, 2>(a, st); break;      // 64x160 per wave, 142 flop/B through the copy path
 #endif
         default: throw rt_error(RT_E_INVALID, "gemm: bad tile configuration");
     }
@@ -1038,6 +1217,7 @@ static int pick_config(const GemmArgs& a, hipStream_t st) {
         float best_ms = 1e30f;
         for (int c = 0; c < RT_NCFG; ++c) {
             if (a.epi == EPI_GEGLU && !kCfg[c].geglu_ok) continue;
+            if (c == 7 && a.mode != A_DENSE) continue;          // the 8-phase kernel is dense-only
             launch_with_cfg(t, c, st);                          // warm (also sets the LDS attribute)
             float ms = 1e30f;
             for (int rep = 0; rep < 3; ++rep) {                 // best of three batches: single batches are +-5 % noisy

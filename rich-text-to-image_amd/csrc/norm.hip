@@ -53,11 +53,19 @@ __global__ __launch_bounds__(512) void gn_stats_kernel(GroupNormArgs p) {
         for (int vec = v0; vec < nv; vec += tcols) {
             const int c = vec * 4;
             float s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
-            for (int r = r0 + rl; r < r1; r += nrl) {
-                float v[4];
-                load4<BF16IN>(p.x1, p.x2, p.C1, p.C2, (size_t)b * p.HW + r, c, v);
+            // four rows per trip: the loads are issued together (one row at a time left ~8 KB in flight per block and the
+            // kernel at 3.7 TB/s); the accumulation order over rows is unchanged
+            for (int r = r0 + rl; r < r1; r += 4 * nrl) {
+                float v[4][4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { s[e] += v[e]; ss[e] += v[e] * v[e]; }
+                for (int u = 0; u < 4; ++u)
+                    if (r + u * nrl < r1) load4<BF16IN>(p.x1, p.x2, p.C1, p.C2, (size_t)b * p.HW + r + u * nrl, c, v[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (r + u * nrl < r1) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { s[e] += v[u][e]; ss[e] += v[u][e] * v[u][e]; }
+                    }
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) { sh_s[rl * C + c + e] = s[e]; sh_q[rl * C + c + e] = ss[e]; }
@@ -137,20 +145,27 @@ __global__ __launch_bounds__(512) void gn_apply_kernel(GroupNormArgs p) {
             const int g = (c + e) / cpg;
             ga[e] = p.gamma[c + e]; be[e] = p.beta[c + e]; mu[e] = mean[g]; rs[e] = rstd[g];
         }
-        for (int r = r0 + rl; r < r1; r += nrl) {
-            const size_t row = (size_t)b * p.HW + r;
-            float v[4], y[4];
-            load4<BF16IN>(p.x1, p.x2, p.C1, p.C2, row, c, v);
+        for (int r = r0 + rl; r < r1; r += 4 * nrl) {               // four rows in flight per thread (see gn_stats_kernel)
+            float v[4][4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                y[e] = (v[e] - mu[e]) * rs[e] * ga[e] + be[e];
-                if (p.silu) y[e] = y[e] / (1.f + __expf(-y[e]));
-            }
-            uint2 o; o.x = pack_bf16x2(y[0], y[1]); o.y = pack_bf16x2(y[2], y[3]);
-            *(uint2*)(p.out + row * C + c) = o;
-            if (p.raw_out) {
-                uint2 w; w.x = pack_bf16x2(v[0], v[1]); w.y = pack_bf16x2(v[2], v[3]);
-                *(uint2*)(p.raw_out + row * C + c) = w;
+            for (int u = 0; u < 4; ++u)
+                if (r + u * nrl < r1) load4<BF16IN>(p.x1, p.x2, p.C1, p.C2, (size_t)b * p.HW + r + u * nrl, c, v[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (r + u * nrl >= r1) continue;
+                const size_t row = (size_t)b * p.HW + r + u * nrl;
+                float y[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    y[e] = (v[u][e] - mu[e]) * rs[e] * ga[e] + be[e];
+                    if (p.silu) y[e] = y[e] / (1.f + __expf(-y[e]));
+                }
+                uint2 o; o.x = pack_bf16x2(y[0], y[1]); o.y = pack_bf16x2(y[2], y[3]);
+                *(uint2*)(p.out + row * C + c) = o;
+                if (p.raw_out) {
+                    uint2 w; w.x = pack_bf16x2(v[u][0], v[u][1]); w.y = pack_bf16x2(v[u][2], v[u][3]);
+                    *(uint2*)(p.raw_out + row * C + c) = w;
+                }
             }
         }
     }

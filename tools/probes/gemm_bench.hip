@@ -4,7 +4,7 @@
 #include <algorithm>
 #include <cstring>
 int main(int argc, char** argv) {
-    struct Shape { int M, N, K; } shapes[] = {{7168, 2560, 1280}, {28672, 1280, 640}, {7168, 10240, 1280}, {28672, 5120, 640}, {8192, 8192, 8192}};
+    struct Shape { int M, N, K; } shapes[] = {{7168, 2560, 1280}, {28672, 1280, 640}, {7168, 10240, 1280}, {28672, 5120, 640}, {7168, 1280, 1280}, {7168, 1280, 5120}, {4096, 4096, 4096}, {8192, 8192, 8192}};
     bf16_t *A, *W, *out, *zero;
     hipMalloc(&A, (size_t)28672 * 8192 * 2); hipMalloc(&W, (size_t)10240 * 8192 * 2); hipMalloc(&out, (size_t)28672 * 10240 * 2); hipMalloc(&zero, 256);
     // pseudo-random bf16 fill (values ~ +-1): data-dependent power/clock effects matter (guide 5.4 rule 25)
@@ -14,7 +14,25 @@ int main(int argc, char** argv) {
     hipMemset(zero, 0, 256);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float *resid, *bias; hipMalloc(&resid, (size_t)28672 * 1280 * 4); hipMemset(resid, 0, (size_t)28672 * 1280 * 4); hipMalloc(&bias, 10240 * 4); hipMemset(bias, 0, 10240 * 4);
-    {   // epilogue cost on the two FF shapes: GEGLU (erf) vs plain bf16, fp32+residual vs plain bf16
+    const bool quick = argc > 1 && !strcmp(argv[1], "q");      // "q": only the per-shape configuration table below
+    {   // GEGLU epilogue: the 16-wave kernel (cfg 3) against the 8-phase kernel (cfg 7), interleaved rounds
+        struct E { int M, N, K; } es[] = {{7168, 10240, 1280}, {28672, 5120, 640}};
+        for (auto e : es) {
+            printf("GEGLU %5dx%5dx%4d:", e.M, e.N, e.K);
+            for (int cfg : {3, 7, 3, 7}) {
+                GemmArgs g{}; g.A = A; g.W = W; g.out = out; g.zero = zero; g.mode = A_DENSE; g.epi = EPI_GEGLU; g.bias = bias;
+                g.M = e.M; g.N = e.N; g.K = e.K; g.lda = e.K; g.ldw = e.K; g.ldo = e.N / 2;
+                for (int r = 0; r < 3; ++r) launch_with_cfg(g, cfg, 0);
+                hipEventRecord(e0, 0);
+                for (int r = 0; r < 30; ++r) launch_with_cfg(g, cfg, 0);
+                hipEventRecord(e1, 0); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                printf("  cfg%d %6.1f us %5.0f TF", cfg, ms / 30 * 1e3, 2.0 * e.M * e.N * e.K / (ms / 30 * 1e-3) / 1e12);
+            }
+            printf("\n");
+        }
+    }
+    if (!quick) {   // epilogue cost on the two FF shapes: GEGLU (erf) vs plain bf16, fp32+residual vs plain bf16
         struct E { int M, N, K, epi, cfg; const char* name; } es[] = {{7168, 10240, 1280, EPI_BF16, 3, "geglu-shape bf16"}, {7168, 10240, 1280, EPI_GEGLU, 3, "geglu-shape GEGLU"},
             {28672, 5120, 640, EPI_BF16, 3, "geglu640 bf16"}, {28672, 5120, 640, EPI_GEGLU, 3, "geglu640 GEGLU"},
             {7168, 1280, 1280, EPI_BF16, 2, "out-shape bf16"}, {7168, 1280, 1280, EPI_F32, 2, "out-shape f32+res"}, {7168, 1280, 5120, EPI_F32, 2, "ff2 f32+res"}, {7168, 1280, 5120, EPI_F32, 6, "ff2 f32+res pp"}};
@@ -30,7 +48,7 @@ int main(int argc, char** argv) {
             printf("%-22s cfg%d %7.1f us\n", e.name, e.cfg, ms / 50 * 1e3);
         }
     }
-    {   // 3x3 convolutions: patch kernel vs the implicit-GEMM configuration 2
+    if (!quick) {   // 3x3 convolutions: patch kernel vs the implicit-GEMM configuration 2
         struct Cv { int B, H, W, Cin, Cout; } cs[] = {{7, 32, 32, 1280, 1280}, {7, 32, 32, 2560, 1280}, {7, 64, 64, 640, 640}, {7, 64, 64, 1920, 640}, {7, 128, 128, 320, 320}, {7, 128, 128, 960, 320}};
         for (auto c : cs) {
             GemmArgs g{}; g.A = A; g.W = W; g.out = out; g.zero = zero; g.mode = A_CONV3; g.epi = EPI_BF16; g.bias = bias;
@@ -49,9 +67,55 @@ int main(int argc, char** argv) {
             printf("\n");
         }
     }
+    {   // L2-channel test: the same problems with the operand rows padded by 128 B (row stride no longer a multiple of 2 KB)
+        struct Shape { int M, N, K, pad; } ps[] = {{8192, 4096, 4096, 0}, {8192, 4096, 4096, 64}, {8192, 4096, 4096, 192}, {7168, 1280, 1280, 0}, {7168, 1280, 1280, 64},
+                                                   {7168, 10240, 1280, 0}, {7168, 10240, 1280, 64}, {7168, 1280, 5120, 0}, {7168, 1280, 5120, 64}};
+        for (auto sh : ps) {
+            printf("pad %3d %5dx%5dx%4d:", sh.pad, sh.M, sh.N, sh.K);
+            for (int cfg : {2, 3, 7}) {
+                GemmArgs g{}; g.A = A; g.W = W; g.out = out; g.zero = zero; g.mode = A_DENSE; g.epi = EPI_BF16;
+                g.M = sh.M; g.N = sh.N; g.K = sh.K; g.lda = sh.K + sh.pad; g.ldw = sh.K + sh.pad; g.ldo = sh.N;
+                for (int r = 0; r < 3; ++r) launch_with_cfg(g, cfg, 0);
+                hipEventRecord(e0, 0);
+                for (int r = 0; r < 30; ++r) launch_with_cfg(g, cfg, 0);
+                hipEventRecord(e1, 0); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                printf("  cfg%d %6.1f us %5.0f TF", cfg, ms / 30 * 1e3, 2.0 * sh.M * sh.N * sh.K / (ms / 30 * 1e-3) / 1e12);
+            }
+            printf("\n");
+        }
+    }
+    {   // tile -> XCD mapping experiments on the 8-phase kernel: debug bit 0 = no XCD remap, bits 4.. = tile-row group height
+        struct Shape { int M, N, K; } ps[] = {{8192, 8192, 8192}, {7168, 10240, 1280}, {4096, 4096, 4096}};
+        for (auto sh : ps) {
+            printf("map %5dx%5dx%4d:", sh.M, sh.N, sh.K);
+            for (int dbg : {0, 1, 2 << 4, 8 << 4, 16 << 4, (16 << 4) | 1}) {
+                GemmArgs g{}; g.A = A; g.W = W; g.out = out; g.zero = zero; g.mode = A_DENSE; g.epi = EPI_BF16; g.debug = dbg;
+                g.M = sh.M; g.N = sh.N; g.K = sh.K; g.lda = sh.K; g.ldw = sh.K; g.ldo = sh.N;
+                for (int r = 0; r < 3; ++r) launch_with_cfg(g, 7, 0);
+                hipEventRecord(e0, 0);
+                for (int r = 0; r < 20; ++r) launch_with_cfg(g, 7, 0);
+                hipEventRecord(e1, 0); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                printf("  dbg%03x %6.1f us %5.0f TF", dbg, ms / 20 * 1e3, 2.0 * sh.M * sh.N * sh.K / (ms / 20 * 1e-3) / 1e12);
+            }
+            printf("\n");
+        }
+    }
+#ifdef RT_G8_TIMING
+    for (auto sh : shapes) {
+        GemmArgs g{}; g.A = A; g.W = W; g.out = out; g.zero = zero; g.mode = A_DENSE; g.epi = EPI_BF16;
+        g.M = sh.M; g.N = sh.N; g.K = sh.K; g.lda = sh.K; g.ldw = sh.K; g.ldo = sh.N;
+        launch_with_cfg(g, 7, 0); launch_with_cfg(g, 7, 0); hipDeviceSynchronize();
+        long long t[32]; hipMemcpyFromSymbol(t, HIP_SYMBOL(g_g8_times), sizeof(t));
+        const double nph = 4.0 * ((sh.K + 63) / 64);
+        printf("g8 timing %5dx%5dx%4d (cycles per phase):\n", sh.M, sh.N, sh.K);
+        for (int w : {0, 3, 4, 7}) printf("    wave %d: load section %6.0f | barrier-in %5.0f | lgkm+mfma %5.0f | barrier-out %5.0f\n", w, t[w * 4] / nph, t[w * 4 + 1] / nph, t[w * 4 + 2] / nph, t[w * 4 + 3] / nph);
+    }
+#endif
     for (auto sh : shapes) {
         printf("%5dx%5dx%4d:", sh.M, sh.N, sh.K);
-        for (int cfg : {2, 3, 6, 8}) {
+        for (int cfg : {2, 3, 6, 7}) {
             GemmArgs g{}; g.A = A; g.W = W; g.out = out; g.zero = zero; g.mode = A_DENSE; g.epi = EPI_BF16;
             g.M = sh.M; g.N = sh.N; g.K = sh.K; g.lda = sh.K; g.ldw = sh.K; g.ldo = sh.N;
             for (int r = 0; r < 3; ++r) launch_with_cfg(g, cfg, 0);
