@@ -74,6 +74,9 @@ struct GemmArgs {
     int rows_per_batch;              // Hout*Wout (conv and temb)
     int Hin, Win, Cin, Hout, Wout;   // conv geometry (Cin padded to a multiple of 8; K = 9*Cin)
     int debug;                       // unused by the product kernels (kept so probe builds can pass flags without changing the ABI of the struct)
+    int split_tiles;                 // 128x128 output tiles of ONE batch entry's share of the problem (0: unknown).  The split-K rule
+                                     // uses it instead of the actual tile count, so a stream's result does not depend on how many
+                                     // other streams share the launch (batch invariance); see splitk_slices in gemm.hip
 };
 void launch_gemm(const GemmArgs& a, hipStream_t st);
 void gemm_force_config(int cfg);

@@ -368,12 +368,15 @@ struct rt_engine {
 
     // ---------------------------------------------------------------------------- launch helpers
     bool dry() const { return ws.dry; }
+    int cur_hw = 0;              // tokens per stream of the block being executed (0 outside the UNet forward): the split-K rule of
+                                 // launch_gemm is keyed on ONE stream's share of a GEMM so that results are batch invariant
     void gemm(const bf16_t* A, int lda, const MatW& W, int M, void* out, int ldo, int epi, const float* res = nullptr,
               int ldres = 0, const float* temb = nullptr, int rows_per_batch = 0) {
         if (dry()) return;
         GemmArgs g{}; g.A = A; g.W = W.w; g.bias = W.b; g.out = out; g.res = res; g.temb = temb; g.zero = zero;
         g.mode = A_DENSE; g.epi = epi; g.M = M; g.N = W.N; g.K = W.K; g.lda = lda; g.ldw = W.K; g.ldo = ldo;
         g.ldres = ldres; g.temb_ld = W.N; g.rows_per_batch = rows_per_batch;
+        if (cur_hw > 0) g.split_tiles = cdiv(cur_hw, 128) * cdiv(W.N, 128);
         prof_begin(RT_PROF_GEMM_DENSE, 2.0 * M * W.N * W.K);
         launch_gemm(g, stream);
         prof_end();
@@ -383,6 +386,7 @@ struct rt_engine {
         if (dry()) return;
         GemmArgs g{}; g.A = Wv.w; g.W = X; g.bias = nullptr; g.out = out; g.zero = zero;
         g.mode = A_DENSE; g.epi = EPI_BF16; g.M = Wv.N; g.N = M; g.K = Wv.K; g.lda = Wv.K; g.ldw = ldx; g.ldo = ldo;
+        if (cur_hw > 0) g.split_tiles = cdiv(Wv.N, 128) * cdiv(cur_hw, 128);
         prof_begin(RT_PROF_GEMM_DENSE, 2.0 * M * Wv.N * Wv.K);
         launch_gemm(g, stream);
         prof_end();
@@ -397,6 +401,7 @@ struct rt_engine {
         g.mode = mode; g.epi = epi; g.M = B * Hout * Wout; g.N = W.N; g.K = W.K; g.lda = 0; g.ldw = W.K; g.ldo = W.N;
         g.ldres = W.N; g.temb_ld = W.N; g.rows_per_batch = Hout * Wout;
         g.Hin = Hin; g.Win = Win; g.Cin = CinP; g.Hout = Hout; g.Wout = Wout;
+        g.split_tiles = cdiv(Hout * Wout, 128) * cdiv(W.N, 128);
         RT_REQUIRE(W.K == 9 * CinP, "conv: weight/input channel mismatch");
         prof_begin(RT_PROF_GEMM_CONV, 2.0 * g.M * W.N * W.K);
         launch_gemm(g, stream);
@@ -424,6 +429,7 @@ struct rt_engine {
                   bool inject_here) {
         const int B = in.B, M = B * HW;
         const int c1 = x1.C, c2 = x2 ? x2->C : 0;
+        cur_hw = HW;
         RT_REQUIRE(c1 + c2 == r.cin, "resnet: input channel mismatch");
         float* out = ws.f32((size_t)M * r.cout);
         {
@@ -469,6 +475,7 @@ struct rt_engine {
     // Transformer2DModel.forward (models/transformer_2d.py:270-310) + BasicTransformerBlock (attention.py:131-206)
     Tensor transformer(TransformerP& t, const FwdIn& in, int HW, Tensor x) {
         const int B = in.B, M = B * HW, C = t.C, HD = t.heads * t.DP;
+        cur_hw = HW;
         RT_REQUIRE(x.C == C, "transformer: channel mismatch");
         RT_REQUIRE(HW % 8 == 0, "transformer: token count (h*w of the attention level) must be a multiple of 8");
         float* out = ws.f32((size_t)M * C);
@@ -637,6 +644,7 @@ struct rt_engine {
             conv3(hn, A_CONV3, conv_out, B, Hh, Ww, x.C, in.eps_out, EPI_F32);
         }
         ws.release(m0);
+        cur_hw = 0;
     }
 
     // ---------------------------------------------------------------------------- per-image setup

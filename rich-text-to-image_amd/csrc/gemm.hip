@@ -27,6 +27,7 @@
 // For convolutions the A operand is gathered on the fly from the NHWC bf16 activation (im2col never
 // materialised): K index = tap*Cin + c.
 #include "common.h"
+#include <algorithm>
 #include <map>
 #include <tuple>
 #include <type_traits>
@@ -272,8 +273,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
         fb_off[j] = BM * BK * 2 + rb * 128; fb_key[j] = (rb >> 1) & 7;
     }
 
-    const int nk = (p.K + BK - 1) / BK;
-#define KMAP(j) ((j) * BK)
+    // split-K (launch_gemm_splitk): blockIdx.y owns the K tiles [kt_first, kt_first + nk) and writes raw fp32 partial sums
+    const int nk_all = (p.K + BK - 1) / BK;
+    const int kt_first = gridDim.y > 1 ? (int)((long)blockIdx.y * nk_all / gridDim.y) : 0;
+    const int nk = gridDim.y > 1 ? (int)((long)(blockIdx.y + 1) * nk_all / gridDim.y) - kt_first : nk_all;
+#define KMAP(j) ((kt_first + (j)) * BK)
 #pragma unroll
     for (int s = 0; s < S - 1; ++s)
         if (s < nk) stage(s, KMAP(s), -1);
@@ -326,6 +330,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     for (; kt + 1 < nk; ++kt) ktile(kt, std::false_type{}, std::false_type{});
     for (; kt < nk; ++kt) ktile(kt, std::false_type{}, std::true_type{});
     __syncthreads();      // every wave is done with the LDS ring: it becomes the epilogue's transpose slabs
+    if (gridDim.y > 1) {
+        GemmArgs q = p;       // partial [split][M][ldo] fp32 (the launcher passes EPI_F32 without bias / residual)
+        q.out = (float*)p.out + (size_t)blockIdx.y * p.M * p.ldo;
+        gemm_epilogue<EPI, TM, TN, NW, S * STAGE>(q, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane, wave, smem);
+        return;
+    }
     gemm_epilogue<EPI, TM, TN, NW, S * STAGE>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane, wave, smem);
 }
 
@@ -733,11 +743,11 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
 
     const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM, nwg = ntm * ntn;
     int bid = blockIdx.x;
-    if (!(p.debug & 1)) {
+    {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int GRP = (p.debug >> 4) ? (p.debug >> 4) : 4;
+    constexpr int GRP = 4;      // (tile -> XCD mapping variants, GRP 2..16 and no remap, all measured within +-2 % on MI355X)
     const int gsz = GRP * ntn;
     const int first_m = (bid / gsz) * GRP;
     const int gm = (ntm - first_m) < GRP ? (ntm - first_m) : GRP;
@@ -1236,6 +1246,104 @@ static int pick_config(const GemmArgs& a, hipStream_t st) {
     return best;
 }
 
+// ---------------------------------------------------------------------------------------------- split-K for small problems
+// The deep levels of SD-v1.5 at 512^2 (16x16 and 8x8 maps, batch 3-5: M = 192 .. 1280 rows, K up to 23040) give a 128x128 tiling
+// 3 .. 100 workgroups with 180+ K tiles each: 200-350 us per convolution on a handful of CUs.  Those problems run as S K-slices of
+// the 128x128 configuration (raw fp32 partial sums) followed by one reduction kernel that sums the slices in ascending order and
+// applies the whole epilogue (bias, time embedding, residual, GEGLU, output type).  The rule depends on the problem shape only
+// (never on timing), so results are reproducible; they differ from the unsplit kernels by fp32 summation order.
+struct ReduceArgs {
+    const float* part; int S; size_t slice;       // S slices of `slice` floats, rows of ldp floats
+    int M, N, ldp;
+    int epi; const float* bias; const float* res; int ldres; const float* temb; int temb_ld, rows_per_batch;
+    void* out; int ldo;
+};
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(ReduceArgs p) {
+    const int NO = p.epi == EPI_GEGLU ? p.N >> 1 : p.N;              // output columns
+    const int nv = NO >> 2;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < (size_t)p.M * nv; idx += (size_t)gridDim.x * 256) {
+        const int row = (int)(idx / nv), oc = (int)(idx - (size_t)row * nv) * 4;
+        // GEGLU: output column oc lives in packed block (oc / 32): value columns 64*blk + (oc % 32), gate columns + 32
+        const int c0 = p.epi == EPI_GEGLU ? (oc >> 5) * 64 + (oc & 31) : oc;
+        float v[4] = {0, 0, 0, 0}, g[4] = {0, 0, 0, 0};
+        for (int s = 0; s < p.S; ++s) {
+            const float* src = p.part + (size_t)s * p.slice + (size_t)row * p.ldp + c0;
+            const float4 a = *(const float4*)src;
+            v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+            if (p.epi == EPI_GEGLU) { const float4 b = *(const float4*)(src + 32); g[0] += b.x; g[1] += b.y; g[2] += b.z; g[3] += b.w; }
+        }
+        if (p.bias) {
+            const float4 b = *(const float4*)(p.bias + c0); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+            if (p.epi == EPI_GEGLU) { const float4 b2 = *(const float4*)(p.bias + c0 + 32); g[0] += b2.x; g[1] += b2.y; g[2] += b2.z; g[3] += b2.w; }
+        }
+        if (p.epi == EPI_GEGLU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= gelu_erf(g[e]);
+        } else if (p.epi == EPI_BF16_TEMB) {
+            const float4 t = *(const float4*)(p.temb + (size_t)(row / p.rows_per_batch) * p.temb_ld + oc);
+            v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+        }
+        if (p.epi == EPI_F32) {
+            if (p.res) { const float4 r = *(const float4*)(p.res + (size_t)row * p.ldres + oc); v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
+            *(float4*)((float*)p.out + (size_t)row * p.ldo + oc) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            uint2 w; w.x = pack_bf16x2(v[0], v[1]); w.y = pack_bf16x2(v[2], v[3]);
+            *(uint2*)((bf16_t*)p.out + (size_t)row * p.ldo + oc) = w;
+        }
+    }
+}
+
+// number of K slices for a problem (1 = do not split).  Shape-only rule.
+static int splitk_slices(const GemmArgs& a) {
+    // callers that batch independent streams pass the tile count of ONE stream; the rule then assumes a nominal batch of four
+    // streams whatever the real batch is, so every stream sees the same K slicing alone or in any batch
+    const long tiles = a.split_tiles > 0 ? 4L * a.split_tiles : (long)cdiv(a.M, 128) * cdiv(a.N, 128);
+    const int nk = cdiv(a.K, BK);
+    if (tiles > 96 || nk < 8) return 1;
+    int s = (int)(256 / tiles); if (s > 16) s = 16;
+    if (s > nk / 4) s = nk / 4;
+    return s < 2 ? 1 : s;
+}
+
+static void launch_gemm_splitk(const GemmArgs& a, int S, hipStream_t st) {
+    static thread_local float* buf = nullptr;
+    static thread_local size_t buf_floats = 0;
+    const int ldp = (a.N + 3) & ~3;
+    const size_t slice = (size_t)a.M * ldp, need = slice * S;
+    if (need > buf_floats) {                                         // grows during warm-up only
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (buf) (void)hipFree(buf);
+        HIP_CHECK(hipMalloc((void**)&buf, need * 4));
+        buf_floats = need;
+    }
+    GemmArgs g = a;
+    g.epi = EPI_F32; g.bias = nullptr; g.res = nullptr; g.temb = nullptr; g.out = buf; g.ldo = ldp;
+    {
+        constexpr int BM = 128, BN = 128, SS = 2;
+        const size_t lds = (size_t)SS * (BM + BN) * BK * 2;
+        dim3 grid(cdiv(a.M, BM) * cdiv(a.N, BN), S), block(256);
+#define RT_SPLIT_LAUNCH(MODE_)                                                                                                    \
+        {                                                                                                                         \
+            static bool attr = false;                                                                                             \
+            if (!attr) { HIP_CHECK(hipFuncSetAttribute((const void*)gemm_kernel<MODE_, EPI_F32, BM, BN, 2, 2, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; } \
+            hipLaunchKernelGGL((gemm_kernel<MODE_, EPI_F32, BM, BN, 2, 2, SS>), grid, block, lds, st, g);                         \
+        }
+        switch (a.mode) {
+            case A_DENSE: RT_SPLIT_LAUNCH(A_DENSE) break;
+            case A_CONV3: RT_SPLIT_LAUNCH(A_CONV3) break;
+            case A_CONV3_S2: RT_SPLIT_LAUNCH(A_CONV3_S2) break;
+            default: RT_SPLIT_LAUNCH(A_CONV3_UP2) break;
+        }
+#undef RT_SPLIT_LAUNCH
+    }
+    ReduceArgs r{};
+    r.part = buf; r.S = S; r.slice = slice; r.M = a.M; r.N = a.N; r.ldp = ldp; r.epi = a.epi; r.bias = a.bias; r.res = a.res; r.ldres = a.ldres;
+    r.temb = a.temb; r.temb_ld = a.temb_ld; r.rows_per_batch = a.rows_per_batch; r.out = a.out; r.ldo = a.ldo;
+    const size_t work = (size_t)a.M * ((a.epi == EPI_GEGLU ? a.N / 2 : a.N) / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<size_t>(cdiv((int)std::min<size_t>(work, 1u << 30), 256), 2048)), dim3(256), 0, st, r);
+    HIP_CHECK(hipGetLastError());
+}
+
 void launch_gemm(const GemmArgs& a, hipStream_t st) {
     RT_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem");
     RT_REQUIRE(a.K % 8 == 0 && a.ldw % 8 == 0, "gemm: K and ldw must be multiples of 8");
@@ -1256,7 +1364,12 @@ void launch_gemm(const GemmArgs& a, hipStream_t st) {
     if (a.bias) RT_REQUIRE(((uintptr_t)a.bias & 15) == 0, "gemm: bias must be 16-B aligned");
     if (a.temb) RT_REQUIRE(a.temb_ld % 4 == 0 && ((uintptr_t)a.temb & 15) == 0, "gemm: temb must be 16-B aligned");
     // In-place residual (out == res) is safe: every element is read and written by the same thread.
-    if (conv_patch_eligible(a)) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cap);
+    const int ksl = (g_force_cfg < 0 && cap == hipStreamCaptureStatusNone) ? splitk_slices(a) : 1;
+    // patch convolutions that cannot fill the chip (< 128 workgroups) go through the split-K implicit GEMM as well
+    const bool patch_underfilled = ksl > 1 && a.mode != A_DENSE;
+    if (conv_patch_eligible(a) && !patch_underfilled) {
         if (a.mode == A_CONV3_UP2) launch_conv3p<EPI_F32, true>(a, st);
         else switch (a.epi) {
             case EPI_BF16: launch_conv3p<EPI_BF16, false>(a, st); break;
@@ -1265,6 +1378,7 @@ void launch_gemm(const GemmArgs& a, hipStream_t st) {
         }
         return;
     }
+    if (ksl > 1) { launch_gemm_splitk(a, ksl, st); return; }
     const int cfg = pick_config(a, st);
     launch_with_cfg(a, cfg, st);
 }

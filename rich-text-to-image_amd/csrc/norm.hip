@@ -119,11 +119,33 @@ void launch_gn_finalize(float* partial, int B, int nchunk, int G, double n, floa
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, B), dim3(256), 0, st, partial, nchunk, G, n, eps, mode);
 }
 
-// grid (nchunk, B); reads the finalized (mean, rstd) of partial[b][0][g]
-template <bool BF16IN>
+// grid (nchunk, B); reads the finalized (mean, rstd) of partial[b][0][g].  A thread owns VW = 8 consecutive channels (two 16-B
+// loads, one 16-B store per output: the 4-channel form spent its time issuing 8-B stores, 3.0 TB/s) or 4 when the channel counts
+// are not multiples of 8.
+template <bool BF16IN, int VW>
+__device__ __forceinline__ void loadv(const void* x1, const void* x2, int C1, int C2, size_t row, int c, float (&v)[VW]) {
+#pragma unroll
+    for (int h = 0; h < VW / 4; ++h) {
+        float t[4];
+        load4<BF16IN>(x1, x2, C1, C2, row, c + 4 * h, t);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * h + e] = t[e];
+    }
+}
+template <int VW>
+__device__ __forceinline__ void storev(bf16_t* dst, const float (&y)[VW]) {
+    if constexpr (VW == 8) {
+        uint4 o; o.x = pack_bf16x2(y[0], y[1]); o.y = pack_bf16x2(y[2], y[3]); o.z = pack_bf16x2(y[4], y[5]); o.w = pack_bf16x2(y[6], y[7]);
+        *(uint4*)dst = o;
+    } else {
+        uint2 o; o.x = pack_bf16x2(y[0], y[1]); o.y = pack_bf16x2(y[2], y[3]);
+        *(uint2*)dst = o;
+    }
+}
+template <bool BF16IN, int VW>
 __global__ __launch_bounds__(512) void gn_apply_kernel(GroupNormArgs p) {
     __shared__ float mean[32], rstd[32];
-    const int C = p.C1 + p.C2, cpg = C / p.G, nv = C >> 2;
+    const int C = p.C1 + p.C2, cpg = C / p.G, nv = C / VW;
     const int b = blockIdx.y, chunk = blockIdx.x;
     if (threadIdx.x < p.G) {
         mean[threadIdx.x] = p.partial[(size_t)b * p.nchunk * 2 * p.G + 2 * threadIdx.x];
@@ -138,34 +160,30 @@ __global__ __launch_bounds__(512) void gn_apply_kernel(GroupNormArgs p) {
     const int v0 = threadIdx.x - rl * tcols;
     if (rl >= nrl) return;
     for (int vec = v0; vec < nv; vec += tcols) {
-        const int c = vec * 4;
-        float ga[4], be[4], mu[4], rs[4];
+        const int c = vec * VW;
+        float ga[VW], be[VW], mu[VW], rs[VW];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < VW; ++e) {
             const int g = (c + e) / cpg;
             ga[e] = p.gamma[c + e]; be[e] = p.beta[c + e]; mu[e] = mean[g]; rs[e] = rstd[g];
         }
-        for (int r = r0 + rl; r < r1; r += 4 * nrl) {               // four rows in flight per thread (see gn_stats_kernel)
-            float v[4][4];
+        for (int r = r0 + rl; r < r1; r += 2 * nrl) {               // two rows in flight per thread
+            float v[2][VW];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (r + u * nrl < r1) load4<BF16IN>(p.x1, p.x2, p.C1, p.C2, (size_t)b * p.HW + r + u * nrl, c, v[u]);
+            for (int u = 0; u < 2; ++u)
+                if (r + u * nrl < r1) loadv<BF16IN, VW>(p.x1, p.x2, p.C1, p.C2, (size_t)b * p.HW + r + u * nrl, c, v[u]);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 2; ++u) {
                 if (r + u * nrl >= r1) continue;
                 const size_t row = (size_t)b * p.HW + r + u * nrl;
-                float y[4];
+                float y[VW];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < VW; ++e) {
                     y[e] = (v[u][e] - mu[e]) * rs[e] * ga[e] + be[e];
                     if (p.silu) y[e] = y[e] / (1.f + __expf(-y[e]));
                 }
-                uint2 o; o.x = pack_bf16x2(y[0], y[1]); o.y = pack_bf16x2(y[2], y[3]);
-                *(uint2*)(p.out + row * C + c) = o;
-                if (p.raw_out) {
-                    uint2 w; w.x = pack_bf16x2(v[u][0], v[u][1]); w.y = pack_bf16x2(v[u][2], v[u][3]);
-                    *(uint2*)(p.raw_out + row * C + c) = w;
-                }
+                storev<VW>(p.out + row * C + c, y);
+                if (p.raw_out) storev<VW>(p.raw_out + row * C + c, v[u]);
             }
         }
     }
@@ -182,20 +200,27 @@ void launch_groupnorm(const GroupNormArgs& a, hipStream_t st) {
     RT_REQUIRE(shp.nrl * C <= GN_MAXC || shp.nrl == 1, "groupnorm: LDS staging too small");
     dim3 grid(a.nchunk, a.B), block(shp.tcols * shp.nrl);
     const double n = (double)(C / a.G) * a.HW;
+    const bool wide = a.C1 % 8 == 0 && a.C2 % 8 == 0;               // 8 channels per thread in the apply pass
+    const GnShape sh8 = gn_block_shape(C >> 3);
+    dim3 block8(sh8.tcols * sh8.nrl);
     if (a.in_bf16) {
         hipLaunchKernelGGL(gn_stats_kernel<true>, grid, block, 0, st, a);
         launch_gn_finalize(a.partial, a.B, a.nchunk, a.G, n, a.eps, 0, st);
-        hipLaunchKernelGGL(gn_apply_kernel<true>, grid, block, 0, st, a);
+        if (wide) hipLaunchKernelGGL((gn_apply_kernel<true, 8>), grid, block8, 0, st, a);
+        else hipLaunchKernelGGL((gn_apply_kernel<true, 4>), grid, block, 0, st, a);
     } else {
         hipLaunchKernelGGL(gn_stats_kernel<false>, grid, block, 0, st, a);
         launch_gn_finalize(a.partial, a.B, a.nchunk, a.G, n, a.eps, 0, st);
-        hipLaunchKernelGGL(gn_apply_kernel<false>, grid, block, 0, st, a);
+        if (wide) hipLaunchKernelGGL((gn_apply_kernel<false, 8>), grid, block8, 0, st, a);
+        else hipLaunchKernelGGL((gn_apply_kernel<false, 4>), grid, block, 0, st, a);
     }
     HIP_CHECK(hipGetLastError());
 }
 
 // ---------------------------------------------------------------- LayerNorm: one wave per row
-#define LN_MAXV 5   // C <= 1280 (float4 per lane per 256 channels)
+// A lane owns 8 consecutive channels per 512-channel pass: two 16-B loads, ONE 16-B store (with 4 channels per lane the kernel sat
+// at 4.0 TB/s, bound by the number of 8-B store instructions: guide T21).
+#define LN_MAXP 3   // C <= 1536 (8 channels per lane per 512-channel pass)
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, bf16_t* __restrict__ out,
                                                         int rows, int C, float eps) {
@@ -203,44 +228,54 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* xr = x + (size_t)row * C;
-    float4 v[LN_MAXV];
+    float4 v[LN_MAXP][2];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int c = i * 256 + lane * 4;
-        if (c < C) { v[i] = *(const float4*)(xr + c); s += v[i].x + v[i].y + v[i].z + v[i].w; }
+    for (int i = 0; i < LN_MAXP; ++i) {
+        const int c = i * 512 + lane * 8;
+        if (c < C) {
+            v[i][0] = *(const float4*)(xr + c); v[i][1] = *(const float4*)(xr + c + 4);
+            s += (v[i][0].x + v[i][0].y + v[i][0].z + v[i][0].w) + (v[i][1].x + v[i][1].y + v[i][1].z + v[i][1].w);
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     const float mu = s / C;
     float ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int c = i * 256 + lane * 4;
+    for (int i = 0; i < LN_MAXP; ++i) {
+        const int c = i * 512 + lane * 8;
         if (c < C) {
-            const float a = v[i].x - mu, b = v[i].y - mu, d = v[i].z - mu, e = v[i].w - mu;
-            ss += a * a + b * b + d * d + e * e;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float a = v[i][h].x - mu, b = v[i][h].y - mu, d = v[i][h].z - mu, e = v[i][h].w - mu;
+                ss += a * a + b * b + d * d + e * e;
+            }
         }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
     const float rs = rsqrtf(ss / C + eps);
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int c = i * 256 + lane * 4;
+    for (int i = 0; i < LN_MAXP; ++i) {
+        const int c = i * 512 + lane * 8;
         if (c < C) {
-            const float4 g = *(const float4*)(gamma + c), bb = *(const float4*)(beta + c);
-            uint2 o;
-            o.x = pack_bf16x2((v[i].x - mu) * rs * g.x + bb.x, (v[i].y - mu) * rs * g.y + bb.y);
-            o.y = pack_bf16x2((v[i].z - mu) * rs * g.z + bb.z, (v[i].w - mu) * rs * g.w + bb.w);
-            *(uint2*)(out + (size_t)row * C + c) = o;
+            uint4 o;
+            uint32_t* ow = (uint32_t*)&o;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float4 g = *(const float4*)(gamma + c + 4 * h), bb = *(const float4*)(beta + c + 4 * h);
+                ow[2 * h] = pack_bf16x2((v[i][h].x - mu) * rs * g.x + bb.x, (v[i][h].y - mu) * rs * g.y + bb.y);
+                ow[2 * h + 1] = pack_bf16x2((v[i][h].z - mu) * rs * g.z + bb.z, (v[i][h].w - mu) * rs * g.w + bb.w);
+            }
+            *(uint4*)(out + (size_t)row * C + c) = o;
         }
     }
 }
 
 void launch_layernorm(const float* x, const float* gamma, const float* beta, bf16_t* out, int rows, int C,
                       float eps, hipStream_t st) {
-    RT_REQUIRE(C % 4 == 0 && C <= LN_MAXV * 256, "layernorm: C must be a multiple of 4 and <= 1280");
+    RT_REQUIRE(C % 8 == 0 && C <= LN_MAXP * 512, "layernorm: C must be a multiple of 8 and <= 1536");
     hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, gamma, beta, out, rows, C, eps);
     HIP_CHECK(hipGetLastError());
 }

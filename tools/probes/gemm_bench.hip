@@ -85,23 +85,6 @@ int main(int argc, char** argv) {
             printf("\n");
         }
     }
-    {   // tile -> XCD mapping experiments on the 8-phase kernel: debug bit 0 = no XCD remap, bits 4.. = tile-row group height
-        struct Shape { int M, N, K; } ps[] = {{8192, 8192, 8192}, {7168, 10240, 1280}, {4096, 4096, 4096}};
-        for (auto sh : ps) {
-            printf("map %5dx%5dx%4d:", sh.M, sh.N, sh.K);
-            for (int dbg : {0, 1, 2 << 4, 8 << 4, 16 << 4, (16 << 4) | 1}) {
-                GemmArgs g{}; g.A = A; g.W = W; g.out = out; g.zero = zero; g.mode = A_DENSE; g.epi = EPI_BF16; g.debug = dbg;
-                g.M = sh.M; g.N = sh.N; g.K = sh.K; g.lda = sh.K; g.ldw = sh.K; g.ldo = sh.N;
-                for (int r = 0; r < 3; ++r) launch_with_cfg(g, 7, 0);
-                hipEventRecord(e0, 0);
-                for (int r = 0; r < 20; ++r) launch_with_cfg(g, 7, 0);
-                hipEventRecord(e1, 0); hipEventSynchronize(e1);
-                float ms; hipEventElapsedTime(&ms, e0, e1);
-                printf("  dbg%03x %6.1f us %5.0f TF", dbg, ms / 20 * 1e3, 2.0 * sh.M * sh.N * sh.K / (ms / 20 * 1e-3) / 1e12);
-            }
-            printf("\n");
-        }
-    }
 #ifdef RT_G8_TIMING
     for (auto sh : shapes) {
         GemmArgs g{}; g.A = A; g.W = W; g.out = out; g.zero = zero; g.mode = A_DENSE; g.epi = EPI_BF16;

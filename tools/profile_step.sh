@@ -12,3 +12,4 @@ DB=$(ls $OUT/*.db | head -1)
 python $ROOT/tools/rocpd_summary.py $DB $ROOT/gpurun_out/${TAG}_kernel_stats.csv > /dev/null
 python $ROOT/tools/gap_analysis.py $DB 0.45 0.7 > $ROOT/gpurun_out/${TAG}_steady_state_kernels.txt
 cat $ROOT/gpurun_out/${TAG}_steady_state_kernels.txt
+cp $OUT/bench.json $ROOT/gpurun_out/${TAG}_bench.json; rm -rf $OUT      # the rocpd database is tens of MB: keep the summaries only
