@@ -126,6 +126,60 @@ void launch_small_linear(const float* a, int lda, const bf16_t* W, int ldw, cons
     HIP_CHECK(hipGetLastError());
 }
 
+// ---------------------------------------------------------------- every resnet's time_emb_proj(silu(emb)) in one launch
+// ResnetBlock2D computes temb = time_emb_proj(silu(emb)) (models/resnet.py:611-613) from the SAME emb in all 22 (SDXL) resnets of a
+// forward: one launch at the start of the forward walks a table of projections (one wave per output feature; bf16 weights; the
+// activation silu(emb) is formed once per lane, not once per output feature as in small_linear_kernel).
+__global__ __launch_bounds__(256) void temb_all_kernel(const float* __restrict__ emb, int lde, const TembEntry* __restrict__ tab, int ntab,
+                                                       int total, int B, int K, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int f = blockIdx.x * 4 + (threadIdx.x >> 6);              // global output feature
+    if (f >= total) return;
+    int t = 0;
+    while (t + 1 < ntab && f >= tab[t + 1].first) ++t;
+    const TembEntry e = tab[t];
+    const int n = f - e.first;
+    float acc[RT_MAXB];
+#pragma unroll
+    for (int b = 0; b < RT_MAXB; ++b) acc[b] = 0.f;
+    for (int k = lane * 8; k < K; k += 512) {
+        const uint4 wv = *(const uint4*)(e.W + (size_t)n * K + k);
+        float w[8];
+        w[0] = __uint_as_float(wv.x << 16); w[1] = __uint_as_float(wv.x & 0xffff0000u);
+        w[2] = __uint_as_float(wv.y << 16); w[3] = __uint_as_float(wv.y & 0xffff0000u);
+        w[4] = __uint_as_float(wv.z << 16); w[5] = __uint_as_float(wv.z & 0xffff0000u);
+        w[6] = __uint_as_float(wv.w << 16); w[7] = __uint_as_float(wv.w & 0xffff0000u);
+#pragma unroll
+        for (int b = 0; b < RT_MAXB; ++b) {
+            if (b < B) {
+                const float4 x0 = *(const float4*)(emb + (size_t)b * lde + k);          // emb already holds silu(emb)
+                const float4 x1 = *(const float4*)(emb + (size_t)b * lde + k + 4);
+                acc[b] += x0.x * w[0] + x0.y * w[1] + x0.z * w[2] + x0.w * w[3] + x1.x * w[4] + x1.y * w[5] + x1.z * w[6] + x1.w * w[7];
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < RT_MAXB; ++b) {
+        if (b < B) {
+            float s = acc[b];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if (lane == 0) out[(size_t)e.out_off + (size_t)b * e.N + n] = s + e.bias[n];
+        }
+    }
+}
+__global__ void silu_kernel(const float* __restrict__ x, float* __restrict__ y, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const float v = x[i]; y[i] = v / (1.f + __expf(-v)); }
+}
+void launch_temb_all(const float* emb, int lde, float* silu_scratch, const TembEntry* tab, int ntab, int total, int B, int K, float* out,
+                     hipStream_t st) {
+    RT_REQUIRE(B >= 1 && B <= RT_MAXB && K % 8 == 0 && lde == K, "temb_all: bad shape");
+    hipLaunchKernelGGL(silu_kernel, dim3(cdiv(B * K, 256)), dim3(256), 0, st, emb, silu_scratch, B * K);
+    hipLaunchKernelGGL(temb_all_kernel, dim3(cdiv(total, 4)), dim3(256), 0, st, silu_scratch, lde, tab, ntab, total, B, K, out);
+    HIP_CHECK(hipGetLastError());
+}
+
 // ---------------------------------------------------------------- latents NCHW f32 -> NHWC bf16 (8 channels)
 __global__ void prep_latents_kernel(PrepArgs p) {
     const int b = blockIdx.y;

@@ -67,6 +67,7 @@ struct MatW { bf16_t* w = nullptr; float* b = nullptr; int N = 0, K = 0; };   //
 struct ResnetP {
     std::string name;
     int cin = 0, cout = 0;
+    int temb_first = 0;          // prefix sum of cout over the resnets before this one (index into the per-forward temb buffer)
     NormW n1, n2;
     MatW c1, c2, temb, sc;
     bool has_sc = false;
@@ -157,6 +158,12 @@ struct rt_engine {
     ResnetP mid_r0, mid_r1;
     TransformerP mid_t;
     int temb_dim = 0;
+    // every resnet's time_emb_proj(silu(emb)) is computed by ONE launch at the start of a forward (launch_temb_all)
+    std::vector<TembEntry> temb_tab;
+    int temb_total = 0;
+    TembEntry* temb_tab_dev = nullptr;
+    int temb_tab_B = -1;             // batch size the device table's out offsets were built for
+    float* temb_all = nullptr;       // [resnet][B][cout] of the running forward
 
     // per-image state
     int n_prompts = 0;
@@ -245,6 +252,8 @@ struct rt_engine {
         r.c2 = mk_conv3(name + ".conv2", cout, cout);
         r.has_sc = cin != cout;
         if (r.has_sc) r.sc = mk_linear(name + ".conv_shortcut", cin, cout, true, true);
+        r.temb_first = temb_total; temb_total += cout;
+        temb_tab.push_back(TembEntry{r.temb.w, r.temb.b, cout, r.temb_first, 0});
         return r;
     }
     // q/k/v projection with head padding d -> DP on the output rows
@@ -310,7 +319,7 @@ struct rt_engine {
     }
 
     void build_plan() {
-        slots.clear(); slot_index.clear(); down.clear(); up.clear();
+        slots.clear(); slot_index.clear(); down.clear(); up.clear(); temb_tab.clear(); temb_total = 0; temb_tab_B = -1;
         const int L = cfg.n_levels;
         const int* boc = cfg.block_out_channels;
         temb_dim = boc[0] * 4;
@@ -437,8 +446,7 @@ struct rt_engine {
             bf16_t* h1 = ws.b16((size_t)M * r.cin);
             bf16_t* raw = r.has_sc ? ws.b16((size_t)M * r.cin) : nullptr;
             groupnorm(x1.p, x2 ? x2->p : nullptr, false, c1, c2, B, HW, r.n1, cfg.norm_eps, true, h1, raw);
-            float* tp = ws.f32((size_t)B * r.cout);
-            if (!dry()) launch_small_linear(emb, temb_dim, r.temb.w, r.temb.K, r.temb.b, tp, r.cout, B, r.cout, temb_dim, 1, 0, stream);
+            const float* tp = temb_all + (size_t)B * r.temb_first;        // computed for all resnets at the start of the forward
             // rich-text feature injection (resnet.py:639-643): out[b] = shortcut(x[b]) + hidden[res_src[b]].  The residual branch
             // (conv1 / norm2 / conv2) of an injected stream is never used, so the trailing run of injected streams is not computed
             // at all (the region streams of a rich-text step are the last ones): Bk streams keep their branch.
@@ -575,6 +583,23 @@ struct rt_engine {
                 launch_small_linear(tsin, cfg.block_out_channels[0], t1.w, t1.K, t1.b, e1, temb_dim, 1, temb_dim, t1.K, 0, 0, stream);
                 launch_small_linear(e1, temb_dim, t2.w, t2.K, t2.b, e2, temb_dim, 1, temb_dim, temb_dim, 1, 0, stream);
                 launch_gather_add_rows(e2, aug_emb, in.prompt, emb, B, temb_dim, stream);
+            }
+        }
+        // time_emb_proj(silu(emb)) of every resnet (resnet.py:611-613): one launch, buffer lives for the whole forward
+        temb_all = ws.f32((size_t)B * temb_total);
+        {
+            Scope sc(ws);
+            float* semb = ws.f32((size_t)B * temb_dim);
+            if (!dry()) {
+                if (temb_tab_B != B) {                                   // out offsets depend on the batch size: rebuild the small table
+                    std::vector<TembEntry> t = temb_tab;
+                    for (auto& e : t) e.out_off = (long)B * e.first;
+                    if (!temb_tab_dev) HIP_CHECK(hipMalloc((void**)&temb_tab_dev, t.size() * sizeof(TembEntry)));
+                    HIP_CHECK(hipMemcpyAsync(temb_tab_dev, t.data(), t.size() * sizeof(TembEntry), hipMemcpyHostToDevice, stream));
+                    HIP_CHECK(hipStreamSynchronize(stream));             // `t` is a stack vector
+                    temb_tab_B = B;
+                }
+                launch_temb_all(emb, temb_dim, semb, temb_tab_dev, (int)temb_tab.size(), temb_total, B, temb_dim, temb_all, stream);
             }
         }
         std::vector<Tensor> skips;
@@ -821,7 +846,7 @@ int rt_destroy(rt_engine* e) {
     if (e->arena_base) {
         (void)hipSetDevice(e->device); (void)hipStreamSynchronize(e->stream);
         for (auto& r : e->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
-        (void)hipFree(e->arena_base); (void)hipFree(e->sarena_base); (void)hipFree(e->ws.base); (void)hipStreamDestroy(e->stream);
+        (void)hipFree(e->arena_base); (void)hipFree(e->sarena_base); (void)hipFree(e->ws.base); (void)hipFree(e->temb_tab_dev); (void)hipStreamDestroy(e->stream);
     }
     delete e;
     return RT_OK;

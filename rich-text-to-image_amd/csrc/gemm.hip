@@ -1148,6 +1148,8 @@ static void launch_me(const GemmArgs& a, int cfg, hipStream_t st) {
 #ifdef RT_PROBE
         case 8: launch_cfg<MODE, EPI, 256, 256, 2, 4, 2>(a, st); break;      // 8 waves, 128x64 per wave (ties cfg 3)
         case 9: launch_cfg<MODE, EPI, 256, 320, 4, 2, 2>(a, st); break;      // 64x160 per wave, 142 flop/B through the copy path
+        case 10: launch_cfg<MODE, EPI, 128, 160, 4, 1, 2>(a, st); break;     // two workgroups per CU: pro/epilogues overlap the partner's loop
+        case 11: launch_cfg<MODE, EPI, 128, 160, 4, 1, 3>(a, st); break;
 #endif
         default: throw rt_error(RT_E_INVALID, "gemm: bad tile configuration");
     }

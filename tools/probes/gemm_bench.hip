@@ -98,7 +98,7 @@ int main(int argc, char** argv) {
 #endif
     for (auto sh : shapes) {
         printf("%5dx%5dx%4d:", sh.M, sh.N, sh.K);
-        for (int cfg : {2, 3, 6, 7}) {
+        for (int cfg : {2, 3, 6, 7, 10, 11}) {
             GemmArgs g{}; g.A = A; g.W = W; g.out = out; g.zero = zero; g.mode = A_DENSE; g.epi = EPI_BF16;
             g.M = sh.M; g.N = sh.N; g.K = sh.K; g.lda = sh.K; g.ldw = sh.K; g.ldo = sh.N;
             for (int r = 0; r < 3; ++r) launch_with_cfg(g, cfg, 0);
