@@ -129,18 +129,23 @@ int rt_unet_forward(rt_engine* e, const float* x, int B, int h, int w, float tim
                     const int* prompt_idx_host, const int* fontsize_host, const int* qk_src_host,
                     const int* res_src_host, float* out);
 
-int rt_op_gemm(const void* A, const void* W, const float* bias, void* out, const float* res, const float* temb,
+/* epi: 0 bf16 out | 1 fp32 out (+ fp32 residual) | 2 bf16 out + per-batch-entry time embedding | 3 GEGLU (bf16 out, N/2 columns)
+ *      | 4 fp16 out (+ fp16 residual): the UNet's residual trunk (fp32 arithmetic in the epilogue, fp16 in HBM like the reference's
+ *        fp16 pipelines).  `res` is fp32 for epi 1 and fp16 for epi 4. */
+int rt_op_gemm(const void* A, const void* W, const float* bias, void* out, const void* res, const float* temb,
                int mode, int epi, int M, int N, int K, int lda, int ldw, int ldo, int ldres, int temb_ld,
                int rows_per_batch, int Hin, int Win, int Cin, int Hout, int Wout, void* stream);
 int rt_op_attention(const void* Q, int ldq, const void* K, int ldk, const void* VT, int ldvt, void* O, int ldo,
                     const int* q_src_host, const int* k_src_host, const int* v_src_host, const int* wset_host,
                     const float* wabs, const float* wsgn, int B, int H, int N, int NK, int nk_valid, int DP, int cross,
                     void* stream);
-int rt_op_groupnorm(const void* x1, const void* x2, int in_bf16, int C1, int C2, int G, int B, int HW,
+/* in_type: 0 fp32, 1 bf16 (x2 must be NULL), 2 fp16 - the element type of x1 / x2 (the UNet trunk is fp16) */
+int rt_op_groupnorm(const void* x1, const void* x2, int in_type, int C1, int C2, int G, int B, int HW,
                     const float* gamma, const float* beta, float eps, int silu, void* out_bf16, void* raw_out_bf16,
                     void* stream);
 int rt_op_layernorm(const float* x, const float* gamma, const float* beta, void* out_bf16, int rows, int C, float eps,
                     void* stream);
+int rt_op_layernorm_f16(const void* x_f16, const float* gamma, const float* beta, void* out_bf16, int rows, int C, float eps, void* stream);
 int rt_op_small_linear(const float* a, int lda, const void* W_bf16, int ldw, const float* bias, float* out, int ldo,
                        int B, int N, int K, int silu_in, int accumulate, void* stream);
 int rt_op_timestep_embed(const float* t, int n, int dim, float* out, int ldo, void* stream);

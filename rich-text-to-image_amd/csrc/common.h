@@ -58,14 +58,15 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 
 // ---------------------------------------------------------------- GEMM / implicit-GEMM conv
 enum { A_DENSE = 0, A_CONV3 = 1, A_CONV3_S2 = 2, A_CONV3_UP2 = 3 };
-enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_BF16_TEMB = 2, EPI_GEGLU = 3 };
+enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_BF16_TEMB = 2, EPI_GEGLU = 3, EPI_F16 = 4 };   // EPI_F16: fp16 output (+ fp16 residual): the UNet trunk
+typedef _Float16 f16_t;
 
 struct GemmArgs {
     const bf16_t* A;   // dense: [M, lda]; conv: NHWC input [B, Hin, Win, Cin]
     const bf16_t* W;   // [N, ldw] (K contiguous)
     const float* bias; // [N] or null
     void* out;         // bf16 or f32, [M, ldo]
-    const float* res;  // EPI_F32: optional residual [M, ldres]
+    const void* res;   // optional residual [M, ldres]: fp32 for EPI_F32, fp16 for EPI_F16
     const float* temb; // EPI_BF16_TEMB: [B, temb_ld]
     const bf16_t* zero; // >= 16 B of zeros
     int mode, epi;
@@ -114,7 +115,7 @@ void launch_attn_store(const AttnStoreArgs& a, hipStream_t st);
 // ---------------------------------------------------------------- norms / elementwise
 struct GroupNormArgs {
     const void* x1; const void* x2;   // x2 may be null; virtual concat along channels [C1 | C2]
-    int in_bf16;                       // 0: fp32 inputs, 1: bf16 input (x2 must be null)
+    int in_bf16;                       // input element type: 0 fp32, 1 bf16 (x2 must be null), 2 fp16 (UNet trunk)
     int C1, C2, G, B, HW;
     const float* gamma; const float* beta; float eps;
     int silu;
@@ -127,8 +128,9 @@ int groupnorm_rows_per_chunk(int HW);
 void launch_groupnorm(const GroupNormArgs& a, hipStream_t st);
 int groupnorm_nchunk(int HW);
 
-void launch_layernorm(const float* x, const float* gamma, const float* beta, bf16_t* out, int rows, int C,
-                      float eps, hipStream_t st);
+void launch_layernorm(const void* x, int x_f16 /* 0: fp32 rows, 1: fp16 rows (UNet trunk) */, const float* gamma, const float* beta,
+                      bf16_t* out, int rows, int C, float eps, hipStream_t st);
+void launch_cast_f16_bf16(const f16_t* x, bf16_t* out, size_t n, hipStream_t st);
 void launch_cast_f32_bf16(const float* x, bf16_t* out, size_t n, hipStream_t st);
 // out[b][n] (+)= sum_k act(a[b][k]) * W[n][k] + bias[n];  B <= 8
 void launch_small_linear(const float* a, int lda, const bf16_t* W, int ldw, const float* bias, float* out, int ldo,

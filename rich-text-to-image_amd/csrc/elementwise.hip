@@ -17,6 +17,24 @@ void launch_cast_f32_bf16(const float* x, bf16_t* out, size_t n, hipStream_t st)
     HIP_CHECK(hipGetLastError());
 }
 
+__global__ void cast_f16_kernel(const f16_t* __restrict__ x, bf16_t* __restrict__ out, size_t n8) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const uint4 u = ((const uint4*)x)[i];
+        const f16_t* h = (const f16_t*)&u;
+        uint4 o;
+        o.x = pack_bf16x2((float)h[0], (float)h[1]); o.y = pack_bf16x2((float)h[2], (float)h[3]);
+        o.z = pack_bf16x2((float)h[4], (float)h[5]); o.w = pack_bf16x2((float)h[6], (float)h[7]);
+        ((uint4*)out)[i] = o;
+    }
+}
+void launch_cast_f16_bf16(const f16_t* x, bf16_t* out, size_t n, hipStream_t st) {
+    RT_REQUIRE(n % 8 == 0, "cast: n must be a multiple of 8");
+    const size_t n8 = n / 8;
+    int grid = (int)((n8 + 255) / 256); if (grid > 2048) grid = 2048; if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(cast_f16_kernel, dim3(grid), dim3(256), 0, st, x, out, n8);
+    HIP_CHECK(hipGetLastError());
+}
+
 // ---------------------------------------------------------------- weight packing
 __global__ void pack_kernel(PackArgs p) {
     const size_t total = (size_t)p.rows * p.cols;

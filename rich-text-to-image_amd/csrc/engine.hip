@@ -50,6 +50,7 @@ struct Workspace {       // stack allocator with mark/release; dry == true measu
     }
     float* f32(size_t n) { return (float*)alloc(n * 4); }
     bf16_t* b16(size_t n) { return (bf16_t*)alloc(n * 2); }
+    f16_t* f16(size_t n) { return (f16_t*)alloc(n * 2); }
     size_t mark() const { return off; }
     void release(size_t m) { off = m; }
 };
@@ -110,7 +111,7 @@ static int pad_head_dim(int d) {
     throw rt_error(RT_E_UNSUPPORTED, "head dim > 160 not supported");
 }
 
-struct Tensor { float* p; int C; };   // fp32 trunk tensor [B, HW, C]
+struct Tensor { f16_t* p; int C; };   // trunk tensor [B, HW, C]: fp16 in HBM (what the reference's fp16 pipelines carry), fp32 in every epilogue's arithmetic
 
 struct FwdIn {
     int B = 0, h = 0, w = 0;
@@ -126,7 +127,7 @@ struct FwdIn {
 struct StepArgs;
 void launch_step_epilogue(const StepArgs& a, hipStream_t st);
 void launch_gather_add_rows(const float* base, const float* table, const int* /*host*/ idx, float* out, int B, int C, hipStream_t st);
-void launch_inject_add(float* out, const float* sc, const float* hres, const int* /*host*/ src, int B, size_t per_batch, hipStream_t st);
+void launch_inject_add(f16_t* out, const f16_t* sc, const float* hres, const int* /*host*/ src, int B, size_t per_batch, hipStream_t st);
 void launch_nhwc4_to_nchw(const float* in, float* out, int B, int HW, hipStream_t st);
 void launch_pad_ctx(const float* ctx, bf16_t* out, int P, int D, hipStream_t st);
 void launch_background_blend(float* lat, const float* lat_ref, const float* mask_last, int n, hipStream_t st);
@@ -379,7 +380,7 @@ struct rt_engine {
     bool dry() const { return ws.dry; }
     int cur_hw = 0;              // tokens per stream of the block being executed (0 outside the UNet forward): the split-K rule of
                                  // launch_gemm is keyed on ONE stream's share of a GEMM so that results are batch invariant
-    void gemm(const bf16_t* A, int lda, const MatW& W, int M, void* out, int ldo, int epi, const float* res = nullptr,
+    void gemm(const bf16_t* A, int lda, const MatW& W, int M, void* out, int ldo, int epi, const void* res = nullptr,
               int ldres = 0, const float* temb = nullptr, int rows_per_batch = 0) {
         if (dry()) return;
         GemmArgs g{}; g.A = A; g.W = W.w; g.bias = W.b; g.out = out; g.res = res; g.temb = temb; g.zero = zero;
@@ -401,7 +402,7 @@ struct rt_engine {
         prof_end();
     }
     void conv3(const bf16_t* in, int mode, const MatW& W, int B, int Hin, int Win, int CinP, void* out, int epi,
-               const float* res = nullptr, const float* temb = nullptr) {
+               const void* res = nullptr, const float* temb = nullptr) {
         if (dry()) return;
         int Hout = Hin, Wout = Win;
         if (mode == A_CONV3_S2) { Hout = (Hin + 1) / 2; Wout = (Win + 1) / 2; }   // k3 s2 p1
@@ -416,20 +417,20 @@ struct rt_engine {
         launch_gemm(g, stream);
         prof_end();
     }
-    void groupnorm(const void* x1, const void* x2, bool in_bf16, int C1, int C2, int B, int HW, const NormW& n, float eps_,
+    void groupnorm(const void* x1, const void* x2, int in_type /* 0 fp32, 1 bf16, 2 fp16 */, int C1, int C2, int B, int HW, const NormW& n, float eps_,
                    bool silu, bf16_t* out, bf16_t* raw) {
         Scope sc(ws);
         const int nchunk = groupnorm_nchunk(HW);
         float* partial = ws.f32((size_t)B * nchunk * cfg.norm_groups * 2);
         if (dry()) return;
-        GroupNormArgs a{}; a.x1 = x1; a.x2 = x2; a.in_bf16 = in_bf16; a.C1 = C1; a.C2 = C2; a.G = cfg.norm_groups; a.B = B;
+        GroupNormArgs a{}; a.x1 = x1; a.x2 = x2; a.in_bf16 = in_type; a.C1 = C1; a.C2 = C2; a.G = cfg.norm_groups; a.B = B;
         a.HW = HW; a.gamma = n.g; a.beta = n.b; a.eps = eps_; a.silu = silu; a.out = out; a.raw_out = raw;
         a.partial = partial; a.nchunk = nchunk; a.rows_per_chunk = groupnorm_rows_per_chunk(HW);
         launch_groupnorm(a, stream);
     }
-    void layernorm(const float* x, const NormW& n, bf16_t* out, int rows) {
+    void layernorm(const f16_t* x, const NormW& n, bf16_t* out, int rows) {
         if (dry()) return;
-        launch_layernorm(x, n.g, n.b, out, rows, n.C, 1e-5f, stream);
+        launch_layernorm(x, 1, n.g, n.b, out, rows, n.C, 1e-5f, stream);
     }
 
     // ---------------------------------------------------------------------------- blocks
@@ -440,12 +441,12 @@ struct rt_engine {
         const int c1 = x1.C, c2 = x2 ? x2->C : 0;
         cur_hw = HW;
         RT_REQUIRE(c1 + c2 == r.cin, "resnet: input channel mismatch");
-        float* out = ws.f32((size_t)M * r.cout);
+        f16_t* out = ws.f16((size_t)M * r.cout);
         {
             Scope sc(ws);
             bf16_t* h1 = ws.b16((size_t)M * r.cin);
             bf16_t* raw = r.has_sc ? ws.b16((size_t)M * r.cin) : nullptr;
-            groupnorm(x1.p, x2 ? x2->p : nullptr, false, c1, c2, B, HW, r.n1, cfg.norm_eps, true, h1, raw);
+            groupnorm(x1.p, x2 ? x2->p : nullptr, 2, c1, c2, B, HW, r.n1, cfg.norm_eps, true, h1, raw);
             const float* tp = temb_all + (size_t)B * r.temb_first;        // computed for all resnets at the start of the forward
             // rich-text feature injection (resnet.py:639-643): out[b] = shortcut(x[b]) + hidden[res_src[b]].  The residual branch
             // (conv1 / norm2 / conv2) of an injected stream is never used, so the trailing run of injected streams is not computed
@@ -463,14 +464,14 @@ struct rt_engine {
             bf16_t* h2 = ws.b16((size_t)Mk * r.cout);
             conv3(h1, A_CONV3, r.c1, Bk, Hh, Ww, r.cin, h2, EPI_BF16_TEMB, nullptr, tp);
             bf16_t* h3 = ws.b16((size_t)Mk * r.cout);
-            groupnorm(h2, nullptr, true, r.cout, 0, Bk, HW, r.n2, cfg.norm_eps, true, h3, nullptr);
-            const float* resid = x1.p;
-            if (r.has_sc) { gemm(raw, r.cin, r.sc, M, out, r.cout, EPI_F32); resid = out; }
+            groupnorm(h2, nullptr, 1, r.cout, 0, Bk, HW, r.n2, cfg.norm_eps, true, h3, nullptr);
+            const f16_t* resid = x1.p;
+            if (r.has_sc) { gemm(raw, r.cin, r.sc, M, out, r.cout, EPI_F16); resid = out; }
             else RT_REQUIRE(!x2, "resnet without shortcut cannot take a concat input");
             if (!any_inject) {
-                conv3(h3, A_CONV3, r.c2, B, Hh, Ww, r.cout, out, EPI_F32, resid);
+                conv3(h3, A_CONV3, r.c2, B, Hh, Ww, r.cout, out, EPI_F16, resid);
             } else {
-                float* hres = ws.f32((size_t)Mk * r.cout);
+                float* hres = ws.f32((size_t)Mk * r.cout);        // fp32: rounded once, together with the shortcut (launch_inject_add)
                 conv3(h3, A_CONV3, r.c2, Bk, Hh, Ww, r.cout, hres, EPI_F32, nullptr);
                 int src[RT_MAXB];
                 for (int b = 0; b < B; ++b) src[b] = in.res_src[b] >= 0 ? in.res_src[b] : b;
@@ -486,15 +487,15 @@ struct rt_engine {
         cur_hw = HW;
         RT_REQUIRE(x.C == C, "transformer: channel mismatch");
         RT_REQUIRE(HW % 8 == 0, "transformer: token count (h*w of the attention level) must be a multiple of 8");
-        float* out = ws.f32((size_t)M * C);
+        f16_t* out = ws.f16((size_t)M * C);
         {
             Scope sc(ws);
-            float* hcur = ws.f32((size_t)M * C);
+            f16_t* hcur = ws.f16((size_t)M * C);
             {
                 Scope s2(ws);
                 bf16_t* g = ws.b16((size_t)M * C);
-                groupnorm(x.p, nullptr, false, C, 0, B, HW, t.gn, 1e-6f, false, g, nullptr);
-                gemm(g, C, t.pin, M, hcur, C, EPI_F32);
+                groupnorm(x.p, nullptr, 2, C, 0, B, HW, t.gn, 1e-6f, false, g, nullptr);
+                gemm(g, C, t.pin, M, hcur, C, EPI_F16);
             }
             for (TBlockP& k : t.blocks) {
                 Scope s2(ws);
@@ -527,7 +528,7 @@ struct rt_engine {
                         k.store_rows[0] = HW; k.store_cols[0] = HW;
                     }
                 }
-                gemm(o, HD, k.out1, M, hcur, C, EPI_F32, hcur, C);
+                gemm(o, HD, k.out1, M, hcur, C, EPI_F16, hcur, C);
                 // --- attn2 (cross, K/V from the per-prompt cache; font-size softmax on flagged streams)
                 layernorm(hcur, k.ln2, n, M);
                 gemm(n, C, k.q2, M, qk, HD, EPI_BF16);
@@ -550,16 +551,16 @@ struct rt_engine {
                         k.store_rows[1] = HW; k.store_cols[1] = 77;
                     }
                 }
-                gemm(o, HD, k.out2, M, hcur, C, EPI_F32, hcur, C);
+                gemm(o, HD, k.out2, M, hcur, C, EPI_F16, hcur, C);
                 // --- GEGLU feed-forward (attention.py:209-304)
                 layernorm(hcur, k.ln3, n, M);
                 bf16_t* gg = ws.b16((size_t)M * 4 * C);
                 gemm(n, C, k.ff1, M, gg, 4 * C, EPI_GEGLU);
-                gemm(gg, 4 * C, k.ff2, M, hcur, C, EPI_F32, hcur, C);
+                gemm(gg, 4 * C, k.ff2, M, hcur, C, EPI_F16, hcur, C);
             }
             bf16_t* hb = ws.b16((size_t)M * C);
-            if (!dry()) launch_cast_f32_bf16(hcur, hb, (size_t)M * C, stream);
-            gemm(hb, C, t.pout, M, out, C, EPI_F32, x.p, C);
+            if (!dry()) launch_cast_f16_bf16(hcur, hb, (size_t)M * C, stream);
+            gemm(hb, C, t.pout, M, out, C, EPI_F16, x.p, C);
         }
         return Tensor{out, C};
     }
@@ -605,7 +606,7 @@ struct rt_engine {
         std::vector<Tensor> skips;
         Tensor x;
         {
-            float* x0 = ws.f32((size_t)B * HW0 * cfg.block_out_channels[0]);
+            f16_t* x0 = ws.f16((size_t)B * HW0 * cfg.block_out_channels[0]);
             Scope sc(ws);
             bf16_t* x8 = ws.b16((size_t)B * HW0 * 8);
             if (!dry()) {
@@ -613,7 +614,7 @@ struct rt_engine {
                 for (int b = 0; b < B; ++b) { p.src[b] = in.x[b]; p.scale[b] = in.scale[b]; }
                 launch_prep_latents(p, stream);
             }
-            conv3(x8, A_CONV3, conv_in, B, Hh, Ww, 8, x0, EPI_F32);
+            conv3(x8, A_CONV3, conv_in, B, Hh, Ww, 8, x0, EPI_F16);
             x = Tensor{x0, cfg.block_out_channels[0]};
         }
         skips.push_back(x);
@@ -627,12 +628,12 @@ struct rt_engine {
             }
             if (d.has_down) {
                 const int nh = (ch + 1) / 2, nw = (cw + 1) / 2;
-                float* y = ws.f32((size_t)B * nh * nw * d.C);
+                f16_t* y = ws.f16((size_t)B * nh * nw * d.C);
                 {
                     Scope sc(ws);
                     bf16_t* xb = ws.b16((size_t)B * ch * cw * d.C);
-                    if (!dry()) launch_cast_f32_bf16(x.p, xb, (size_t)B * ch * cw * d.C, stream);
-                    conv3(xb, A_CONV3_S2, d.down, B, ch, cw, d.C, y, EPI_F32);
+                    if (!dry()) launch_cast_f16_bf16(x.p, xb, (size_t)B * ch * cw * d.C, stream);
+                    conv3(xb, A_CONV3_S2, d.down, B, ch, cw, d.C, y, EPI_F16);
                 }
                 ch = nh; cw = nw;
                 x = Tensor{y, d.C};
@@ -651,12 +652,12 @@ struct rt_engine {
                 if (u.has_attn) x = transformer(u.attn[j], in, ch * cw, x);
             }
             if (u.has_up) {
-                float* y = ws.f32((size_t)B * ch * cw * 4 * u.C);
+                f16_t* y = ws.f16((size_t)B * ch * cw * 4 * u.C);
                 {
                     Scope sc(ws);
                     bf16_t* xb = ws.b16((size_t)B * ch * cw * u.C);
-                    if (!dry()) launch_cast_f32_bf16(x.p, xb, (size_t)B * ch * cw * u.C, stream);
-                    conv3(xb, A_CONV3_UP2, u.up, B, ch, cw, u.C, y, EPI_F32);
+                    if (!dry()) launch_cast_f16_bf16(x.p, xb, (size_t)B * ch * cw * u.C, stream);
+                    conv3(xb, A_CONV3_UP2, u.up, B, ch, cw, u.C, y, EPI_F16);
                 }
                 ch *= 2; cw *= 2;
                 x = Tensor{y, u.C};
@@ -665,7 +666,7 @@ struct rt_engine {
         {
             Scope sc(ws);
             bf16_t* hn = ws.b16((size_t)B * HW0 * x.C);
-            groupnorm(x.p, nullptr, false, x.C, 0, B, HW0, norm_out, cfg.norm_eps, true, hn, nullptr);
+            groupnorm(x.p, nullptr, 2, x.C, 0, B, HW0, norm_out, cfg.norm_eps, true, hn, nullptr);
             conv3(hn, A_CONV3, conv_out, B, Hh, Ww, x.C, in.eps_out, EPI_F32);
         }
         ws.release(m0);
@@ -1046,7 +1047,7 @@ int rt_op_gemm_force_config(int cfg) {
     return RT_OK;
 }
 
-int rt_op_gemm(const void* A, const void* W, const float* bias, void* out, const float* res, const float* temb, int mode,
+int rt_op_gemm(const void* A, const void* W, const float* bias, void* out, const void* res, const float* temb, int mode,
                int epi, int M, int N, int K, int lda, int ldw, int ldo, int ldres, int temb_ld, int rows_per_batch, int Hin,
                int Win, int Cin, int Hout, int Wout, void* stream) {
     OP_TRY({
@@ -1084,7 +1085,10 @@ int rt_op_groupnorm(const void* x1, const void* x2, int in_bf16, int C1, int C2,
     })
 }
 int rt_op_layernorm(const float* x, const float* gamma, const float* beta, void* out, int rows, int C, float eps, void* stream) {
-    OP_TRY({ launch_layernorm(x, gamma, beta, (bf16_t*)out, rows, C, eps, (hipStream_t)stream); })
+    OP_TRY({ launch_layernorm(x, 0, gamma, beta, (bf16_t*)out, rows, C, eps, (hipStream_t)stream); })
+}
+int rt_op_layernorm_f16(const void* x_f16, const float* gamma, const float* beta, void* out, int rows, int C, float eps, void* stream) {
+    OP_TRY({ launch_layernorm(x_f16, 1, gamma, beta, (bf16_t*)out, rows, C, eps, (hipStream_t)stream); })
 }
 int rt_op_small_linear(const float* a, int lda, const void* W, int ldw, const float* bias, float* out, int ldo, int B, int N,
                        int K, int silu_in, int accumulate, void* stream) {

@@ -62,7 +62,8 @@ template <int EPI, int TM, int TN, int NWC, int LDS_BYTES, bool PATCH = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[TM][TN], int wrow0, int wcol0, int lane, int wave_c,
                                               char* smem, int prow_base = 0, int pW = 0) {
     auto grow = [&](int r) { return PATCH ? prow_base + (r >> 4) * pW + (r & 15) : r; };
-    constexpr bool F32 = EPI == EPI_F32;
+    constexpr bool F16 = EPI == EPI_F16;               // fp32 slab like EPI_F32, fp16 in HBM (output and residual)
+    constexpr bool F32 = EPI == EPI_F32 || F16;
     constexpr int ES = F32 ? 4 : 2;
     constexpr int TO = EPI == EPI_GEGLU ? TN / 2 : TN;                 // 32-column output tiles per wave
     static_assert(EPI != EPI_GEGLU || TN % 2 == 0, "GEGLU needs value/gate tile pairs in one wave");
@@ -123,6 +124,31 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
             // ---- slab -> HBM, row-contiguous 16-B chunks (LDS operations of one wave execute in order)
             const int ncol_pass = (TO - t0 < TS ? TO - t0 : TS) * 32;   // columns staged in this pass
             const int cpr_pass = ncol_pass * ES / 16;
+            if constexpr (F16) {
+                // 8 columns per lane: two 16-B slab reads, one 16-B residual read, ONE 16-B store
+                const int cpr8 = cpr_pass >> 1;
+#pragma unroll
+                for (int idx0 = 0; idx0 < 16 * CPR; idx0 += 64) {
+                    const int idx = idx0 + lane;
+                    const int r = idx / cpr8, c8 = idx - r * cpr8;
+                    if (r >= 32) continue;
+                    const int row = grow(wrow0 + i * 32 + r);
+                    const int col = ocol0 + t0 * 32 + c8 * 8;
+                    if (row >= p.M || col >= NO) continue;
+                    const float4 a0 = *(const float4*)(slab + r * RS + c8 * 32), a1 = *(const float4*)(slab + r * RS + c8 * 32 + 16);
+                    float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                    if (p.res) {
+                        const uint4 rq = *(const uint4*)((const f16_t*)p.res + (size_t)row * p.ldres + col);
+                        const f16_t* rh = (const f16_t*)&rq;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += (float)rh[e];
+                    }
+                    uint4 o; f16_t* oh = (f16_t*)&o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) oh[e] = (f16_t)v[e];
+                    *(uint4*)((f16_t*)p.out + (size_t)row * p.ldo + col) = o;
+                }
+            } else {
 #pragma unroll
             for (int idx0 = 0; idx0 < 32 * CPR; idx0 += 64) {
                 const int idx = idx0 + lane;
@@ -134,11 +160,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
                 const uint4 q = *(const uint4*)(slab + r * RS + ch * 16);
                 if constexpr (F32) {
                     float4 o = make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w));
-                    if (p.res) { const float4 rv = *(const float4*)(p.res + (size_t)row * p.ldres + col); o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w; }
+                    if (p.res) { const float4 rv = *(const float4*)((const float*)p.res + (size_t)row * p.ldres + col); o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w; }
                     *(float4*)((float*)p.out + (size_t)row * p.ldo + col) = o;
                 } else {
                     *(uint4*)((bf16_t*)p.out + (size_t)row * p.ldo + col) = q;
                 }
+            }
             }
         }
     }
@@ -1157,17 +1184,21 @@ static void launch_me(const GemmArgs& a, int cfg, hipStream_t st) {
 
 // (A operand mode, epilogue) combinations that exist on the hot path; anything else is rejected loudly.
 static void launch_with_cfg(const GemmArgs& a, int cfg, hipStream_t st) {
-    const int key = a.mode * 4 + a.epi;
+    const int key = a.mode * 8 + a.epi;
     switch (key) {
-        case A_DENSE * 4 + EPI_BF16: launch_me<A_DENSE, EPI_BF16>(a, cfg, st); break;
-        case A_DENSE * 4 + EPI_F32: launch_me<A_DENSE, EPI_F32>(a, cfg, st); break;
-        case A_DENSE * 4 + EPI_BF16_TEMB: launch_me<A_DENSE, EPI_BF16_TEMB>(a, cfg, st); break;
-        case A_DENSE * 4 + EPI_GEGLU: launch_me<A_DENSE, EPI_GEGLU>(a, cfg, st); break;
-        case A_CONV3 * 4 + EPI_BF16: launch_me<A_CONV3, EPI_BF16>(a, cfg, st); break;     // VAE decoder convs (no time embedding) and backward-data
-        case A_CONV3 * 4 + EPI_F32: launch_me<A_CONV3, EPI_F32>(a, cfg, st); break;
-        case A_CONV3 * 4 + EPI_BF16_TEMB: launch_me<A_CONV3, EPI_BF16_TEMB>(a, cfg, st); break;
-        case A_CONV3_S2 * 4 + EPI_F32: launch_me<A_CONV3_S2, EPI_F32>(a, cfg, st); break;
-        case A_CONV3_UP2 * 4 + EPI_F32: launch_me<A_CONV3_UP2, EPI_F32>(a, cfg, st); break;
+        case A_DENSE * 8 + EPI_BF16: launch_me<A_DENSE, EPI_BF16>(a, cfg, st); break;
+        case A_DENSE * 8 + EPI_F32: launch_me<A_DENSE, EPI_F32>(a, cfg, st); break;
+        case A_DENSE * 8 + EPI_F16: launch_me<A_DENSE, EPI_F16>(a, cfg, st); break;
+        case A_DENSE * 8 + EPI_BF16_TEMB: launch_me<A_DENSE, EPI_BF16_TEMB>(a, cfg, st); break;
+        case A_DENSE * 8 + EPI_GEGLU: launch_me<A_DENSE, EPI_GEGLU>(a, cfg, st); break;
+        case A_CONV3 * 8 + EPI_BF16: launch_me<A_CONV3, EPI_BF16>(a, cfg, st); break;     // VAE decoder convs (no time embedding) and backward-data
+        case A_CONV3 * 8 + EPI_F32: launch_me<A_CONV3, EPI_F32>(a, cfg, st); break;
+        case A_CONV3 * 8 + EPI_F16: launch_me<A_CONV3, EPI_F16>(a, cfg, st); break;
+        case A_CONV3 * 8 + EPI_BF16_TEMB: launch_me<A_CONV3, EPI_BF16_TEMB>(a, cfg, st); break;
+        case A_CONV3_S2 * 8 + EPI_F32: launch_me<A_CONV3_S2, EPI_F32>(a, cfg, st); break;
+        case A_CONV3_S2 * 8 + EPI_F16: launch_me<A_CONV3_S2, EPI_F16>(a, cfg, st); break;
+        case A_CONV3_UP2 * 8 + EPI_F32: launch_me<A_CONV3_UP2, EPI_F32>(a, cfg, st); break;
+        case A_CONV3_UP2 * 8 + EPI_F16: launch_me<A_CONV3_UP2, EPI_F16>(a, cfg, st); break;
         default: throw rt_error(RT_E_UNSUPPORTED, "gemm: (operand mode, epilogue) combination not built");
     }
     HIP_CHECK(hipGetLastError());
@@ -1193,8 +1224,8 @@ static void launch_conv3p(const GemmArgs& a, hipStream_t st) {
 }
 static bool conv_patch_eligible(const GemmArgs& a) {
     if (!g_conv_patch || a.mode == A_DENSE || a.rows_per_batch <= 0 || a.Hout % 16 || a.Wout % 16 || a.Cin % 64 || a.M % a.rows_per_batch) return false;
-    if (a.mode == A_CONV3) return a.Hin == a.Hout && a.Win == a.Wout && (a.epi == EPI_BF16 || a.epi == EPI_F32 || a.epi == EPI_BF16_TEMB);
-    if (a.mode == A_CONV3_UP2) return a.Hout == 2 * a.Hin && a.Wout == 2 * a.Win && a.epi == EPI_F32;
+    if (a.mode == A_CONV3) return a.Hin == a.Hout && a.Win == a.Wout && (a.epi == EPI_BF16 || a.epi == EPI_F32 || a.epi == EPI_F16 || a.epi == EPI_BF16_TEMB);
+    if (a.mode == A_CONV3_UP2) return a.Hout == 2 * a.Hin && a.Wout == 2 * a.Win && (a.epi == EPI_F32 || a.epi == EPI_F16);
     return false;
 }
 void gemm_force_config(int cfg) { g_force_cfg = cfg; }
@@ -1257,7 +1288,7 @@ static int pick_config(const GemmArgs& a, hipStream_t st) {
 struct ReduceArgs {
     const float* part; int S; size_t slice;       // S slices of `slice` floats, rows of ldp floats
     int M, N, ldp;
-    int epi; const float* bias; const float* res; int ldres; const float* temb; int temb_ld, rows_per_batch;
+    int epi; const float* bias; const void* res; int ldres; const float* temb; int temb_ld, rows_per_batch;
     void* out; int ldo;
 };
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(ReduceArgs p) {
@@ -1286,8 +1317,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ReduceArgs p) {
             v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
         }
         if (p.epi == EPI_F32) {
-            if (p.res) { const float4 r = *(const float4*)(p.res + (size_t)row * p.ldres + oc); v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
+            if (p.res) { const float4 r = *(const float4*)((const float*)p.res + (size_t)row * p.ldres + oc); v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
             *(float4*)((float*)p.out + (size_t)row * p.ldo + oc) = make_float4(v[0], v[1], v[2], v[3]);
+        } else if (p.epi == EPI_F16) {
+            if (p.res) {
+                const uint2 rq = *(const uint2*)((const f16_t*)p.res + (size_t)row * p.ldres + oc);
+                const f16_t* rh = (const f16_t*)&rq;
+                v[0] += (float)rh[0]; v[1] += (float)rh[1]; v[2] += (float)rh[2]; v[3] += (float)rh[3];
+            }
+            uint2 w; f16_t* oh = (f16_t*)&w;
+            oh[0] = (f16_t)v[0]; oh[1] = (f16_t)v[1]; oh[2] = (f16_t)v[2]; oh[3] = (f16_t)v[3];
+            *(uint2*)((f16_t*)p.out + (size_t)row * p.ldo + oc) = w;
         } else {
             uint2 w; w.x = pack_bf16x2(v[0], v[1]); w.y = pack_bf16x2(v[2], v[3]);
             *(uint2*)((bf16_t*)p.out + (size_t)row * p.ldo + oc) = w;
@@ -1359,7 +1399,9 @@ void launch_gemm(const GemmArgs& a, hipStream_t st) {
     }
     if (a.epi == EPI_GEGLU) RT_REQUIRE(a.N % 64 == 0, "geglu: N must be a multiple of 64");
     RT_REQUIRE(a.N % 4 == 0, "gemm: N must be a multiple of 4");
-    if (a.epi == EPI_BF16 || a.epi == EPI_BF16_TEMB) RT_REQUIRE(a.N % 8 == 0 && a.ldo % 8 == 0, "gemm: bf16 output needs N % 8 == 0");
+    if (a.epi == EPI_BF16 || a.epi == EPI_BF16_TEMB || a.epi == EPI_F16) RT_REQUIRE(a.N % 8 == 0 && a.ldo % 8 == 0, "gemm: 16-bit output needs N % 8 == 0");
+    if (a.epi == EPI_F16 && a.res) RT_REQUIRE(a.ldres % 8 == 0, "gemm: fp16 residual needs ldres % 8 == 0");
+    RT_REQUIRE(a.epi >= EPI_BF16 && a.epi <= EPI_F16, "gemm: unknown epilogue");
     if (a.epi == EPI_GEGLU) RT_REQUIRE(a.N % 16 == 0 && a.ldo % 8 == 0, "gemm: GEGLU output needs N % 16 == 0");
     RT_REQUIRE(a.ldo % 4 == 0 && ((uintptr_t)a.out & 15) == 0, "gemm: output must be 16-B aligned with ldo % 4 == 0");
     if (a.res) RT_REQUIRE(a.ldres % 4 == 0 && ((uintptr_t)a.res & 15) == 0, "gemm: residual must be 16-B aligned");
@@ -1372,10 +1414,11 @@ void launch_gemm(const GemmArgs& a, hipStream_t st) {
     // patch convolutions that cannot fill the chip (< 128 workgroups) go through the split-K implicit GEMM as well
     const bool patch_underfilled = ksl > 1 && a.mode != A_DENSE;
     if (conv_patch_eligible(a) && !patch_underfilled) {
-        if (a.mode == A_CONV3_UP2) launch_conv3p<EPI_F32, true>(a, st);
+        if (a.mode == A_CONV3_UP2) { if (a.epi == EPI_F16) launch_conv3p<EPI_F16, true>(a, st); else launch_conv3p<EPI_F32, true>(a, st); }
         else switch (a.epi) {
             case EPI_BF16: launch_conv3p<EPI_BF16, false>(a, st); break;
             case EPI_F32: launch_conv3p<EPI_F32, false>(a, st); break;
+            case EPI_F16: launch_conv3p<EPI_F16, false>(a, st); break;
             default: launch_conv3p<EPI_BF16_TEMB, false>(a, st); break;
         }
         return;

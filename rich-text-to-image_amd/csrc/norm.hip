@@ -13,12 +13,17 @@ static inline int gn_rows_per_chunk(int HW) { int r = HW / 128; return r < 16 ? 
 int groupnorm_rows_per_chunk(int HW) { return gn_rows_per_chunk(HW); }
 int groupnorm_nchunk(int HW) { return cdiv(HW, gn_rows_per_chunk(HW)); }
 
-template <bool BF16IN>
+// IT: element type of the input(s): 0 fp32, 1 bf16 (single source), 2 fp16 (the UNet trunk; virtual concat allowed)
+template <int IT>
 __device__ __forceinline__ void load4(const void* x1, const void* x2, int C1, int C2, size_t row, int c, float v[4]) {
-    if (BF16IN) {
+    if (IT == 1) {
         const uint2 u = *(const uint2*)((const bf16_t*)x1 + row * C1 + c);
         v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
         v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+    } else if (IT == 2) {
+        const uint2 u = (c < C1) ? *(const uint2*)((const f16_t*)x1 + row * C1 + c) : *(const uint2*)((const f16_t*)x2 + row * C2 + (c - C1));
+        const f16_t* h = (const f16_t*)&u;
+        v[0] = (float)h[0]; v[1] = (float)h[1]; v[2] = (float)h[2]; v[3] = (float)h[3];
     } else {
         const float4 f = (c < C1) ? *(const float4*)((const float*)x1 + row * C1 + c)
                                   : *(const float4*)((const float*)x2 + row * C2 + (c - C1));
@@ -38,7 +43,7 @@ __host__ __device__ inline GnShape gn_block_shape(int nv) {
 }
 
 // grid (nchunk, B); partial[b][chunk][g][2] = (sum, sumsq) over this chunk's rows
-template <bool BF16IN>
+template <int BF16IN>
 __global__ __launch_bounds__(512) void gn_stats_kernel(GroupNormArgs p) {
     __shared__ float sh_s[GN_MAXC], sh_q[GN_MAXC];
     const int C = p.C1 + p.C2, cpg = C / p.G, nv = C >> 2;
@@ -122,7 +127,7 @@ void launch_gn_finalize(float* partial, int B, int nchunk, int G, double n, floa
 // grid (nchunk, B); reads the finalized (mean, rstd) of partial[b][0][g].  A thread owns VW = 8 consecutive channels (two 16-B
 // loads, one 16-B store per output: the 4-channel form spent its time issuing 8-B stores, 3.0 TB/s) or 4 when the channel counts
 // are not multiples of 8.
-template <bool BF16IN, int VW>
+template <int BF16IN, int VW>
 __device__ __forceinline__ void loadv(const void* x1, const void* x2, int C1, int C2, size_t row, int c, float (&v)[VW]) {
 #pragma unroll
     for (int h = 0; h < VW / 4; ++h) {
@@ -142,7 +147,7 @@ __device__ __forceinline__ void storev(bf16_t* dst, const float (&y)[VW]) {
         *(uint2*)dst = o;
     }
 }
-template <bool BF16IN, int VW>
+template <int BF16IN, int VW>
 __global__ __launch_bounds__(512) void gn_apply_kernel(GroupNormArgs p) {
     __shared__ float mean[32], rstd[32];
     const int C = p.C1 + p.C2, cpg = C / p.G, nv = C / VW;
@@ -193,7 +198,7 @@ void launch_groupnorm(const GroupNormArgs& a, hipStream_t st) {
     const int C = a.C1 + a.C2;
     RT_REQUIRE(a.G >= 1 && a.G <= 32 && C % a.G == 0, "groupnorm: bad group count");
     RT_REQUIRE(a.C1 % 4 == 0 && a.C2 % 4 == 0, "groupnorm: channels must be multiples of 4");
-    RT_REQUIRE(!(a.in_bf16 && a.x2), "groupnorm: bf16 input cannot be a concat");
+    RT_REQUIRE(a.in_bf16 >= 0 && a.in_bf16 <= 2 && !(a.in_bf16 == 1 && a.x2), "groupnorm: input type 0 fp32 / 1 bf16 (no concat) / 2 fp16");
     RT_REQUIRE(a.nchunk == groupnorm_nchunk(a.HW) && a.rows_per_chunk == gn_rows_per_chunk(a.HW), "groupnorm: nchunk mismatch");
     RT_REQUIRE(C <= GN_MAXC, "groupnorm: too many channels");
     const GnShape shp = gn_block_shape(C >> 2);
@@ -203,17 +208,15 @@ void launch_groupnorm(const GroupNormArgs& a, hipStream_t st) {
     const bool wide = a.C1 % 8 == 0 && a.C2 % 8 == 0;               // 8 channels per thread in the apply pass
     const GnShape sh8 = gn_block_shape(C >> 3);
     dim3 block8(sh8.tcols * sh8.nrl);
-    if (a.in_bf16) {
-        hipLaunchKernelGGL(gn_stats_kernel<true>, grid, block, 0, st, a);
-        launch_gn_finalize(a.partial, a.B, a.nchunk, a.G, n, a.eps, 0, st);
-        if (wide) hipLaunchKernelGGL((gn_apply_kernel<true, 8>), grid, block8, 0, st, a);
-        else hipLaunchKernelGGL((gn_apply_kernel<true, 4>), grid, block, 0, st, a);
-    } else {
-        hipLaunchKernelGGL(gn_stats_kernel<false>, grid, block, 0, st, a);
-        launch_gn_finalize(a.partial, a.B, a.nchunk, a.G, n, a.eps, 0, st);
-        if (wide) hipLaunchKernelGGL((gn_apply_kernel<false, 8>), grid, block8, 0, st, a);
-        else hipLaunchKernelGGL((gn_apply_kernel<false, 4>), grid, block, 0, st, a);
+#define RT_GN_LAUNCH(IT)                                                                                  \
+    {                                                                                                         \
+        hipLaunchKernelGGL(gn_stats_kernel<IT>, grid, block, 0, st, a);                                       \
+        launch_gn_finalize(a.partial, a.B, a.nchunk, a.G, n, a.eps, 0, st);                                   \
+        if (wide) hipLaunchKernelGGL((gn_apply_kernel<IT, 8>), grid, block8, 0, st, a);                       \
+        else hipLaunchKernelGGL((gn_apply_kernel<IT, 4>), grid, block, 0, st, a);                             \
     }
+    if (a.in_bf16 == 1) RT_GN_LAUNCH(1) else if (a.in_bf16 == 2) RT_GN_LAUNCH(2) else RT_GN_LAUNCH(0)
+#undef RT_GN_LAUNCH
     HIP_CHECK(hipGetLastError());
 }
 
@@ -221,20 +224,31 @@ void launch_groupnorm(const GroupNormArgs& a, hipStream_t st) {
 // A lane owns 8 consecutive channels per 512-channel pass: two 16-B loads, ONE 16-B store (with 4 channels per lane the kernel sat
 // at 4.0 TB/s, bound by the number of 8-B store instructions: guide T21).
 #define LN_MAXP 3   // C <= 1536 (8 channels per lane per 512-channel pass)
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+template <bool F16IN>
+__device__ __forceinline__ void ln_load8(const void* xr, int c, float4 (&v)[2]) {
+    if (F16IN) {
+        const uint4 u = *(const uint4*)((const f16_t*)xr + c);
+        const f16_t* h = (const f16_t*)&u;
+        v[0] = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]); v[1] = make_float4((float)h[4], (float)h[5], (float)h[6], (float)h[7]);
+    } else {
+        v[0] = *(const float4*)((const float*)xr + c); v[1] = *(const float4*)((const float*)xr + c + 4);
+    }
+}
+template <bool F16IN>
+__global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, bf16_t* __restrict__ out,
                                                         int rows, int C, float eps) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const float* xr = x + (size_t)row * C;
+    const char* xr = (const char*)x + (size_t)row * C * (F16IN ? 2 : 4);
     float4 v[LN_MAXP][2];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < LN_MAXP; ++i) {
         const int c = i * 512 + lane * 8;
         if (c < C) {
-            v[i][0] = *(const float4*)(xr + c); v[i][1] = *(const float4*)(xr + c + 4);
+            ln_load8<F16IN>(xr, c, v[i]);
             s += (v[i][0].x + v[i][0].y + v[i][0].z + v[i][0].w) + (v[i][1].x + v[i][1].y + v[i][1].z + v[i][1].w);
         }
     }
@@ -273,9 +287,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
-void launch_layernorm(const float* x, const float* gamma, const float* beta, bf16_t* out, int rows, int C,
+void launch_layernorm(const void* x, int x_f16, const float* gamma, const float* beta, bf16_t* out, int rows, int C,
                       float eps, hipStream_t st) {
     RT_REQUIRE(C % 8 == 0 && C <= LN_MAXP * 512, "layernorm: C must be a multiple of 8 and <= 1536");
-    hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, gamma, beta, out, rows, C, eps);
+    if (x_f16) hipLaunchKernelGGL(layernorm_kernel<true>, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, gamma, beta, out, rows, C, eps);
+    else hipLaunchKernelGGL(layernorm_kernel<false>, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, gamma, beta, out, rows, C, eps);
     HIP_CHECK(hipGetLastError());
 }

@@ -102,18 +102,23 @@ void launch_gather_add_rows(const float* base, const float* table, const int* id
     HIP_CHECK(hipGetLastError());
 }
 
-// out[b] = sc[b] + hres[src[b]]   (out may alias sc)
-__global__ void inject_add_kernel(float* out, const float* sc, const float* hres, IdxList src, size_t per_batch4) {
+// out[b] = sc[b] + hres[src[b]]   (out may alias sc).  sc / out are fp16 trunk tensors, hres is the fp32 residual branch: the sum is
+// rounded once, exactly like the fused epilogue of a resnet without injection (a stream keeps its bits whether or not another
+// stream of the batch injects).
+__global__ void inject_add_kernel(f16_t* out, const f16_t* sc, const float* hres, IdxList src, size_t per_batch4) {
     const int b = blockIdx.y;
-    const float4* s4 = (const float4*)sc + (size_t)b * per_batch4;
+    const uint2* s4 = (const uint2*)sc + (size_t)b * per_batch4;
     const float4* h4 = (const float4*)hres + (size_t)src.v[b] * per_batch4;
-    float4* o4 = (float4*)out + (size_t)b * per_batch4;
+    uint2* o4 = (uint2*)out + (size_t)b * per_batch4;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < per_batch4; i += (size_t)gridDim.x * blockDim.x) {
-        const float4 a = s4[i], h = h4[i];
-        o4[i] = make_float4(a.x + h.x, a.y + h.y, a.z + h.z, a.w + h.w);
+        const uint2 a = s4[i]; const float4 h = h4[i];
+        const f16_t* ah = (const f16_t*)&a;
+        uint2 o; f16_t* oh = (f16_t*)&o;
+        oh[0] = (f16_t)(h.x + (float)ah[0]); oh[1] = (f16_t)(h.y + (float)ah[1]); oh[2] = (f16_t)(h.z + (float)ah[2]); oh[3] = (f16_t)(h.w + (float)ah[3]);
+        o4[i] = o;
     }
 }
-void launch_inject_add(float* out, const float* sc, const float* hres, const int* src, int B, size_t per_batch, hipStream_t st) {
+void launch_inject_add(f16_t* out, const f16_t* sc, const float* hres, const int* src, int B, size_t per_batch, hipStream_t st) {
     IdxList l{}; for (int b = 0; b < B; ++b) l.v[b] = src[b];
     const size_t n4 = per_batch / 4;
     int gx = (int)((n4 + 255) / 256); if (gx > 1024) gx = 1024;

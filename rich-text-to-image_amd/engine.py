@@ -11,7 +11,7 @@ RT_MAX_STREAMS = 16
 DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2
 SCHED_EULER, SCHED_PNDM = 0, 1
 A_DENSE, A_CONV3, A_CONV3_S2, A_CONV3_UP2 = 0, 1, 2, 3
-EPI_BF16, EPI_F32, EPI_BF16_TEMB, EPI_GEGLU = 0, 1, 2, 3
+EPI_BF16, EPI_F32, EPI_BF16_TEMB, EPI_GEGLU, EPI_F16 = 0, 1, 2, 3, 4
 
 # UNet architectures of the two pipelines (models/region_diffusion.py:32, region_diffusion_sdxl.py:115;
 # values = the published unet/config.json of runwayml/stable-diffusion-v1-5 and
@@ -65,7 +65,7 @@ _SYMBOLS = [
     "rt_weight_info", "rt_bind_weight", "rt_weights_missing", "rt_arena_info", "rt_arena_mark_bound",
     "rt_set_prompts", "rt_set_masks", "rt_set_fontsize", "rt_set_schedule", "rt_set_latents", "rt_get_latents",
     "rt_region_step", "rt_plain_step", "rt_unet_forward", "rt_op_gemm", "rt_op_attention", "rt_op_groupnorm",
-    "rt_op_layernorm", "rt_op_small_linear", "rt_op_timestep_embed", "rt_op_last_error", "rt_profile_enable",
+    "rt_op_layernorm", "rt_op_layernorm_f16", "rt_op_small_linear", "rt_op_timestep_embed", "rt_op_last_error", "rt_profile_enable",
     "rt_profile_read", "rt_op_gemm_force_config", "rt_op_gemm_debug", "rt_attn_store_enable", "rt_attn_store_reset",
     "rt_attn_store_read", "rt_attn_module_count", "rt_attn_module_info", "rt_get_state_ptrs", "rt_background_blend", "rt_vae_create", "rt_vae_destroy",
     "rt_vae_last_error", "rt_vae_weight_count", "rt_vae_weight_info", "rt_vae_bind_weight", "rt_vae_synchronize", "rt_vae_decode",

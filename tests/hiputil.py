@@ -32,7 +32,7 @@ def gemm(A, W, bias=None, epi=0, res=None, temb=None, rows_per_batch=0, mode=0, 
         rows_per_batch = Hout * Wout
         lda = 0
     oc = out_cols if out_cols is not None else (N // 2 if epi == 3 else N)
-    out = torch.empty(M, oc, device=DEV, dtype=torch.float32 if epi == 1 else torch.bfloat16)
+    out = torch.empty(M, oc, device=DEV, dtype={1: torch.float32, 4: torch.float16}.get(epi, torch.bfloat16))
     chk(lib.rt_op_gemm(_ptr(A), _ptr(W), _ptr(bias), _ptr(out), _ptr(res), _ptr(temb), mode, epi, M, N, K, lda, W.stride(0),
                        out.stride(0), res.stride(0) if res is not None else 0, temb.stride(0) if temb is not None else 0,
                        rows_per_batch, Hin, Win, Cin, Hout, Wout, None))
@@ -56,7 +56,7 @@ def attention(Q, K, VT, B, H, N, NK, DP, ldq=None, ldk=None, q_src=None, k_src=N
 
 def groupnorm(x1, x2, G, gamma, beta, eps, silu, want_raw=False):
     lib = load_library()
-    in_bf16 = x1.dtype == torch.bfloat16
+    in_bf16 = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[x1.dtype]
     B, HW, C1 = x1.shape
     C2 = x2.shape[2] if x2 is not None else 0
     out = torch.empty(B, HW, C1 + C2, device=DEV, dtype=torch.bfloat16)
@@ -71,7 +71,8 @@ def layernorm(x, gamma, beta, eps=1e-5):
     lib = load_library()
     rows, Cc = x.shape
     out = torch.empty(rows, Cc, device=DEV, dtype=torch.bfloat16)
-    chk(lib.rt_op_layernorm(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(out), rows, Cc, C.c_float(eps), None))
+    fn = lib.rt_op_layernorm_f16 if x.dtype == torch.float16 else lib.rt_op_layernorm
+    chk(fn(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(out), rows, Cc, C.c_float(eps), None))
     torch.cuda.synchronize()
     return out
 

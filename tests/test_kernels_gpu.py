@@ -34,6 +34,17 @@ def test_gemm_dense_f32_bias_residual(M, N, K):
     report(f"gemm_f32 {M}x{N}x{K}", out, ref, **F32_OUT)
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (1000, 72, 200), (4096, 1280, 1280), (320, 1280, 5120)])
+def test_gemm_fp16_trunk_epilogue(M, N, K):
+    """epi 4: fp16 output with an fp16 residual, fp32 arithmetic - what every trunk-producing GEMM / conv of the UNet uses."""
+    A, W = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=K ** -0.5))
+    bias, res = rnd(N, seed=3).to(DEV), (rnd(M, N, seed=4) * 3).to(DEV).to(torch.float16)
+    out = gemm(A, W, bias, epi=4, res=res)
+    ref = A.float() @ W.float().t() + bias + res.float()
+    assert out.dtype == torch.float16
+    report(f"gemm_f16 {M}x{N}x{K}", out, ref, atol=4e-3, rtol=1.5e-3)        # fp16 rounding: 2^-11 relative
+
+
 def test_gemm_is_transpose_detecting_and_asymmetric():
     # A = I (padded) with asymmetric W catches swapped row/col mapping of the MFMA C layout
     M = N = K = 128
@@ -337,18 +348,23 @@ def test_attention_against_reference_module_golden():
 @pytest.mark.parametrize("B,HW,C1,C2,G,silu,bf16in", [(2, 256, 64, 0, 8, True, False), (3, 1024, 320, 0, 32, True, False),
                                                       (2, 64, 1280, 640, 32, True, False), (2, 4096, 640, 320, 32, True, False),
                                                       (2, 256, 320, 0, 32, False, False), (2, 1024, 96, 0, 8, True, True),
-                                                      (1, 16384, 320, 0, 32, True, False)])
+                                                      (1, 16384, 320, 0, 32, True, False),
+                                                      (2, 64, 1280, 640, 32, True, "f16"), (2, 1024, 320, 0, 32, False, "f16"),
+                                                      (3, 256, 96, 32, 8, True, "f16")])
 def test_groupnorm(B, HW, C1, C2, G, silu, bf16in):
     x1 = rnd(B, HW, C1, seed=60) * 2 + 0.5
     x2 = rnd(B, HW, C2, seed=61) - 0.3 if C2 else None
     gamma, beta = (1 + 0.1 * rnd(C1 + C2, seed=62)).to(DEV), (0.1 * rnd(C1 + C2, seed=63)).to(DEV)
     eps = 1e-5 if silu else 1e-6
-    if bf16in:
+    if bf16in == "f16":                              # fp16 trunk tensors incl. the virtual concat of the up blocks
+        x1 = x1.to(torch.float16)
+        x2 = x2.to(torch.float16) if C2 else None
+    elif bf16in:
         x1 = x1.to(torch.bfloat16)
     xin1 = x1.to(DEV).contiguous()
     xin2 = x2.to(DEV).contiguous() if C2 else None
     out, raw = groupnorm(xin1, xin2, G, gamma, beta, eps, silu, want_raw=True)
-    xc = torch.cat([x1.float(), x2], -1) if C2 else x1.float()
+    xc = torch.cat([x1.float(), x2.float()], -1) if C2 else x1.float()
     ref = F.group_norm(xc.permute(0, 2, 1).to(DEV), G, gamma, beta, eps).permute(0, 2, 1)
     if silu:
         ref = F.silu(ref)
@@ -356,12 +372,15 @@ def test_groupnorm(B, HW, C1, C2, G, silu, bf16in):
     report("groupnorm raw copy", raw, xc, atol=1e-2, rtol=8e-3)
 
 
+@pytest.mark.parametrize("f16", [False, True])
 @pytest.mark.parametrize("rows,C", [(100, 64), (512, 640), (1024, 1280), (77, 320)])
-def test_layernorm(rows, C):
+def test_layernorm(rows, C, f16):
     x = (rnd(rows, C, seed=70) * 3 + 1).to(DEV)
+    if f16:
+        x = x.to(torch.float16)                     # the UNet trunk is fp16; the text encoder's residual stream fp32
     gamma, beta = (1 + 0.1 * rnd(C, seed=71)).to(DEV), (0.1 * rnd(C, seed=72)).to(DEV)
     out = layernorm(x, gamma, beta)
-    report(f"layernorm {rows}x{C}", out, F.layer_norm(x, (C,), gamma, beta, 1e-5), **BF16_OUT)
+    report(f"layernorm {rows}x{C}", out, F.layer_norm(x.float(), (C,), gamma, beta, 1e-5), **BF16_OUT)
 
 
 def test_small_linear_and_timestep_embedding():
