@@ -129,6 +129,13 @@ void launch_gn_finalize(float* partial, int B, int nchunk, int G, double n, floa
 // are not multiples of 8.
 template <int BF16IN, int VW>
 __device__ __forceinline__ void loadv(const void* x1, const void* x2, int C1, int C2, size_t row, int c, float (&v)[VW]) {
+    if constexpr (BF16IN == 2 && VW == 8) {          // fp16 trunk: one 16-B load (C1 % 8 == 0: the vector never straddles x1 | x2)
+        const uint4 u = (c < C1) ? *(const uint4*)((const f16_t*)x1 + row * C1 + c) : *(const uint4*)((const f16_t*)x2 + row * C2 + (c - C1));
+        const f16_t* h = (const f16_t*)&u;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)h[e];
+        return;
+    }
 #pragma unroll
     for (int h = 0; h < VW / 4; ++h) {
         float t[4];
@@ -166,11 +173,11 @@ __global__ __launch_bounds__(512) void gn_apply_kernel(GroupNormArgs p) {
     if (rl >= nrl) return;
     for (int vec = v0; vec < nv; vec += tcols) {
         const int c = vec * VW;
-        float ga[VW], be[VW], mu[VW], rs[VW];
+        float sc[VW], sh[VW];                                      // y = x * sc + sh  ==  (x - mean) * rstd * gamma + beta
 #pragma unroll
         for (int e = 0; e < VW; ++e) {
             const int g = (c + e) / cpg;
-            ga[e] = p.gamma[c + e]; be[e] = p.beta[c + e]; mu[e] = mean[g]; rs[e] = rstd[g];
+            sc[e] = rstd[g] * p.gamma[c + e]; sh[e] = p.beta[c + e] - mean[g] * sc[e];
         }
         for (int r = r0 + rl; r < r1; r += 2 * nrl) {               // two rows in flight per thread
             float v[2][VW];
@@ -184,8 +191,9 @@ __global__ __launch_bounds__(512) void gn_apply_kernel(GroupNormArgs p) {
                 float y[VW];
 #pragma unroll
                 for (int e = 0; e < VW; ++e) {
-                    y[e] = (v[u][e] - mu[e]) * rs[e] * ga[e] + be[e];
-                    if (p.silu) y[e] = y[e] / (1.f + __expf(-y[e]));
+                    y[e] = v[u][e] * sc[e] + sh[e];
+                    // SiLU with v_exp_f32 (2^x) + v_rcp_f32: the IEEE division alone was ~10 VALU ops per element, half of this kernel
+                    if (p.silu) y[e] = y[e] * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * y[e]));
                 }
                 storev<VW>(p.out + row * C + c, y);
                 if (p.raw_out) storev<VW>(p.raw_out + row * C + c, v[u]);
