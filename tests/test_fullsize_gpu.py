@@ -169,6 +169,8 @@ def test_sdxl_config3_rich_step_matches_oracle(sdxl):
     ref, ref_ref = torch.chunk(out, 2, dim=0)
     r, rr = rel_l2(got - lat0, ref - lat0), rel_l2(got_ref - lat0, ref_ref - lat0)
     print(f"SDXL config 3, injected rich step (R=4, inject_selfattn=0.5): latent UPDATE rel-L2 {r:.3e} (reference stream {rr:.3e})")
+    # the update is dsigma * (eps_u + 5 (eps_t - eps_u)): classifier-free guidance multiplies the ~7e-3 error of each forward by
+    # the guidance scale relative to the (small) difference of the two predictions; measured 2.2e-2 / 2.3e-2 on MI355X (deterministic)
     assert r < 3e-2 and rr < 3e-2
 
 
