@@ -109,7 +109,8 @@ def broadcast_weights(engine, src=0):
 def broadcast_pipeline(unet_engine, vae=None, text_encoders=(), src=0):
     """Everything a rank needs to sample without touching the checkpoint files: the UNet arena, the VAE decoder arena and the
     text-encoder weights (HipCLIPTextEncoder.parameter_tensors()), three collectives in total.  Ranks != src construct the same
-    objects from the configs alone (checkpoint.load_pipeline(..., weights=False))."""
+    objects from the configs alone (any state dict of the right shapes, e.g. engine.random_state_dict(config), or the
+    constructors' lazily zero-filled arenas): only the tensor SHAPES must agree, which the configs determine."""
     global LAST_BROADCAST_CALLS
     t = broadcast_weights(unet_engine, src)
     if not dist.is_initialized() or dist.get_world_size() == 1:
