@@ -32,8 +32,11 @@ __device__ long long g_attn_times[4 * 8];
 // RAGGED (self-attention only): NK is not a multiple of the key tile (token grids like 12x12 or 20x20): the last tile re-reads
 // clamped rows / 8-key chunks (always valid memory of this batch entry) and masks the keys >= NK.  NK % 8 == 0 is required so
 // that the 16-B V^T chunks of every batch entry stay aligned.
-template <int DP, int KT, bool CROSS, bool RAGGED = false>
-__global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
+// NW = waves per workgroup (4 or 8): every wave owns 32 queries and all of them share the staged K / V^T tiles, so an 8-wave
+// workgroup issues half the LDS-DMA pieces per query (2 instead of 4 per wave and 64-key tile) and halves the L2 -> LDS bytes.
+template <int DP, int KT, bool CROSS, bool RAGGED = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
+    constexpr int NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE = KT * DP * 2;          // bytes of one K (or V^T) tile
     constexpr int STAGE = 2 * TILE;
@@ -55,14 +58,14 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
         bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
         const int qb = bid % p.nqb; bid /= p.nqb;          // order (head, batch entry, query block): streams that attend with the
         b = bid % p.B; h = bid / p.B;                          // same Q/K source (injection) are neighbours and share K in L2 too
-        q0 = qb * 128;
+        q0 = qb * (32 * NW);
     }
     const int qb = p.q_src[b], kb = p.k_src[b], vb = p.v_src[b];
 
     float* wl = (float*)(smem + 2 * STAGE);    // cross: [2][KT] multipliers
     if (CROSS) {
         const int ws = p.wset[b];
-        for (int i = tid; i < KT; i += 256) {
+        for (int i = tid; i < KT; i += NT) {
             wl[i] = p.wabs[ws * p.NK + i];
             wl[KT + i] = p.wsgn[ws * p.NK + i];
         }
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
         char* ks_ = smem + s * STAGE;
         char* vs_ = ks_ + TILE;
 #pragma unroll
-        for (int c0 = 0; c0 < NCH; c0 += 256) {
+        for (int c0 = 0; c0 < NCH; c0 += NT) {
             const int idx = c0 + tid;
             if (idx < NCH) {   // wave-uniform: NCH % 64 == 0
                 const int rl = idx >> 2, ps = idx & 3;
@@ -242,21 +245,28 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     }
 }
 
-template <int DP, int KT, bool CROSS, bool RAGGED = false>
+template <int DP, int KT, bool CROSS, bool RAGGED = false, int NW = 4>
 static void launch_t(const AttnArgs& a, hipStream_t st) {
-    const size_t lds = 4 * (size_t)KT * DP * 2 + (CROSS ? 2 * KT * sizeof(float) : 0);
+    // K / V^T double buffer (+ the cross-attention multipliers); the epilogue reuses it as NW slabs of 32 x (DP*2 + 16) bytes
+    size_t lds = 4 * (size_t)KT * DP * 2 + (CROSS ? 2 * KT * sizeof(float) : 0);
+    const size_t slabs = (size_t)NW * 32 * (DP * 2 + 16);
+    if (slabs > lds) lds = slabs;
     static bool attr = false;
     if (!attr) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)attn_kernel<DP, KT, CROSS, RAGGED>,
+        HIP_CHECK(hipFuncSetAttribute((const void*)attn_kernel<DP, KT, CROSS, RAGGED, NW>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
     AttnArgs aa = a;
-    aa.nqb = cdiv(a.N, 128);
-    dim3 grid(aa.nqb * a.H * a.B), block(256);
-    hipLaunchKernelGGL((attn_kernel<DP, KT, CROSS, RAGGED>), grid, block, lds, st, aa);
+    aa.nqb = cdiv(a.N, 32 * NW);
+    dim3 grid(aa.nqb * a.H * a.B), block(NW * 64);
+    hipLaunchKernelGGL((attn_kernel<DP, KT, CROSS, RAGGED, NW>), grid, block, lds, st, aa);
     HIP_CHECK(hipGetLastError());
 }
+
+#ifdef RT_PROBE
+int g_attn_nw = 0;          // probe override: 4 or 8 waves per workgroup for the d = 64 self-attention kernel
+#endif
 
 void launch_attention(const AttnArgs& a, hipStream_t st) {
     RT_REQUIRE(a.B >= 1 && a.B <= RT_MAXB, "attention: batch must be in [1,16]");
@@ -275,9 +285,22 @@ void launch_attention(const AttnArgs& a, hipStream_t st) {
     } else {
         RT_REQUIRE(a.NK % 8 == 0 && a.NK >= 8, "self-attention: key count must be a multiple of 8");
         const bool ragged = a.NK % 64 != 0;
+        // 256-query workgroups (NW = 8) halve the LDS-DMA pieces per query but measured 751 vs 802 TFLOP/s in the engine and
+        // 908 vs 941 / 642 vs 694 stand-alone (N = 4096 / 1024): the kernel is bound by its softmax VALU work, not by the K / V^T
+        // fill, and an 8-wave barrier costs more than the saved copies.  Kept for the probe only.
+        bool wide = false; (void)wide;
+#ifdef RT_PROBE
+        if (g_attn_nw) wide = g_attn_nw == 8;
+#endif
         switch (a.DP) {
             case 32: ragged ? launch_t<32, 64, false, true>(a, st) : launch_t<32, 64, false>(a, st); break;
-            case 64: ragged ? launch_t<64, 64, false, true>(a, st) : launch_t<64, 64, false>(a, st); break;
+            case 64:
+                if (ragged) launch_t<64, 64, false, true>(a, st);
+#ifdef RT_PROBE
+                else if (wide) launch_t<64, 64, false, false, 8>(a, st);
+#endif
+                else launch_t<64, 64, false>(a, st);
+                break;
             case 96: ragged ? launch_t<96, 64, false, true>(a, st) : launch_t<96, 64, false>(a, st); break;
             case 160: ragged ? launch_t<160, 64, false, true>(a, st) : launch_t<160, 64, false>(a, st); break;
             default: throw rt_error(RT_E_UNSUPPORTED, "attention: unsupported padded head dim");

@@ -123,6 +123,10 @@ struct GroupNormArgs {
     bf16_t* raw_out;                   // optional: un-normalised bf16 copy of the (concatenated) input
     float* partial;                    // workspace [B, nchunk, G, 2]
     int nchunk, rows_per_chunk;        // from groupnorm_nchunk / groupnorm_rows_per_chunk
+    int fuse_finalize;                 // 1 (UNet forward, nchunk <= 128): every block of the apply kernel reduces the per-chunk partials
+                                       // itself (one launch fewer; `partial` keeps the RAW sums).  0: gn_finalize_kernel leaves
+                                       // (mean, rstd) in chunk 0's slot, which the VAE backward reads.
+    double fin_n;                      // set by launch_groupnorm: elements per group
 };
 int groupnorm_rows_per_chunk(int HW);
 void launch_groupnorm(const GroupNormArgs& a, hipStream_t st);
@@ -140,6 +144,7 @@ struct TembEntry { const bf16_t* W; const float* bias; int N; int first; long ou
 void launch_temb_all(const float* emb, int lde, float* silu_scratch, const TembEntry* tab, int ntab, int total, int B, int K, float* out,
                      hipStream_t st);
 void launch_timestep_embed(const float* t, int n, int dim, float* out, int ldo, hipStream_t st);
+void launch_timestep_embed_scalar(float t, int dim, float* out, hipStream_t st);
 // CLIP text encoder pieces (text.hip)
 void launch_embed(const int* ids, const float* tok, const float* pos, float* out, int rows, int N, int C, int vocab, hipStream_t st);
 void launch_activation(const bf16_t* x, bf16_t* out, size_t n, int kind, hipStream_t st);      // 0 quick_gelu, 1 gelu(erf)

@@ -73,18 +73,24 @@ void launch_pack(const PackArgs& a, hipStream_t st) {
 // ---------------------------------------------------------------- sinusoidal embedding
 // diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): [cos(t f_j) | sin(t f_j)]
 // (reference call sites: models/unet_2d_condition.py:784,849)
-__global__ void timestep_embed_kernel(const float* __restrict__ t, int n, int dim, float* __restrict__ out, int ldo) {
+// `t` == nullptr: one row whose timestep is the kernel ARGUMENT tval (the per-step scalar of the UNet forward travels with the
+// launch instead of through a 4-byte pageable host-to-device copy, which the runtime stages synchronously).
+__global__ void timestep_embed_kernel(const float* __restrict__ t, float tval, int n, int dim, float* __restrict__ out, int ldo) {
     const int half = dim >> 1;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n * dim; i += gridDim.x * blockDim.x) {
         const int r = i / dim, j = i % dim;
         const int jj = j < half ? j : j - half;
         const float f = expf(-9.210340371976184f * (float)jj / (float)half);
-        const float a = t[r] * f;
+        const float a = (t ? t[r] : tval) * f;
         out[(size_t)r * ldo + j] = j < half ? cosf(a) : sinf(a);
     }
 }
 void launch_timestep_embed(const float* t, int n, int dim, float* out, int ldo, hipStream_t st) {
-    hipLaunchKernelGGL(timestep_embed_kernel, dim3(cdiv(n * dim, 256)), dim3(256), 0, st, t, n, dim, out, ldo);
+    hipLaunchKernelGGL(timestep_embed_kernel, dim3(cdiv(n * dim, 256)), dim3(256), 0, st, t, 0.f, n, dim, out, ldo);
+    HIP_CHECK(hipGetLastError());
+}
+void launch_timestep_embed_scalar(float t, int dim, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(timestep_embed_kernel, dim3(cdiv(dim, 256)), dim3(256), 0, st, (const float*)nullptr, t, 1, dim, out, dim);
     HIP_CHECK(hipGetLastError());
 }
 

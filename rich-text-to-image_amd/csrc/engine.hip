@@ -426,6 +426,7 @@ struct rt_engine {
         GroupNormArgs a{}; a.x1 = x1; a.x2 = x2; a.in_bf16 = in_type; a.C1 = C1; a.C2 = C2; a.G = cfg.norm_groups; a.B = B;
         a.HW = HW; a.gamma = n.g; a.beta = n.b; a.eps = eps_; a.silu = silu; a.out = out; a.raw_out = raw;
         a.partial = partial; a.nchunk = nchunk; a.rows_per_chunk = groupnorm_rows_per_chunk(HW);
+        a.fuse_finalize = 1;
         launch_groupnorm(a, stream);
     }
     void layernorm(const f16_t* x, const NormW& n, bf16_t* out, int rows) {
@@ -576,11 +577,10 @@ struct rt_engine {
         float* emb = ws.f32((size_t)B * temb_dim);
         {
             Scope sc(ws);
-            float* tv = ws.f32(4); float* tsin = ws.f32(cfg.block_out_channels[0]);
+            float* tsin = ws.f32(cfg.block_out_channels[0]);
             float* e1 = ws.f32(temb_dim); float* e2 = ws.f32(temb_dim);
             if (!dry()) {
-                HIP_CHECK(hipMemcpyAsync(tv, &in.t, 4, hipMemcpyHostToDevice, stream));
-                launch_timestep_embed(tv, 1, cfg.block_out_channels[0], tsin, cfg.block_out_channels[0], stream);
+                launch_timestep_embed_scalar(in.t, cfg.block_out_channels[0], tsin, stream);
                 launch_small_linear(tsin, cfg.block_out_channels[0], t1.w, t1.K, t1.b, e1, temb_dim, 1, temb_dim, t1.K, 0, 0, stream);
                 launch_small_linear(e1, temb_dim, t2.w, t2.K, t2.b, e2, temb_dim, 1, temb_dim, temb_dim, 1, 0, stream);
                 launch_gather_add_rows(e2, aug_emb, in.prompt, emb, B, temb_dim, stream);
@@ -1078,7 +1078,7 @@ int rt_op_groupnorm(const void* x1, const void* x2, int in_bf16, int C1, int C2,
         a.nchunk = groupnorm_nchunk(HW); a.rows_per_chunk = groupnorm_rows_per_chunk(HW);
         float* partial = nullptr;
         HIP_CHECK(hipMalloc((void**)&partial, (size_t)B * a.nchunk * G * 2 * 4));
-        a.partial = partial;
+        a.partial = partial; a.fuse_finalize = 1;               // the path the UNet forward takes
         launch_groupnorm(a, (hipStream_t)stream);
         HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
         HIP_CHECK(hipFree(partial));

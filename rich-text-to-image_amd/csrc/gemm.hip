@@ -28,6 +28,7 @@
 // materialised): K index = tap*Cin + c.
 #include "common.h"
 #include <algorithm>
+#include <cmath>
 #include <map>
 #include <tuple>
 #include <type_traits>
@@ -311,11 +312,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
 
     // one K tile: wait for it, barrier, then (reads ks+1 | DMA issue of tile kt+S-1 | MFMA ks) per k-step.
     // MORE / LAST are compile-time so the loop body is straight-line code (no control flow between MFMAs).
-    auto ktile = [&](int kt, auto more_c, auto last_c) {
+    auto ktile = [&](int kt, auto more_c, auto behind_c) {
         constexpr bool MORE = decltype(more_c)::value;     // another tile will be staged during this one
-        constexpr bool LAST = decltype(last_c)::value;     // nothing stays in flight behind tile kt
-        if (S == 3 && !LAST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        constexpr int BEHIND = decltype(behind_c)::value;  // tiles that stay in flight behind tile kt (0 .. S-2)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BEHIND * P) : "memory");
         __builtin_amdgcn_s_barrier();            // every wave's part of tile kt is in LDS; ring slot (kt-1)%S is free
         __builtin_amdgcn_sched_barrier(0);
         const int ns = (kt + S - 1) % S, nk0 = KMAP(kt + S - 1);
@@ -352,10 +352,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
             __builtin_amdgcn_sched_barrier(0);   // keep the (reads ks+1 | DMA issue | MFMA ks) grouping
         }
     };
+    static_assert(S >= 2 && S <= 4 && (S - 2) * P <= 63, "ring depth");
     int kt = 0;
-    for (; kt + S - 1 < nk; ++kt) ktile(kt, std::true_type{}, std::false_type{});
-    for (; kt + 1 < nk; ++kt) ktile(kt, std::false_type{}, std::false_type{});
-    for (; kt < nk; ++kt) ktile(kt, std::false_type{}, std::true_type{});
+    for (; kt + S - 1 < nk; ++kt) ktile(kt, std::true_type{}, std::integral_constant<int, S - 2>{});
+    // drain: tile kt has min(S - 2, nk - 1 - kt) younger tiles in flight
+    if (S >= 4) for (; kt + 2 < nk; ++kt) ktile(kt, std::false_type{}, std::integral_constant<int, (S >= 4 ? 2 : 0)>{});
+    if (S >= 3) for (; kt + 1 < nk; ++kt) ktile(kt, std::false_type{}, std::integral_constant<int, (S >= 3 ? 1 : 0)>{});
+    for (; kt < nk; ++kt) ktile(kt, std::false_type{}, std::integral_constant<int, 0>{});
     __syncthreads();      // every wave is done with the LDS ring: it becomes the epilogue's transpose slabs
     if (gridDim.y > 1) {
         GemmArgs q = p;       // partial [split][M][ldo] fp32 (the launcher passes EPI_F32 without bias / residual)
@@ -917,10 +920,13 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
 // Requirements: mode A_CONV3 (stride 1, pad 1), H % 16 == 0, W % 16 == 0, Cin % 64 == 0.
 // UP2: the nearest-2x upsample of Upsample2D (resnet.py:137-172) folded in: the 16x16 OUTPUT patch reads a 10x10 input halo
 // (input pixel = output pixel >> 1), so the halo is 100 rows instead of 324.
-template <int EPI, bool UP2>
+// TN = 32-channel column tiles per workgroup (BN = 32 TN output channels): 5 by default; 3 or 2 when a launch would otherwise put
+// fewer workgroups on the chip than it has CUs (SD-v1.5: 48-160 workgroups at BN = 160).  The k order does not depend on TN, so
+// every TN gives bit-identical results and the launcher may pick it from the actual batch size.
+template <int EPI, bool UP2, int TN = 5>
 __global__ __launch_bounds__(512) void conv3p_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int BN = 160, NW = 8, TN = 5;
+    constexpr int BN = 32 * TN, NW = 8;
     constexpr int HW_ = UP2 ? 10 : 18;                                    // halo width (input pixels)
     constexpr int HROWS = UP2 ? 104 : 328, ASLOT = HROWS * 128, BSLOT = BN * 128;
     constexpr int GA = HROWS / 8, GB = BN / 8;
@@ -1006,14 +1012,15 @@ __global__ __launch_bounds__(512) void conv3p_kernel(GemmArgs p) {
 
     const int nc = p.Cin >> 6;
     const int nsteps = nc * 9;
-    auto wait_vm = [&](int n) {                     // n is wave-uniform
+    auto wait_vm = [&](int n) {                     // n is wave-uniform: 0, 1, NB, NB + 1 or 2 NB
         if (n >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
-    static_assert(NB == 3, "wait_vm is written for 3 W pieces (+1 halo piece) per wave and step");
+    static_assert(NB >= 1 && NB <= 3, "wait_vm covers up to 3 W pieces (+1 halo piece) per wave and step");
     // prologue: whole halo of chunk 0, W tiles of steps 0..2 (nsteps >= 9); halo + W(0) must have landed
 #pragma unroll
     for (int i = 0; i < NAH; ++i) stage_halo(0, 0, i);
@@ -1209,18 +1216,45 @@ static void launch_with_cfg(const GemmArgs& a, int cfg, hipStream_t st) {
 // configurations are bit-identical in their results, tuning never changes outputs.
 static int g_force_cfg = -1;
 static int g_conv_patch = 1;
+#ifdef RT_PROBE
+int g_conv3p_tn = 0;          // probe override of the patch kernel's column-tile count
+#endif
 void gemm_set_debug(int flags) { g_conv_patch = (flags & 1) ? 0 : 1; }   // bit 0: route eligible convs through the implicit-GEMM kernels (A/B tests)
 
-template <int EPI, bool UP2>
-static void launch_conv3p(const GemmArgs& a, hipStream_t st) {
-    constexpr int LDS = 2 * (UP2 ? 104 : 328) * 128 + 3 * 160 * 128;
+template <int EPI, bool UP2, int TN>
+static void launch_conv3p_tn(const GemmArgs& a, int ntm, hipStream_t st) {
+    constexpr int LDS = 2 * (UP2 ? 104 : 328) * 128 + 3 * 32 * TN * 128;
     static bool attr = false;
     if (!attr) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)conv3p_kernel<EPI, UP2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        HIP_CHECK(hipFuncSetAttribute((const void*)conv3p_kernel<EPI, UP2, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr = true;
     }
+    hipLaunchKernelGGL((conv3p_kernel<EPI, UP2, TN>), dim3(ntm * cdiv(a.N, 32 * TN)), dim3(512), LDS, st, a);
+}
+template <int EPI, bool UP2>
+static void launch_conv3p(const GemmArgs& a, hipStream_t st) {
     const int ntm = (a.M / a.rows_per_batch) * (a.Hout / 16) * (a.Wout / 16);
-    hipLaunchKernelGGL((conv3p_kernel<EPI, UP2>), dim3(ntm * cdiv(a.N, 160)), dim3(512), LDS, st, a);
+    // Narrower column tiles when 160-channel tiles leave CUs idle or start a mostly empty second round (one workgroup per CU: 145 KB
+    // of LDS).  Cost model fitted to tools/probes/conv_bench.hip on MI355X: a 96- / 64-channel workgroup takes 0.72 / 0.55 of a
+    // 160-channel one; the big workgroups pay whole rounds of 256, the 64-channel ones about half of the rounding.  Results do not
+    // depend on TN (same k order), so the choice may follow the actual batch size.
+    auto cost = [&](int tn_, double c) {
+        const double r = (double)ntm * cdiv(a.N, 32 * tn_) / 256.0;
+        if (r <= 1.0) return c;
+        const double up = std::ceil(r);
+        return c * (tn_ == 2 ? r + 0.5 * (up - r) : up);
+    };
+    const double c5 = cost(5, 1.0), c3 = cost(3, 0.72), c2 = cost(2, 0.55);
+    int tn = 5;
+    double best = c5;
+    if (c3 < best * 0.97) { tn = 3; best = c3; }
+    if (c2 < best * 0.97) { tn = 2; best = c2; }
+#ifdef RT_PROBE
+    if (g_conv3p_tn) tn = g_conv3p_tn;
+#endif
+    if (tn == 2) launch_conv3p_tn<EPI, UP2, 2>(a, ntm, st);
+    else if (tn == 3) launch_conv3p_tn<EPI, UP2, 3>(a, ntm, st);
+    else launch_conv3p_tn<EPI, UP2, 5>(a, ntm, st);
 }
 static bool conv_patch_eligible(const GemmArgs& a) {
     if (!g_conv_patch || a.mode == A_DENSE || a.rows_per_batch <= 0 || a.Hout % 16 || a.Wout % 16 || a.Cin % 64 || a.M % a.rows_per_batch) return false;
@@ -1361,7 +1395,10 @@ static void launch_gemm_splitk(const GemmArgs& a, int S, hipStream_t st) {
     GemmArgs g = a;
     g.epi = EPI_F32; g.bias = nullptr; g.res = nullptr; g.temb = nullptr; g.out = buf; g.ldo = ldp;
     {
-        constexpr int BM = 128, BN = 128, SS = 2;
+        // 4-deep ring: a slice's workgroup runs alone on its CU and streams cold weights, so the K tiles in flight (3 instead of 1)
+        // are what hides the HBM latency (config 1, 2-deep ring: the 8x8 / 16x16 convolutions ran at 0.4 TB/s of weight traffic;
+        // 99.9 -> 108.7 steps/s with 4 slots, same with 3 slots or with twice the slices on 2 slots)
+        constexpr int BM = 128, BN = 128, SS = 4;
         const size_t lds = (size_t)SS * (BM + BN) * BK * 2;
         dim3 grid(cdiv(a.M, BM) * cdiv(a.N, BN), S), block(256);
 #define RT_SPLIT_LAUNCH(MODE_)                                                                                                    \

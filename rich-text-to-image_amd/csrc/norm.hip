@@ -159,7 +159,29 @@ __global__ __launch_bounds__(512) void gn_apply_kernel(GroupNormArgs p) {
     __shared__ float mean[32], rstd[32];
     const int C = p.C1 + p.C2, cpg = C / p.G, nv = C / VW;
     const int b = blockIdx.y, chunk = blockIdx.x;
-    if (threadIdx.x < p.G) {
+    if (p.fuse_finalize) {
+        // raw per-chunk (sum, sumsq): 16 threads per group sum every 16th chunk in fp64, thread g adds the 16 pieces in a fixed
+        // order => deterministic and independent of the batch size; same (mean, rstd) arithmetic as gn_finalize_kernel mode 0
+        __shared__ double fs[32 * 16], fq[32 * 16];
+        for (int idx = threadIdx.x; idx < p.G * 16; idx += blockDim.x) {
+            const int g = idx >> 4, j = idx & 15;
+            double s = 0.0, q = 0.0;
+            for (int k = j; k < p.nchunk; k += 16) {
+                const float2 sq = *(const float2*)(p.partial + ((size_t)b * p.nchunk + k) * 2 * p.G + 2 * g);
+                s += (double)sq.x; q += (double)sq.y;
+            }
+            fs[idx] = s; fq[idx] = q;
+        }
+        __syncthreads();
+        if (threadIdx.x < p.G) {
+            double s = 0.0, q = 0.0;
+            for (int j = 0; j < 16; ++j) { s += fs[threadIdx.x * 16 + j]; q += fq[threadIdx.x * 16 + j]; }
+            const double mu = s / p.fin_n;
+            double var = q / p.fin_n - mu * mu;
+            if (var < 0) var = 0;
+            mean[threadIdx.x] = (float)mu; rstd[threadIdx.x] = (float)(1.0 / sqrt(var + (double)p.eps));
+        }
+    } else if (threadIdx.x < p.G) {
         mean[threadIdx.x] = p.partial[(size_t)b * p.nchunk * 2 * p.G + 2 * threadIdx.x];
         rstd[threadIdx.x] = p.partial[(size_t)b * p.nchunk * 2 * p.G + 2 * threadIdx.x + 1];
     }
@@ -216,12 +238,15 @@ void launch_groupnorm(const GroupNormArgs& a, hipStream_t st) {
     const bool wide = a.C1 % 8 == 0 && a.C2 % 8 == 0;               // 8 channels per thread in the apply pass
     const GnShape sh8 = gn_block_shape(C >> 3);
     dim3 block8(sh8.tcols * sh8.nrl);
+    GroupNormArgs aa = a;
+    aa.fuse_finalize = a.fuse_finalize && a.nchunk <= 128;
+    aa.fin_n = n;
 #define RT_GN_LAUNCH(IT)                                                                                  \
     {                                                                                                         \
-        hipLaunchKernelGGL(gn_stats_kernel<IT>, grid, block, 0, st, a);                                       \
-        launch_gn_finalize(a.partial, a.B, a.nchunk, a.G, n, a.eps, 0, st);                                   \
-        if (wide) hipLaunchKernelGGL((gn_apply_kernel<IT, 8>), grid, block8, 0, st, a);                       \
-        else hipLaunchKernelGGL((gn_apply_kernel<IT, 4>), grid, block, 0, st, a);                             \
+        hipLaunchKernelGGL(gn_stats_kernel<IT>, grid, block, 0, st, aa);                                      \
+        if (!aa.fuse_finalize) launch_gn_finalize(a.partial, a.B, a.nchunk, a.G, n, a.eps, 0, st);            \
+        if (wide) hipLaunchKernelGGL((gn_apply_kernel<IT, 8>), grid, block8, 0, st, aa);                      \
+        else hipLaunchKernelGGL((gn_apply_kernel<IT, 4>), grid, block, 0, st, aa);                            \
     }
     if (a.in_bf16 == 1) RT_GN_LAUNCH(1) else if (a.in_bf16 == 2) RT_GN_LAUNCH(2) else RT_GN_LAUNCH(0)
 #undef RT_GN_LAUNCH

@@ -21,6 +21,15 @@ def main(db_path, lo=0.45, hi=0.7):
         print(f"{100.0 * t / busy:6.2f} %  calls {c:6d}  avg {t / c / 1e3:8.1f} us  {name[:100]}")
     big = [g for g in gaps if g > 20000]
     print(f"gaps > 20 us: {len(big)} totalling {sum(big) / 1e6:.2f} ms")
+    # which kernel pairs sit either side of the long gaps (host synchronisation points show up here)
+    where = {}
+    for i in range(len(rows) - 1):
+        g = rows[i + 1][0] - rows[i][1]
+        if g > 20000:
+            k = (rows[i][2][:48], rows[i + 1][2][:48])
+            a = where.setdefault(k, [0, 0]); a[0] += 1; a[1] += g
+    for (a_, b_), (c, t) in sorted(where.items(), key=lambda kv: -kv[1][1])[:8]:
+        print(f"   {c:4d} gaps {t / 1e6:8.2f} ms  after [{a_}]  before [{b_}]")
     print(f"kernels {len(rows)}  span {span / 1e6:.2f} ms  busy {busy / 1e6:.2f} ms ({100.0 * busy / span:.1f} %)  "
           f"gap total {sum(gaps) / 1e6:.2f} ms  median {gaps[n // 2] / 1e3:.2f} us  p90 {gaps[int(n * 0.9)] / 1e3:.2f} us  max {gaps[-1] / 1e3:.1f} us")
 

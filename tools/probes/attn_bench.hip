@@ -1,4 +1,4 @@
-// Stand-alone self-attention timing (+ per-segment s_memtime breakdown with -DRT_ATTN_TIMING) for the two SDXL shapes.
+// Build with -DRT_PROBE.  Stand-alone self-attention timing (+ per-segment s_memtime breakdown with -DRT_ATTN_TIMING) for the two SDXL shapes.
 #include "../../rich-text-to-image_amd/csrc/attention.hip"
 #include <vector>
 int main() {
@@ -11,7 +11,9 @@ int main() {
       for (bf16_t* dst : {Q, K, VT}) { for (auto& v : h) { x = x * 1664525u + 1013904223u; v = (uint16_t)(0x3c00 | ((x >> 9) & 0x83ff) | ((x >> 3) & 0x8000)); }
         hipMemcpy(dst, h.data(), h.size() * 2, hipMemcpyHostToDevice); } }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int nw : {4, 8, 4, 8})
     for (auto sh : shs) {
+        g_attn_nw = nw;
         AttnArgs a{}; a.Q = Q; a.ldq = sh.H * DP; a.K = K; a.ldk = sh.H * DP; a.VT = VT; a.ldvt = sh.B * sh.N; a.O = O; a.ldo = sh.H * DP;
         for (int b = 0; b < sh.B; ++b) { a.q_src[b] = a.k_src[b] = a.v_src[b] = b; a.wset[b] = 0; }
         a.B = sh.B; a.H = sh.H; a.N = sh.N; a.NK = sh.N; a.nk_valid = sh.N; a.DP = DP; a.cross = 0;
@@ -20,7 +22,7 @@ int main() {
         for (int r = 0; r < 20; ++r) launch_attention(a, 0);
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
-        printf("self-attn B%d H%d N%d d64: %7.1f us %6.0f TF\n", sh.B, sh.H, sh.N, ms / 20 * 1e3, 4.0 * sh.B * sh.H * (double)sh.N * sh.N * 64 / (ms / 20 * 1e-3) / 1e12);
+        printf("self-attn %d waves/WG B%d H%d N%d d64: %7.1f us %6.0f TF\n", nw, sh.B, sh.H, sh.N, ms / 20 * 1e3, 4.0 * sh.B * sh.H * (double)sh.N * sh.N * 64 / (ms / 20 * 1e-3) / 1e12);
 #ifdef RT_ATTN_TIMING
         long long t[32]; hipMemcpyFromSymbol(t, HIP_SYMBOL(g_attn_times), sizeof(t));
         const double nt = sh.N / 64.0;
