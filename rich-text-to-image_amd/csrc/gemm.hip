@@ -1236,13 +1236,13 @@ static void launch_conv3p(const GemmArgs& a, hipStream_t st) {
     const int ntm = (a.M / a.rows_per_batch) * (a.Hout / 16) * (a.Wout / 16);
     // Narrower column tiles when 160-channel tiles leave CUs idle or start a mostly empty second round (one workgroup per CU: 145 KB
     // of LDS).  Cost model fitted to tools/probes/conv_bench.hip on MI355X: a 96- / 64-channel workgroup takes 0.72 / 0.55 of a
-    // 160-channel one; the big workgroups pay whole rounds of 256, the 64-channel ones about half of the rounding.  Results do not
+    // 160-channel one; the big workgroups pay whole rounds of 256, the 64-channel ones 0.4 of the rounding.  Results do not
     // depend on TN (same k order), so the choice may follow the actual batch size.
     auto cost = [&](int tn_, double c) {
         const double r = (double)ntm * cdiv(a.N, 32 * tn_) / 256.0;
         if (r <= 1.0) return c;
         const double up = std::ceil(r);
-        return c * (tn_ == 2 ? r + 0.5 * (up - r) : up);
+        return c * (tn_ == 2 ? r + 0.4 * (up - r) : up);
     };
     const double c5 = cost(5, 1.0), c3 = cost(3, 0.72), c2 = cost(2, 0.55);
     int tn = 5;

@@ -180,6 +180,22 @@ def test_conv3x3_patch_kernel(B, H, W_, Cin, Cout, epi):
     report("patch conv vs implicit GEMM", out, old, atol=1e-4 if epi == 1 else 2e-2, rtol=1e-4 if epi == 1 else 1e-2)
 
 
+@pytest.mark.parametrize("H,Cin,Cout,small,big", [(64, 320, 320, 2, 7), (32, 640, 640, 4, 7), (32, 1280, 1280, 5, 7)])
+def test_conv3x3_patch_kernel_column_tilings_are_bit_identical(H, Cin, Cout, small, big):
+    """The launcher narrows the patch kernel's column tile (160 -> 96 / 64 channels) when a launch would leave CUs idle, so the
+    tiling follows the batch size; the k order does not, hence an image must convolve to the same bits alone or in a larger batch
+    (64x64x320: 2 images -> 64-channel tiles, 7 -> 160; 32x32x640: 4 -> 64, 7 -> 96; 32x32x1280: 5 -> 64, 7 -> 160)."""
+    x = rnd(big, Cin, H, H, seed=30)
+    w = rnd(Cout, Cin, 3, 3, seed=31, scale=(9 * Cin) ** -0.5)
+    bias = rnd(Cout, seed=32)
+    A, Wp = bf(x.permute(0, 2, 3, 1)), bf(_conv_weight_packed(w))
+    full = gemm(A, Wp, bias.to(DEV), epi=0, mode=1, conv=(H, H))
+    part = gemm(A[:small].contiguous(), Wp, bias.to(DEV), epi=0, mode=1, conv=(H, H))
+    assert torch.equal(full[: small * H * H], part)
+    ref = F.conv2d(x[:1].to(torch.bfloat16).float().to(DEV), w.to(torch.bfloat16).float().to(DEV), bias.to(DEV), padding=1).permute(0, 2, 3, 1)
+    report(f"patch conv {H}x{H}x{Cin}->{Cout} vs torch", full[: H * H].reshape(1, H, H, Cout), ref, **BF16_OUT)
+
+
 @pytest.mark.parametrize("B,H,W_,Cin,Cout", [(2, 16, 16, 64, 96), (1, 8, 24, 128, 200), (7, 32, 32, 1280, 1280)])
 def test_conv3x3_patch_kernel_upsample(B, H, W_, Cin, Cout):
     """Upsample2D folded into the patch kernel (10x10 input halo per 16x16 output patch) vs torch and vs the implicit-GEMM loader."""

@@ -40,5 +40,26 @@ int main() {
         for (int v = 1; v < 3; ++v) { hipMemcpy(h1.data(), out[v], nb * 2, hipMemcpyDeviceToHost); same = same && !memcmp(h0.data(), h1.data(), nb * 2); }
         printf("  %s\n", same ? "bit-identical" : "DIFFERENT");
     }
+    // 16x16 maps (SD-v1.5 level 2): the engine routes these through the split-K implicit GEMM (launch_gemm); compare with the patch kernel
+    struct Cv2 { int B, H, W, Cin, Cout; } c2[] = {{3, 16, 16, 1280, 1280}, {5, 16, 16, 1280, 1280}, {3, 16, 16, 2560, 1280}, {5, 16, 16, 2560, 1280}, {3, 16, 16, 640, 1280}};
+    float* of; hipMalloc(&of, (size_t)5 * 256 * 1280 * 4);
+    for (auto c : c2) {
+        GemmArgs g{}; g.A = A; g.W = W; g.zero = zero; g.mode = A_CONV3; g.epi = EPI_F32; g.bias = bias; g.out = of;
+        g.M = c.B * c.H * c.W; g.N = c.Cout; g.K = 9 * c.Cin; g.ldw = g.K; g.ldo = c.Cout; g.rows_per_batch = c.H * c.W;
+        g.Hin = g.Hout = c.H; g.Win = g.Wout = c.W; g.Cin = c.Cin;
+        g.split_tiles = cdiv(c.H * c.W, 128) * cdiv(c.Cout, 128);
+        printf("conv %dx%dx%dx%d->%d:", c.B, c.H, c.W, c.Cin, c.Cout);
+        for (int variant = 0; variant < 3; ++variant) {
+            g_conv3p_tn = variant == 1 ? 2 : 3;
+            auto run = [&]() { if (variant == 0) launch_gemm(g, 0); else launch_conv3p<EPI_F32, false>(g, 0); };
+            for (int r = 0; r < 3; ++r) run();
+            hipEventRecord(e0, 0);
+            for (int r = 0; r < 20; ++r) run();
+            hipEventRecord(e1, 0); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            printf("  %s %7.1f us %5.0f TF", variant == 0 ? "split-K (engine route)" : variant == 1 ? "patch TN2" : "patch TN3", ms / 20 * 1e3, 2.0 * g.M * g.N * g.K / (ms / 20 * 1e-3) / 1e12);
+        }
+        printf("\n");
+    }
     return 0;
 }
