@@ -130,7 +130,16 @@ class OracleUNet:
         return F.layer_norm(x, (x.shape[-1],), self.sd[name + ".weight"], self.sd[name + ".bias"], 1e-5)
 
     # ---- attention (attention_processor.py:476-545) -----------------------------------------
+    # `attn_impl(oracle, name, x, heads, ctx, fontsize, real_probs) -> (out, probs)`: optional replacement of the whole attention
+    # module (tests plug the product's AttnProcessor into this UNet the way set_attn_processor does in the reference)
+    attn_impl = None
+
     def _attention(self, name, x, heads, ctx=None, fontsize=None, real_probs=None, capture=None):
+        if self.attn_impl is not None:
+            o, probs = self.attn_impl(self, name, x, heads, ctx, fontsize, real_probs)
+            if capture is not None:
+                capture[name] = probs
+            return o, probs
         B, N, C = x.shape
         q = self._lin(x, name + ".to_q", bias=False)
         src = x if ctx is None else ctx

@@ -463,6 +463,61 @@ def test_attn_processor_seam_matches_reference_module_golden():
         proc(selfa, x2, real_attn_probs=torch.zeros(4, 128, 256, device=DEV))
 
 
+@pytest.mark.parametrize("which", ["xl", "sd"])
+def test_attn_processor_inside_a_unet_forward(which):
+    """The processor seam exercised the way the reference uses it (unet.set_attn_processor + the hook families of
+    region_diffusion*.py): EVERY attention module of a UNet forward goes through HipAttnProcessor - cross-attention with the
+    font-size dict, self-attention whose returned handle is captured on a `text_ref` forward and passed back as real_attn_probs on
+    a region forward - while everything else stays the fp32 oracle.  Reference: the same forwards with the oracle's own attention."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from oracle.unet import OracleUNet, TINY_SD_CONFIG, TINY_XL_CONFIG, random_state_dict
+    from rich_text_to_image_amd.attention_processor import HipAttnProcessor
+    xl = which == "xl"
+    cfg = TINY_XL_CONFIG if xl else TINY_SD_CONFIG
+    sd = random_state_dict(cfg, seed=11)
+    hw = 32
+    g = torch.Generator().manual_seed(77)
+    D = cfg["cross_attention_dim"]
+    emb = torch.randn(2, 77, D, generator=g)
+    pooled = torch.randn(2, 32, generator=g) if xl else None
+    tid = torch.tensor([[hw * 8.0, hw * 8.0, 0, 0, hw * 8.0, hw * 8.0]]) if xl else None
+    lat, lat_ref = torch.randn(1, 4, hw, hw, generator=g), torch.randn(1, 4, hw, hw, generator=g)
+    fsd = {"word_pos": torch.tensor([2, 6]), "font_size": torch.tensor([3.0, -1.5])}
+
+    def added(k):
+        return {"text_embeds": pooled[k:k + 1], "time_ids": tid} if xl else None
+
+    def run(o):
+        with torch.no_grad():
+            a = o.forward(lat, 500.0, emb[:1], added(0), ctl={"fontsize": fsd})
+            cap = {}
+            b = o.forward(lat_ref, 500.0, emb[1:2], added(1), ctl={"capture": cap})
+            inj = {k: v for k, v in cap.items() if k.endswith("attn1")}
+            c = o.forward(lat, 500.0, emb[1:2], added(1), ctl={"inject": inj})
+        return a, b, c
+    ref = run(OracleUNet(cfg, sd))
+
+    proc, mods, calls = HipAttnProcessor(), {}, {"self": 0, "cross": 0, "injected": 0}
+
+    def impl(o, name, x, heads, ctx, fontsize, real_probs):
+        if name not in mods:
+            lsd = {k[len(name) + 1:]: v for k, v in o.sd.items() if k.startswith(name + ".")}
+            mods[name] = _StubAttention(lsd, heads, cross_dim=None if ctx is None else ctx.shape[-1])
+        y, maps = proc(mods[name], x.to(DEV), real_attn_probs=real_probs, attn_weights=fontsize,
+                       encoder_hidden_states=None if ctx is None else ctx.to(DEV))
+        calls["cross" if ctx is not None else ("injected" if real_probs is not None else "self")] += 1
+        return y.float().cpu(), maps[1]                      # what the hooks keep: out[1][1] (rd.py:366,382 / xl.py:1064-1106)
+    o2 = OracleUNet(cfg, sd)
+    o2.attn_impl = impl
+    got = run(o2)
+    assert calls["self"] > 0 and calls["cross"] > 0 and calls["injected"] > 0 and calls["injected"] * 2 == calls["self"]
+    for name, a, b in zip(("font-size", "text_ref (captured)", "region (injected)"), got, ref):
+        r = ((a - b).pow(2).sum() / b.pow(2).sum()).sqrt().item()
+        print(f"{which} processor inside the UNet, {name}: rel-L2 {r:.3e}")
+        assert r < 1.5e-2, name
+
+
 def test_attn_processor_probs_avg_at_4096_tokens():
     """SDXL's first attention level has 64x64 = 4096 tokens and the XL token-map hook reads probs_avg of EVERY attn1 layer
     (region_diffusion_sdxl.py:980-992): the averaged map must exist there too (keys are processed in 1024-key chunks)."""
