@@ -112,17 +112,25 @@ def test_gemm_tile_configurations_are_bit_identical(cfg):
         lib.rt_op_gemm_force_config(-1)
 
 
-def test_gemm_autotune_keeps_inplace_residual_intact():
-    M, N, K = 2048, 1280, 640
+def test_gemm_in_situ_tuning_is_invisible():
+    """The tuner ranks the tile configurations on the real launches of a shape (each launch of a shape under tuning takes the next
+    configuration, bracketed by HIP events): 48 launches of one in-place-residual problem - more than 8 configurations x 4 samples -
+    must all give the same bits, before, while and after the shape settles (a shape no other test uses, so tuning starts here)."""
+    M, N, K = 4352, 1280, 704
     A, W = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=K ** -0.5))
     h0 = rnd(M, N, seed=4).to(DEV)
-    h = h0.clone()
     from rich_text_to_image_amd.engine import load_library, _ptr
     lib = load_library()
-    rc = lib.rt_op_gemm(_ptr(A), _ptr(W), None, _ptr(h), _ptr(h), None, 0, 1, M, N, K, K, K, N, N, 0, 0, 0, 0, 0, 0, 0, None)
-    assert rc == 0
+    outs = []
+    for _ in range(48):
+        h = h0.clone()
+        rc = lib.rt_op_gemm(_ptr(A), _ptr(W), None, _ptr(h), _ptr(h), None, 0, 1, M, N, K, K, K, N, N, 0, 0, 0, 0, 0, 0, 0, None)
+        assert rc == 0
+        outs.append(h)
     torch.cuda.synchronize()
-    report("in-place residual through autotune", h, A.float() @ W.float().t() + h0, **F32_OUT)
+    for h in outs[1:]:
+        assert torch.equal(h, outs[0])
+    report("in-place residual while the shape is being tuned", outs[0], A.float() @ W.float().t() + h0, **F32_OUT)
 
 
 def _conv_weight_packed(w):          # [Cout, Cin, 3, 3] -> [Cout, 9*Cin], K = tap*Cin + c
