@@ -1299,8 +1299,14 @@ struct Tuner {
         for (int c = 0; c < RT_NCFG; ++c) {
             if (!admissible(a, c)) continue;
             if (ts.n[c] < RT_TUNE_SAMPLES) return;
-            const float m = ts.ms[c] / ts.n[c];
-            if (m < best_ms) { best_ms = m; ts.best = c; }
+            best_ms = std::min(best_ms, ts.ms[c] / ts.n[c]);
+        }
+        // within 2 % of the best mean the configurations are indistinguishable in the step time (the chip runs power-limited,
+        // DESIGN.md 6.1): take the largest tile among them, which moves the fewest bytes through L2 / HBM per flop
+        int area = -1;
+        for (int c = 0; c < RT_NCFG; ++c) {
+            if (!admissible(a, c) || ts.ms[c] / ts.n[c] > best_ms * 1.02f) continue;
+            if (kCfg[c].BM * kCfg[c].BN > area) { area = kCfg[c].BM * kCfg[c].BN; ts.best = c; }
         }
     }
     void drain() {                                              // resolve the completed event pairs (stream order: stop at the first busy one)

@@ -1,4 +1,10 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_kernels_gpu.py -q -m gpu -k "in_situ or tile_configurations" 2>&1 | tail -3 > gpurun_out/r2r_tests.log
-bash tools/pmc_passes.sh r2f > gpurun_out/r2r_pmc.log 2>&1
-cat gpurun_out/r2r_tests.log; tail -3 gpurun_out/r2r_pmc.log
+for i in 1 2 3; do
+python bench.py --no-cpu-baseline > gpurun_out/r2t_new$i.json 2> gpurun_out/r2t.err
+(cd _head && python bench.py --no-cpu-baseline > ../gpurun_out/r2t_head$i.json 2>> ../gpurun_out/r2t.err)
+done
+python - <<'PY'
+import json
+for f in ['r2t_new1','r2t_head1','r2t_new2','r2t_head2','r2t_new3','r2t_head3']:
+    d=json.loads(open('gpurun_out/%s.json'%f).read().strip().splitlines()[-1]); print(f, round(d['ms_per_step'],3), round(d['roofline']['frac'],4), {k:round(v['total_ms'],2) for k,v in d['roofline']['per_kernel'].items()})
+PY
