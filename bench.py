@@ -154,7 +154,12 @@ def other_config(args):
             "finite": r["finite"],
             "roofline": {"bound": "mfma", "kernel": "whole step (UNet forwards + VAE guidance where configured)", "achieved": tf,
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_BF16_TFLOPS, "traffic": None},
-            "cpu_baseline": None}
+            "cpu_baseline": None,
+            # numerics of these workloads are pinned by the GPU tests, not inside this (timing-only) line
+            "parity": None,
+            "parity_tests": {1: "tests/test_fullsize_gpu.py::test_sd15_config1_rich_loop_matches_oracle (SD-v1.5 full architecture, PLMS loop vs the fp32 oracle)",
+                             2: "tests/test_fullsize_gpu.py::test_sd15_full_architecture_stream_modes_match_oracle + test_full_width_vae_decode_and_guidance_gradient_match_oracle",
+                             5: "tests/test_fullsize_gpu.py::test_sdxl_config3_rich_step_matches_oracle + test_full_width_vae_decode_and_guidance_gradient_match_oracle"}[args.config]}
     print(json.dumps(line), flush=True)
 
 
