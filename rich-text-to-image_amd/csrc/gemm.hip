@@ -20,6 +20,9 @@
 //     cfg 4: 256x160, 8 compute waves (8x1) + 4 LOADER waves, 3-slot ring (gemm_ws_kernel)
 //     cfg 5: 256x128, 8 compute waves (4x2) + 4 loader waves
 //     cfg 6: 256x160, 8 waves in two groups one barrier apart (gemm_pp_kernel): long-K problems
+//     cfg 7: 256x256, 8 waves (2x4), 8-phase half-tile pipeline (gemm8_kernel): dense, long K
+// The per-shape choice is made in situ on the real launches (Tuner below); under-filled problems go through split-K slices of the
+// 128x128 kernel with a 4-slot ring, eligible 3x3 convolutions through conv3p_kernel.
 // (A ping-pong variant with two wave groups half an iteration apart was measured and dropped: 3.2k cycles per
 //  K tile against 2.2k here, because the ~1.0k cycles of LDS-DMA issue sit in one of the two phases.)
 // All configurations accumulate every output element in the same k order with the same MFMA shape, so the
@@ -1301,7 +1304,7 @@ struct Tuner {
             if (ts.n[c] < RT_TUNE_SAMPLES) return;
             best_ms = std::min(best_ms, ts.ms[c] / ts.n[c]);
         }
-        // within 2 % of the best mean the configurations are indistinguishable in the step time (the chip runs power-limited,
+        // within 2 % of the best mean the configurations are indistinguishable in the step time (the clock is power-managed,
         // DESIGN.md 6.1): take the largest tile among them, which moves the fewest bytes through L2 / HBM per flop
         int area = -1;
         for (int c = 0; c < RT_NCFG; ++c) {
