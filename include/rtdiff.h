@@ -165,7 +165,7 @@ int rt_op_causal_attention(const void* q, const void* k, const void* v, int ld, 
 int rt_op_attention_probs_avg(const void* Q, int ldq, long long q_row0, const void* K, int ldk, long long k_row0, float* out,
                               int H, int N, int NK, int NKpad, int NKrows, int DP, int accumulate, void* stream);
 const char* rt_op_last_error(void);
-/* GEMM tile configuration: -1 = tuned per shape (default); 0..7 force one (tests / micro-benchmarks).
+/* GEMM tile configuration: -1 = tuned per shape (default); 0..8 force one (tests / micro-benchmarks).
  * All configurations give bit-identical results, which is what lets the tuner rank them on the REAL launches: while a shape is
  * being tuned, successive launches of it cycle through the configurations between pairs of HIP events (csrc/gemm.hip). */
 int rt_op_gemm_force_config(int cfg);

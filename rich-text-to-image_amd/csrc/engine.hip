@@ -1042,7 +1042,7 @@ static bf16_t* op_zero_page() {
 const char* rt_op_last_error(void) { return g_op_error.c_str(); }
 int rt_op_gemm_debug(int d) { gemm_set_debug(d); return RT_OK; }
 int rt_op_gemm_force_config(int cfg) {
-    if (cfg < -1 || cfg > 7) return RT_E_INVALID;
+    if (cfg < -1 || cfg > 8) return RT_E_INVALID;
     gemm_force_config(cfg);
     return RT_OK;
 }

@@ -21,6 +21,7 @@
 //     cfg 5: 256x128, 8 compute waves (4x2) + 4 loader waves
 //     cfg 6: 256x160, 8 waves in two groups one barrier apart (gemm_pp_kernel): long-K problems
 //     cfg 7: 256x256, 8 waves (2x4), 8-phase half-tile pipeline (gemm8_kernel): dense, long K
+//     cfg 8: 256x320, 8 waves (4x2, 64x160 each), 2 stages: N = 640 (28672x640x640 33.9 vs 38.0 us, x2560 99.9 vs 105-112 us)
 // The per-shape choice is made in situ on the real launches (Tuner below); under-filled problems go through split-K slices of the
 // 128x128 kernel with a 4-slot ring, eligible 3x3 convolutions through conv3p_kernel.
 // (A ping-pong variant with two wave groups half an iteration apart was measured and dropped: 3.2k cycles per
@@ -1102,9 +1103,10 @@ __global__ __launch_bounds__(512) void conv3p_kernel(GemmArgs p) {
 
 // ---------------------------------------------------------------------------------------------- launch
 struct TileCfg { int BM, BN, threads, stages, geglu_ok; };
-#define RT_NCFG 8
+#define RT_NCFG 9
 static const TileCfg kCfg[RT_NCFG] = {{128, 128, 256, 2, 1}, {256, 128, 512, 3, 1}, {256, 160, 512, 3, 0}, {256, 256, 1024, 2, 1},
-                                       {256, 160, 768, 3, 0}, {256, 128, 768, 3, 1}, {256, 160, 512, 3, 0}, {256, 256, 512, 2, 1}};
+                                       {256, 160, 768, 3, 0}, {256, 128, 768, 3, 1}, {256, 160, 512, 3, 0}, {256, 256, 512, 2, 1},
+                                       {256, 320, 512, 2, 0}};
 
 template <int MODE, int EPI, int BM, int BN, int WM, int WN, int S>
 static void launch_cfg(const GemmArgs& a, hipStream_t st) {
@@ -1182,9 +1184,9 @@ static void launch_me(const GemmArgs& a, int cfg, hipStream_t st) {
             if constexpr (MODE == A_DENSE) launch_g8<EPI>(a, st);
             else throw rt_error(RT_E_INVALID, "gemm: the 8-phase configuration is dense-only");
             break;
+        case 8: launch_cfg<MODE, EPI, 256, 320, 4, 2, 2>(a, st); break;      // 64x160 per wave: the N = 640 problems (2 column tiles, 224 workgroups at M = 28672)
 #ifdef RT_PROBE
-        case 8: launch_cfg<MODE, EPI, 256, 256, 2, 4, 2>(a, st); break;      // 8 waves, 128x64 per wave (ties cfg 3)
-        case 9: launch_cfg<MODE, EPI, 256, 320, 4, 2, 2>(a, st); break;      // 64x160 per wave, 142 flop/B through the copy path
+        case 9: launch_cfg<MODE, EPI, 256, 256, 2, 4, 2>(a, st); break;      // 8 waves, 128x64 per wave (ties cfg 3)
         case 10: launch_cfg<MODE, EPI, 128, 160, 4, 1, 2>(a, st); break;     // two workgroups per CU: pro/epilogues overlap the partner's loop
         case 11: launch_cfg<MODE, EPI, 128, 160, 4, 1, 3>(a, st); break;
 #endif

@@ -4,7 +4,7 @@
 #include <algorithm>
 #include <cstring>
 int main(int argc, char** argv) {
-    struct Shape { int M, N, K; } shapes[] = {{7168, 2560, 1280}, {28672, 1280, 640}, {7168, 10240, 1280}, {28672, 5120, 640}, {7168, 1280, 1280}, {7168, 1280, 5120}, {4096, 4096, 4096}, {8192, 8192, 8192}};
+    struct Shape { int M, N, K; } shapes[] = {{7168, 2560, 1280}, {28672, 1280, 640}, {7168, 10240, 1280}, {28672, 5120, 640}, {7168, 1280, 1280}, {7168, 1280, 5120}, {28672, 640, 640}, {28672, 640, 2560}, {4096, 4096, 4096}, {8192, 8192, 8192}};
     bf16_t *A, *W, *out, *zero;
     hipMalloc(&A, (size_t)28672 * 8192 * 2); hipMalloc(&W, (size_t)10240 * 8192 * 2); hipMalloc(&out, (size_t)28672 * 10240 * 2); hipMalloc(&zero, 256);
     // pseudo-random bf16 fill (values ~ +-1): data-dependent power/clock effects matter (guide 5.4 rule 25)
@@ -98,7 +98,7 @@ int main(int argc, char** argv) {
 #endif
     for (auto sh : shapes) {
         printf("%5dx%5dx%4d:", sh.M, sh.N, sh.K);
-        for (int cfg : {2, 3, 6, 7, 10, 11}) {
+        for (int cfg : {2, 9, 3, 7, 0, 1, 6}) {
             GemmArgs g{}; g.A = A; g.W = W; g.out = out; g.zero = zero; g.mode = A_DENSE; g.epi = EPI_BF16;
             g.M = sh.M; g.N = sh.N; g.K = sh.K; g.lda = sh.K; g.ldw = sh.K; g.ldo = sh.N;
             for (int r = 0; r < 3; ++r) launch_with_cfg(g, cfg, 0);
