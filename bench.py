@@ -11,7 +11,9 @@ A "step" is one iteration of the loop at models/region_diffusion_sdxl.py:779 (al
 CFG, scheduler step).  Every forward the reference executes is executed (no dead-forward elision).
 
   python bench.py --gpus N --steps K --warmup W
-N > 1: launched by torch.distributed.run, one rank per GPU; each rank runs an independent image (own seed,
+N > 1: one rank per GPU under torch.distributed.run - either launched that way by the caller (RANK / LOCAL_RANK / WORLD_SIZE in the
+environment) or, when `python bench.py --gpus N` is run bare, by re-executing itself under `python -m torch.distributed.run
+--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (launcher.self_launch).  Each rank runs an independent image (own seed,
 latents, masks, prompts) after ONE broadcast of the packed weight arena (RCCL); no per-step collectives;
 value = N*K / max-over-ranks time ("weak" scaling).
 """
@@ -163,6 +165,33 @@ def other_config(args):
     print(json.dumps(line), flush=True)
 
 
+def dry_launch(args):
+    """The N > 1 control path of this file without GPUs (tests/test_distributed_cpu.py): gloo rendezvous from the
+    torch.distributed.run environment, ONE broadcast of an arena-shaped byte buffer from rank 0, barrier, max-over-ranks, rank 0
+    prints the contract line with value = null."""
+    from rich_text_to_image_amd import launcher
+    rank, local_rank, world = launcher.init_distributed("gloo")
+    if world != args.gpus:
+        sys.exit(f"bench: --gpus {args.gpus} but the launch environment says WORLD_SIZE={world}")
+    arena = (torch.arange(1 << 16, dtype=torch.int64) % 251).to(torch.uint8) if rank == 0 else torch.zeros(1 << 16, dtype=torch.uint8)
+    t0 = time.perf_counter()
+    calls = launcher.broadcast_tensor(arena, src=0)
+    bcast_s = time.perf_counter() - t0
+    ok = bool(torch.equal(arena, (torch.arange(1 << 16, dtype=torch.int64) % 251).to(torch.uint8)))
+    launcher.barrier()
+    dt = launcher.max_over_ranks(1.0 + rank)
+    mine = launcher.shard_round_robin(list(range(2 * world)), rank, world)
+    if rank == 0:
+        print(json.dumps({"metric": "denoising steps/sec (SDXL 1024^2, 50-step, 4 regions)", "value": None, "unit": "steps/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_launch": True, "scaling": "weak",
+                          "weight_broadcast_calls": calls, "weight_broadcast_s": bcast_s, "arena_received": ok,
+                          "max_over_ranks": dt, "requests_rank0": mine}), flush=True)
+    if not ok:
+        sys.exit("bench: dry launch: broadcast payload mismatch")
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,6 +199,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--elide", action="store_true", help="skip reference forwards that cannot influence the output")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="exercise the multi-rank launch path only (rendezvous, one arena-sized broadcast, barrier, max-over-ranks) "
+                         "on the gloo backend without touching a GPU, and print the JSON line with value = null (CPU test of --gpus N)")
     ap.add_argument("--config", type=int, default=3, choices=[1, 2, 3, 5],
                     help="BASELINE.json configuration (SURVEY 8d numbering): 3 = the headline SDXL workload (default); "
                          "1 / 2 = SD-v1.5 (R=2 plain; R=4 + colour guidance); 5 = SDXL + colour guidance + background blend")
@@ -180,9 +212,19 @@ def main():
         return other_config(args)
 
     from rich_text_to_image_amd import launcher
+    err = launcher.self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus, require_gpus=not args.dry_launch)
+    if err is not None:
+        # not enough GPUs on this node: say so in the line the driver parses (no value) and on stderr
+        print(f"bench: {err}", file=sys.stderr)
+        print(json.dumps({"metric": "denoising steps/sec (SDXL 1024^2, 50-step, 4 regions)", "value": None, "unit": "steps/s",
+                          "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "error": err}), flush=True)
+        return
+    if args.dry_launch:
+        return dry_launch(args)
     from rich_text_to_image_amd.engine import Engine, SDXL_CONFIG
     rank, local_rank, world = launcher.init_distributed()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        sys.exit(f"bench: --gpus {args.gpus} but the launch environment says WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
 

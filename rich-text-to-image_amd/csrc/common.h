@@ -50,6 +50,16 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// gelu(x) = 0.5 x (1 + erf(x / sqrt 2)) with erf from Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 output
+// grid): one v_rcp + one v_exp + 7 FMAs instead of libm's branchy erff (the GEGLU epilogues run it on 32 values per lane and tile).
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float er = 1.f - poly * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);      // erf(|x| / sqrt 2)
+    return 0.5f * x + 0.5f * fabsf(x) * er;                                                   // x * 0.5 * (1 + sign(x) * er)
+}
+
 // async global -> LDS copy of 16 B per lane (LDS destination = wave-uniform base + lane*16)
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -75,13 +85,21 @@ struct GemmArgs {
     int rows_per_batch;              // Hout*Wout (conv and temb)
     int Hin, Win, Cin, Hout, Wout;   // conv geometry (Cin padded to a multiple of 8; K = 9*Cin)
     int debug;                       // unused by the product kernels (kept so probe builds can pass flags without changing the ABI of the struct)
+    int rows_per_stream;             // tokens ONE stream contributes to the batched dimension (0: unknown): keys the tile-class choice of
+                                     // gemm16.hip so that a stream's result does not depend on the other streams of the launch
+    int weights_on_rows;             // 1: the V^T product (A = weight rows, W = token rows): tile-class choices key on M instead of N
     int split_tiles;                 // 128x128 output tiles of ONE batch entry's share of the problem (0: unknown).  The split-K rule
                                      // uses it instead of the actual tile count, so a stream's result does not depend on how many
                                      // other streams share the launch (batch invariance); see splitk_slices in gemm.hip
 };
 void launch_gemm(const GemmArgs& a, hipStream_t st);
-void gemm_force_config(int cfg);
-void gemm_set_debug(int d);   // -1 auto-tune, 0..3 fixed tile configuration
+void gemm_force_config(int cfg);   // -1: shape-based choice; 0..8: force a gemm.hip tile configuration (also keeps gemm16.hip out)
+void gemm_set_debug(int d);        // bit 0: eligible 3x3 convolutions through the implicit-GEMM kernels; bit 1: keep gemm16.hip out
+// gemm16.hip: 16x16x32-MFMA family (224-row tiles, intra-tile K split); dense problems with K % 64 == 0 only
+#define RT_G16_NVAR 9
+bool gemm16_supported(const GemmArgs& a);
+int gemm16_pick(const GemmArgs& a, int weights_on_rows, int* wstat);      // variant id or -1; pure function of the shape
+void launch_gemm16_variant(const GemmArgs& a, int variant, int wstat, hipStream_t st);
 
 // ---------------------------------------------------------------- attention
 #define RT_MAXB 16

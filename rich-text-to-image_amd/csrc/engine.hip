@@ -386,7 +386,7 @@ struct rt_engine {
         GemmArgs g{}; g.A = A; g.W = W.w; g.bias = W.b; g.out = out; g.res = res; g.temb = temb; g.zero = zero;
         g.mode = A_DENSE; g.epi = epi; g.M = M; g.N = W.N; g.K = W.K; g.lda = lda; g.ldw = W.K; g.ldo = ldo;
         g.ldres = ldres; g.temb_ld = W.N; g.rows_per_batch = rows_per_batch;
-        if (cur_hw > 0) g.split_tiles = cdiv(cur_hw, 128) * cdiv(W.N, 128);
+        if (cur_hw > 0) { g.split_tiles = cdiv(cur_hw, 128) * cdiv(W.N, 128); g.rows_per_stream = cur_hw; }
         prof_begin(RT_PROF_GEMM_DENSE, 2.0 * M * W.N * W.K);
         launch_gemm(g, stream);
         prof_end();
@@ -396,7 +396,8 @@ struct rt_engine {
         if (dry()) return;
         GemmArgs g{}; g.A = Wv.w; g.W = X; g.bias = nullptr; g.out = out; g.zero = zero;
         g.mode = A_DENSE; g.epi = EPI_BF16; g.M = Wv.N; g.N = M; g.K = Wv.K; g.lda = Wv.K; g.ldw = ldx; g.ldo = ldo;
-        if (cur_hw > 0) g.split_tiles = cdiv(Wv.N, 128) * cdiv(cur_hw, 128);
+        g.weights_on_rows = 1;
+        if (cur_hw > 0) { g.split_tiles = cdiv(Wv.N, 128) * cdiv(cur_hw, 128); g.rows_per_stream = cur_hw; }
         prof_begin(RT_PROF_GEMM_DENSE, 2.0 * M * Wv.N * Wv.K);
         launch_gemm(g, stream);
         prof_end();

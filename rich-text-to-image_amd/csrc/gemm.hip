@@ -44,16 +44,6 @@
 #define RT_ABLATE 0
 #endif
 
-// gelu(x) = 0.5 x (1 + erf(x / sqrt 2)) with erf from Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 output
-// grid): one v_rcp + one v_exp + 7 FMAs instead of libm's branchy erff (the GEGLU epilogue runs it on 32 values per lane and tile).
-__device__ __forceinline__ float gelu_erf(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * z);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float er = 1.f - poly * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);      // erf(|x| / sqrt 2)
-    return 0.5f * x + 0.5f * fabsf(x) * er;                                                   // x * 0.5 * (1 + sign(x) * er)
-}
-
 // ---- epilogue (shared by both main-loop variants), specialised at compile time on the epilogue kind.
 // With swapped operands the 32x32 accumulator tile is D[n][m]: m = lane&31 (row of C), n = (r&3) + 8*(r>>2) +
 // 4*(lane>>5) (column of C), i.e. a lane owns ONE output row and 4 consecutive columns per register quad.
@@ -1220,10 +1210,12 @@ static void launch_with_cfg(const GemmArgs& a, int cfg, hipStream_t st) {
 // configurations are bit-identical in their results, tuning never changes outputs.
 static int g_force_cfg = -1;
 static int g_conv_patch = 1;
+static int g_use16 = 1;
 #ifdef RT_PROBE
 int g_conv3p_tn = 0;          // probe override of the patch kernel's column-tile count
 #endif
-void gemm_set_debug(int flags) { g_conv_patch = (flags & 1) ? 0 : 1; }   // bit 0: route eligible convs through the implicit-GEMM kernels (A/B tests)
+// bit 0: route eligible convs through the implicit-GEMM kernels; bit 1: keep the 16x16x32 family (gemm16.hip) out (A/B tests)
+void gemm_set_debug(int flags) { g_conv_patch = (flags & 1) ? 0 : 1; g_use16 = (flags & 2) ? 0 : 1; }
 
 template <int EPI, bool UP2, int TN>
 static void launch_conv3p_tn(const GemmArgs& a, int ntm, hipStream_t st) {
@@ -1499,6 +1491,12 @@ void launch_gemm(const GemmArgs& a, hipStream_t st) {
         return;
     }
     if (ksl > 1) { launch_gemm_splitk(a, ksl, st); return; }
+    if (g_force_cfg < 0 && g_use16) {
+        // the 16x16x32 family: tile = pure function of the shape (class from the weight side, row tiling from M), no timing involved
+        int wstat = 0;
+        const int v = gemm16_pick(a, a.weights_on_rows, &wstat);
+        if (v >= 0) { launch_gemm16_variant(a, v, wstat, st); return; }
+    }
     TuneState* timed = nullptr;
     const int cfg = pick_config(a, st, &timed);
     if (!timed) { launch_with_cfg(a, cfg, st); return; }

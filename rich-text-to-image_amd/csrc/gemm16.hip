@@ -1,0 +1,424 @@
+// bf16 GEMM family on v_mfma_f32_16x16x32_bf16 for gfx950 (round 3): dense C[M,N] = A[M,K] * W[N,K]^T with the UNet's epilogues.
+//
+// Why a second family next to gemm.hip (32x32x16 tiles): every GEMM of a rich-text step has M = F * h*w with F = 7 streams
+// (models/region_diffusion_sdxl.py:779-872 runs 7 UNet forwards per step), i.e. M = 7168 or 28672 = 7 * 2^k.  256-row tiles give
+// 28 x 8 = 224 workgroups for the 1280-channel projections (32 of 256 CUs idle) and 4.375 rounds for the GEGLU GEMM; 224-row
+// tiles (14 x 16) give exactly 256 / 1280 workgroups.  224 rows cannot be split over 4 SIMDs with 32x32 MFMA tiles; with 16x16
+// tiles two M-waves take 7 row tiles each.  The second reason is the LDS array: the 8(M) x 1(N) wave layout that 256x160 tiles force
+// on 32x32 tiles makes every wave read the whole W tile (192 KB of ds_read per K tile + 53 KB of LDS-DMA writes: the LDS array is
+// busy ~90 % of the MFMA time).  Here a 224x160 tile is computed by 2(M) x 2(N) x 2(K) waves: each wave owns a 112x80 output
+// quadrant for ONE HALF of every 64-deep K tile (7 + 5 fragment reads per 35 MFMAs: 96 KB of ds_read per K tile) and the two K
+// halves are added through LDS in the epilogue.
+//
+//   class B ("K-split"): WK = 2.  out = (sum over even 32-deep k steps) + (sum over odd 32-deep k steps), each ascending.
+//   class A            : WK = 1.  out = sum over 32-deep k steps, ascending.
+// Within a class every tile shape accumulates every output element in the same order, so the ROW tiling (224 / 256 rows) may follow M
+// (the batch size) while the class is a pure function of (epilogue, N, K): a stream's result does not depend on which other streams
+// share the launch (batch invariance), by construction instead of by the all-configurations-bit-identical rule of gemm.hip.
+//
+// Main loop: S-slot LDS ring of 64-deep K tiles filled by global_load_lds_dwordx4 (same XOR swizzle on the source address as
+// gemm.hip: slot ^= (row>>1)&7, conflict-free ds_read_b128 for the 16-row fragments of the 16x16x32 MFMA as well); the fragments of
+// k step u+1 are read into registers WHILE the MFMAs of step u run (A fragments roll through one register set row by row, W
+// fragments are double buffered), so a tile's LDS slot is free as soon as its last fragments were read: all S slots are in flight
+// behind the MFMAs (gemm.hip keeps the tile being multiplied in LDS: S-1 slots).  One counted s_waitcnt vmcnt + raw s_barrier per K tile.
+#include "common.h"
+#include <algorithm>
+#include <type_traits>
+
+#define BK16 64
+
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+// LDS-DMA through a buffer descriptor: buffer_load_dwordx4 v(voff), s[rsrc], s(soff) offen lds.  `base` must be wave-uniform; the
+// descriptor is rebuilt from it at every call site (4 SALU moves, hoisted by the compiler).  Kept in a non-template __device__
+// function: the descriptor type exists in device compilation only and a kernel TEMPLATE that names it loses its host-side stub.
+__device__ __forceinline__ void glds16_buf(const void* base, int voff_bytes, int soff_bytes, void* lds_wave_base) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff_bytes, soff_bytes, 0, 0);
+}
+
+template <int EPI, int TMW, int TNW, int WM, int WN, int WK, int S>
+__global__ __launch_bounds__(512) void gemm16_kernel(GemmArgs p, int wstat) {
+    static_assert(WM * WN * WK == 8, "8 waves");
+    static_assert(WK == 1 || WK == 2, "K split over at most two waves");
+    constexpr int NW = 8;
+    constexpr int BM = WM * TMW * 16, BN = WN * TNW * 16;
+    constexpr int STAGE = (BM + BN) * 128;                 // bytes per ring slot: A rows then W rows, 128 B (64 k) each
+    constexpr int GA = BM / 8, GB = BN / 8, GT = GA + GB;  // 8-row groups = one wave-wide LDS-DMA each
+    constexpr int PW = (GT + NW - 1) / NW;                 // LDS-DMA pieces per wave and K tile
+    constexpr int KS = 2 / WK;                             // 32-deep k steps per K tile and wave
+    static_assert(EPI != EPI_GEGLU || TNW == 4, "GEGLU: a wave owns one packed 64-column block [32 value | 32 gate]");
+    static_assert((S - 2) * PW <= 63 && S >= 2 && S <= 3, "ring depth");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kh = WK == 2 ? (wave & 1) : 0;
+    const int wq = WK == 2 ? (wave >> 1) : wave;
+    const int wm = wq / WN, wn = wq % WN;
+
+    // ---- tile mapping.  Default: XCD-aware bijective remap (each XCD gets a contiguous run of tiles) + groups of 4 tile rows x all
+    // tile columns.  wstat (wide N, e.g. GEGLU): every XCD owns ntn/8 tile COLUMNS for all tile rows, so its share of W stays in its
+    // 4 MiB L2 for the whole launch and W is fetched from HBM exactly once (the grouped order re-fetched the 26 MB GEGLU weight 7 x).
+    const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM, nwg = ntm * ntn;
+    int tm, tn;
+    if (wstat) {
+        const int cpx = ntn >> 3, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;   // host guarantees ntn % 8 == 0
+        tn = xcd * cpx + idx % cpx; tm = idx / cpx;
+    } else {
+        int bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        constexpr int GRP = 4;
+        const int gsz = GRP * ntn;
+        const int first_m = (bid / gsz) * GRP;
+        const int gm = (ntm - first_m) < GRP ? (ntm - first_m) : GRP;
+        tm = first_m + (bid % gsz) % gm; tn = (bid % gsz) / gm;
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- loader: piece i of this wave copies 8-row group g = i*8 + wave of the (A rows | W rows) list.  Buffer-descriptor LDS-DMA
+    // (buffer_load_dwordx4 ... offen lds, guide T8): per piece ONE 32-bit VGPR byte offset, the K-tile offset is a scalar (soffset)
+    // and the operand base sits in an SGPR descriptor - the flat form kept a 64-bit address per piece alive and spilled in the loop.
+    const int lrow = lane >> 3, pslot = lane & 7;
+    int voff[PW];                       // byte offset of this lane's 16-B chunk at k0 = 0
+    int ldst[PW];                       // LDS byte offset of the group inside a ring slot (wave-uniform)
+    bool pisA[PW];                      // wave-uniform
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+        int g = i * NW + wave; if (g > GT - 1) g = GT - 1;          // tail duplicates copy the same bytes to the same place
+        const bool isA = g < GA;
+        const int gl = isA ? g : g - GA;
+        int row = (isA ? m0 : n0) + gl * 8 + lrow;
+        const int lim = isA ? p.M : p.N;
+        if (row >= lim) row = lim - 1;
+        const int key = ((gl << 2) | (lrow >> 1)) & 7;              // (tile row >> 1) & 7
+        voff[i] = (row * (isA ? p.lda : p.ldw) + ((pslot ^ key) << 3)) * 2;
+        pisA[i] = isA;
+        ldst[i] = (isA ? 0 : BM * 128) + gl * 1024;
+    }
+    const int nk = p.K / BK16;                                       // host guarantees K % 64 == 0
+    // K tile t -> slot t % S.  Behind the last tile the copies re-read tile nk-1 into a free slot: the vmcnt bookkeeping stays uniform.
+    auto stage_piece = [&](int t, int slot_off, int i) {
+        const int tt = t < nk ? t : nk - 1;
+        char* dst = smem + slot_off + ldst[i];
+        glds16_buf(pisA[i] ? (const void*)p.A : (const void*)p.W, voff[i], tt * (BK16 * 2), dst);
+    };
+    auto stage = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < PW; ++i) stage_piece(t, t * STAGE, i);     // prologue only: t < S
+    };
+
+    // ---- fragments: lane (l15, q): row l15 of a 16-row tile, 16-B chunk c = 4*khalf + q of the 128-B row
+    const int l15 = lane & 15, q4 = lane >> 4;
+    const int key = (l15 >> 1) & 7;                                  // tile bases are multiples of 16 rows: the key depends on l15 only
+    int aoff[KS], boff[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int c = (WK == 2 ? kh : ks) * 4 + q4;
+        aoff[ks] = (wm * TMW * 16 + l15) * 128 + ((c ^ key) << 4);
+        boff[ks] = BM * 128 + (wn * TNW * 16 + l15) * 128 + ((c ^ key) << 4);
+    }
+    f32x4_t acc[TMW][TNW];
+#pragma unroll
+    for (int i = 0; i < TMW; ++i)
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue: all S slots in flight; tile 0 landed; fragments of k step 0 in registers
+#pragma unroll
+    for (int s = 0; s < S; ++s) stage(s);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 1) * PW) : "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 fa[TMW], fb[2][TNW];
+#pragma unroll
+    for (int j = 0; j < TNW; ++j) fb[0][j] = *(const bf16x8*)(smem + boff[0] + j * 2048);
+#pragma unroll
+    for (int i = 0; i < TMW; ++i) fa[i] = *(const bf16x8*)(smem + aoff[0] + i * 2048);
+
+    // One k step.  CUR: which W fragment set it multiplies.  KSI: k step inside the tile.  NEXT: 0 = no further step,
+    // 1 = next step is in the same K tile, 2 = next step opens K tile t+1 (wait + barrier, then refill tile t's slot with tile t+S).
+    // cur_off / nxt_off: LDS byte offsets of the slots of tiles t and t+1 (scalars carried by the loop; no modulo arithmetic in
+    // the loop: hipcc's strength reduction turned `% 3` into per-fragment VGPR induction variables that spilled).
+    auto kstep = [&](int t, int cur_off, int nxt_off, auto cur_c, auto ksi_c, auto next_c) {
+        constexpr int CUR = decltype(cur_c)::value, KSI = decltype(ksi_c)::value, NEXT = decltype(next_c)::value;
+        constexpr int NKS = NEXT == 1 ? KSI + 1 : 0;                 // k step index of the next step inside its tile
+        const int rd = __builtin_amdgcn_readfirstlane(NEXT == 2 ? nxt_off : cur_off);
+        const char* na = smem + rd + aoff[NKS];
+        const char* nbb = smem + rd + boff[NKS];
+        // row 0 first: its operands were read a whole step ago, and the last fragment read of the previous step (issued behind
+        // that step's last MFMA row) retires behind these MFMAs instead of in front of the barrier
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[CUR][j], fa[0], acc[0][j], 0, 0, 0);
+        if constexpr (NEXT == 2) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // every fragment read of tile t is retired: its slot may be refilled
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * PW) : "memory");   // this wave's pieces of tile t+1 landed
+            __builtin_amdgcn_s_barrier();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NEXT != 0) {
+#pragma unroll
+            for (int j = 0; j < TNW; ++j) fb[CUR ^ 1][j] = *(const bf16x8*)(nbb + j * 2048);
+            fa[0] = *(const bf16x8*)(na);
+        }
+#pragma unroll
+        for (int i = 1; i < TMW; ++i) {
+#pragma unroll
+            for (int j = 0; j < TNW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[CUR][j], fa[i], acc[i][j], 0, 0, 0);
+            if constexpr (NEXT != 0) fa[i] = *(const bf16x8*)(na + i * 2048);
+            if constexpr (NEXT == 2) {
+                // LDS-DMA issue slots spread behind the MFMA rows (a piece costs its wave 60-200 cycles of issue under load)
+                constexpr int PPR = (PW + TMW - 2) / (TMW - 1);      // pieces per MFMA row
+#pragma unroll
+                for (int pc = 0; pc < PPR; ++pc) { const int pi = (i - 1) * PPR + pc; if (pi < PW) stage_piece(t + S, cur_off, pi); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>; using C2 = std::integral_constant<int, 2>;
+    int cur_off = 0, nxt_off = STAGE;
+    auto advance = [&]() { cur_off = nxt_off; nxt_off = nxt_off + STAGE == S * STAGE ? 0 : nxt_off + STAGE; };
+    if constexpr (KS == 1) {
+        int t = 0;
+        for (; t + 2 < nk; t += 2) {
+            kstep(t, cur_off, nxt_off, C0{}, C0{}, C2{}); advance();
+            kstep(t + 1, cur_off, nxt_off, C1{}, C0{}, C2{}); advance();
+        }
+        // host guarantees an even number of K tiles for the K-split class (K % 128 == 0): one tail shape, no register shuffling
+        kstep(t, cur_off, nxt_off, C0{}, C0{}, C2{}); advance(); kstep(t + 1, cur_off, nxt_off, C1{}, C0{}, C0{});
+    } else {
+        int t = 0;
+        for (; t + 1 < nk; ++t) { kstep(t, cur_off, nxt_off, C0{}, C0{}, C1{}); kstep(t, cur_off, nxt_off, C1{}, C1{}, C2{}); advance(); }
+        kstep(t, cur_off, nxt_off, C0{}, C0{}, C1{}); kstep(t, cur_off, nxt_off, C1{}, C1{}, C0{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the dummy copies behind the last tile
+    __syncthreads();                                                 // the ring is free: exchange buffers + transpose slabs
+
+    // ---- K-split reduction: kh = 0 ends up owning row tiles [0, H0), kh = 1 owns [H0, TMW).  Two passes through one LDS region.
+    constexpr int H0 = (TMW + 1) / 2;
+    if constexpr (WK == 2) {
+        static_assert(4 * H0 * TNW * 1024 <= S * STAGE, "exchange region");
+        char* xr = smem + (size_t)wq * (H0 * TNW * 1024) + lane * 16;
+        if (kh == 1) {
+#pragma unroll
+            for (int i = 0; i < H0; ++i)
+#pragma unroll
+                for (int j = 0; j < TNW; ++j) *(f32x4_t*)(xr + (i * TNW + j) * 1024) = acc[i][j];
+        }
+        __syncthreads();
+        if (kh == 0) {
+#pragma unroll
+            for (int i = 0; i < H0; ++i)
+#pragma unroll
+                for (int j = 0; j < TNW; ++j) acc[i][j] += *(const f32x4_t*)(xr + (i * TNW + j) * 1024);
+        }
+        __syncthreads();
+        if (kh == 0) {
+#pragma unroll
+            for (int i = H0; i < TMW; ++i)
+#pragma unroll
+                for (int j = 0; j < TNW; ++j) *(f32x4_t*)(xr + ((i - H0) * TNW + j) * 1024) = acc[i][j];
+        }
+        __syncthreads();
+        if (kh == 1) {
+            // acc(kh=0) + acc(kh=1) in that order in both halves: even k steps first
+#pragma unroll
+            for (int i = H0; i < TMW; ++i)
+#pragma unroll
+                for (int j = 0; j < TNW; ++j) acc[i][j] = *(const f32x4_t*)(xr + ((i - H0) * TNW + j) * 1024) + acc[i][j];
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane (l15, q4) holds row l15 and columns 4*q4 .. +3 of every 16x16 tile.  Each wave transposes one 16-row tile
+    // at a time through its private slab and moves row-contiguous 16-B chunks to / from HBM (guide T21).
+    constexpr bool F16 = EPI == EPI_F16;
+    constexpr bool F32 = EPI == EPI_F32 || F16;                      // fp32 slab; F16: fp16 in HBM (output and residual), rounded once
+    constexpr int ES = F32 ? 4 : 2;
+    constexpr int TNO = EPI == EPI_GEGLU ? TNW / 2 : TNW;            // 16-column output tiles per wave
+    constexpr int RS = TNO * 16 * ES + 16;                           // slab row stride (16-B pad: conflict-free 16-B column writes)
+    static_assert(8 * 16 * RS <= S * STAGE, "slabs");
+    char* slab = smem + (size_t)wave * 16 * RS;
+    const int NO = EPI == EPI_GEGLU ? (p.N >> 1) : p.N;
+    const int wcol0 = n0 + wn * TNW * 16;                            // first (packed) column of this wave
+    const int ocol0 = EPI == EPI_GEGLU ? (wcol0 >> 1) : wcol0;
+    float bias_v[TNO][4], bias_g[TNO][4];
+#pragma unroll
+    for (int t = 0; t < TNO; ++t) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bias_v[t][e] = 0.f; bias_g[t][e] = 0.f; }
+        const int col = wcol0 + t * 16 + 4 * q4;
+        if (p.bias) {
+            if constexpr (EPI == EPI_GEGLU) {
+                if (wcol0 + 64 <= p.N) {
+                    const float4 b0 = *(const float4*)(p.bias + col), b1 = *(const float4*)(p.bias + col + 32);
+                    bias_v[t][0] = b0.x; bias_v[t][1] = b0.y; bias_v[t][2] = b0.z; bias_v[t][3] = b0.w;
+                    bias_g[t][0] = b1.x; bias_g[t][1] = b1.y; bias_g[t][2] = b1.z; bias_g[t][3] = b1.w;
+                }
+            } else if (col < p.N) {
+                const float4 b0 = *(const float4*)(p.bias + col);
+                bias_v[t][0] = b0.x; bias_v[t][1] = b0.y; bias_v[t][2] = b0.z; bias_v[t][3] = b0.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TMW; ++i) {
+        if (WK == 2 && ((i < H0) != (kh == 0))) continue;            // wave-uniform
+        // registers -> slab
+#pragma unroll
+        for (int t = 0; t < TNO; ++t) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if constexpr (EPI == EPI_GEGLU) v[e] = (acc[i][t][e] + bias_v[t][e]) * gelu_erf(acc[i][t + 2][e] + bias_g[t][e]);
+                else v[e] = acc[i][t][e] + bias_v[t][e];
+            }
+            char* dst = slab + l15 * RS + (t * 16 + 4 * q4) * ES;
+            if constexpr (F32) *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+            else { uint2 w; w.x = pack_bf16x2(v[0], v[1]); w.y = pack_bf16x2(v[2], v[3]); *(uint2*)dst = w; }
+        }
+        // slab -> HBM (LDS operations of one wave execute in order: no barrier)
+        const int row0 = m0 + (wm * TMW + i) * 16;
+        if constexpr (F16) {
+            constexpr int IPR = TNO * 16 / 8;                        // 8-column items per row
+#pragma unroll
+            for (int idx0 = 0; idx0 < 16 * IPR; idx0 += 64) {
+                const int idx = idx0 + lane;
+                const int r = idx / IPR, c8 = idx - r * IPR;
+                const int row = row0 + r, col = ocol0 + c8 * 8;
+                if (r >= 16 || row >= p.M || col >= NO) continue;
+                const float4 a0 = *(const float4*)(slab + r * RS + c8 * 32), a1 = *(const float4*)(slab + r * RS + c8 * 32 + 16);
+                float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                if (p.res) {
+                    const uint4 rq = *(const uint4*)((const f16_t*)p.res + (size_t)row * p.ldres + col);
+                    const f16_t* rh = (const f16_t*)&rq;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)rh[e];
+                }
+                uint4 o; f16_t* oh = (f16_t*)&o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) oh[e] = (f16_t)v[e];
+                *(uint4*)((f16_t*)p.out + (size_t)row * p.ldo + col) = o;
+            }
+        } else {
+            constexpr int CPR = TNO * 16 * ES / 16;                  // 16-B chunks per row
+#pragma unroll
+            for (int idx0 = 0; idx0 < 16 * CPR; idx0 += 64) {
+                const int idx = idx0 + lane;
+                const int r = idx / CPR, ch = idx - r * CPR;
+                const int row = row0 + r, col = ocol0 + ch * (16 / ES);
+                if (r >= 16 || row >= p.M || col >= NO) continue;
+                const uint4 qv = *(const uint4*)(slab + r * RS + ch * 16);
+                if constexpr (F32) {
+                    float4 o = make_float4(__uint_as_float(qv.x), __uint_as_float(qv.y), __uint_as_float(qv.z), __uint_as_float(qv.w));
+                    if (p.res) { const float4 rv = *(const float4*)((const float*)p.res + (size_t)row * p.ldres + col); o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w; }
+                    *(float4*)((float*)p.out + (size_t)row * p.ldo + col) = o;
+                } else {
+                    *(uint4*)((bf16_t*)p.out + (size_t)row * p.ldo + col) = qv;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- launch
+struct G16Var { int BM, BN, WK, S, geglu_ok; };
+// variant ids (probe / tests).  Within a class (A: WK = 1, B: WK = 2) all variants are bit-identical per output element.
+static const G16Var kVar[RT_G16_NVAR] = {
+    {224, 160, 2, 3, 0},   // 0  class B: N = 1280 / 640 / 320 families, M = 7 * 2^k
+    {128, 160, 2, 3, 0},   // 1  class B, 128 rows (M = 2^k: the Q|K projection of the 4 non-injected streams, SD-v1.5 batches)
+    {224, 256, 1, 2, 1},   // 2  class A: wide N (GEGLU)
+    {256, 256, 1, 2, 1},   // 3
+    {224, 320, 1, 2, 0},   // 4  class A, 320 columns
+    {256, 320, 1, 2, 0},   // 5
+    {160, 224, 2, 3, 0},   // 6  class B transposed: V^T = Wv X^T (rows = head channels, columns = tokens)
+    {160, 128, 2, 3, 0},   // 7  class B transposed, 128 token columns
+    {128, 256, 1, 3, 1},   // 8  class A, 128 rows
+};
+
+template <int EPI, int TMW, int TNW, int WM, int WN, int WK, int S>
+static void launch_v(const GemmArgs& a, int wstat, hipStream_t st) {
+    constexpr int BM = WM * TMW * 16, BN = WN * TNW * 16;
+    constexpr int LDS = S * (BM + BN) * 128;
+    static bool attr = false;
+    if (!attr) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)gemm16_kernel<EPI, TMW, TNW, WM, WN, WK, S>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr = true;
+    }
+    const int ntn = cdiv(a.N, BN), ntm = cdiv(a.M, BM);
+    if (wstat && (ntn % 8 != 0)) wstat = 0;
+    hipLaunchKernelGGL((gemm16_kernel<EPI, TMW, TNW, WM, WN, WK, S>), dim3(ntm * ntn), dim3(512), LDS, st, a, wstat);
+    HIP_CHECK(hipGetLastError());
+}
+
+template <int EPI>
+static void launch_e(const GemmArgs& a, int v, int wstat, hipStream_t st) {
+    switch (v) {
+        case 2: launch_v<EPI, 7, 4, 2, 4, 1, 2>(a, wstat, st); return;
+        case 3: launch_v<EPI, 8, 4, 2, 4, 1, 2>(a, wstat, st); return;
+        case 8: launch_v<EPI, 4, 4, 2, 4, 1, 3>(a, wstat, st); return;
+        default: break;
+    }
+    if constexpr (EPI != EPI_GEGLU) {
+        switch (v) {
+            case 0: launch_v<EPI, 7, 5, 2, 2, 2, 3>(a, wstat, st); return;
+            case 1: launch_v<EPI, 4, 5, 2, 2, 2, 3>(a, wstat, st); return;
+            case 4: launch_v<EPI, 7, 5, 2, 4, 1, 2>(a, wstat, st); return;
+            case 5: launch_v<EPI, 8, 5, 2, 4, 1, 2>(a, wstat, st); return;
+            case 6: launch_v<EPI, 5, 7, 2, 2, 2, 3>(a, wstat, st); return;
+            case 7: launch_v<EPI, 5, 4, 2, 2, 2, 3>(a, wstat, st); return;
+            default: break;
+        }
+    }
+    throw rt_error(RT_E_INVALID, "gemm16: variant cannot run this epilogue");
+}
+
+bool gemm16_supported(const GemmArgs& a) {
+    if (a.mode != A_DENSE || a.K % (2 * BK16) != 0) return false;      // K % 128: the K-split class runs pairs of K tiles
+    if (!(a.epi == EPI_BF16 || a.epi == EPI_F32 || a.epi == EPI_F16 || a.epi == EPI_GEGLU)) return false;
+    if (a.lda % 8 || a.ldw % 8) return false;
+    return true;
+}
+
+void launch_gemm16_variant(const GemmArgs& a, int v, int wstat, hipStream_t st) {
+    RT_REQUIRE(gemm16_supported(a), "gemm16: problem outside the family's domain (dense, K % 128 == 0)");
+    RT_REQUIRE(v >= 0 && v < RT_G16_NVAR, "gemm16: variant");
+    switch (a.epi) {
+        case EPI_BF16: launch_e<EPI_BF16>(a, v, wstat, st); break;
+        case EPI_F32: launch_e<EPI_F32>(a, v, wstat, st); break;
+        case EPI_F16: launch_e<EPI_F16>(a, v, wstat, st); break;
+        default: launch_e<EPI_GEGLU>(a, v, wstat, st); break;
+    }
+}
+
+// Tile choice, a pure function of the shape (no timing): the CLASS (A / B, i.e. the accumulation order of an output element) follows
+// the weight side only - (epilogue, N, K), or (M, K) for the V^T product whose weights are the A operand - and the number of rows ONE
+// stream contributes (a.rows_per_stream: identical for a stream computed alone or inside any batch); the tile inside the class follows
+// the actual extent of the batched dimension.  Returns -1 when the family has no tile for the shape (the caller stays on gemm.hip).
+int gemm16_pick(const GemmArgs& a, int weights_on_rows, int* wstat) {
+    *wstat = 0;
+    if (!gemm16_supported(a)) return -1;
+    const int batched = weights_on_rows ? a.N : a.M;                 // extent of the token dimension
+    const int rps = a.rows_per_stream > 0 ? a.rows_per_stream : batched;
+    if (rps < 256) return -1;                                        // small maps stay on gemm.hip (128x128 tiles / split-K)
+    const double nk = a.K / 64.0;
+    // launch time model in units of one K tile of a 224x160 tile: whole rounds of 256 workgroups (one per CU) x (K tiles x tile
+    // area + a fixed prologue / epilogue share); tiles of 128 rows feed the matrix pipe ~20 % worse per flop
+    auto cost = [&](int BMv, int BNv, double eff) {
+        const long tiles = (long)cdiv(a.M, BMv) * cdiv(a.N, BNv);
+        return (double)((tiles + 255) / 256) * (nk * BMv * BNv / (224.0 * 160.0) * eff + 6.0);
+    };
+    if (weights_on_rows) {
+        if (a.epi != EPI_BF16 || a.M % 160 != 0) return -1;
+        return cost(160, 224, 1.0) <= cost(160, 128, 1.2) ? 6 : 7;
+    }
+    if (a.epi == EPI_GEGLU) {
+        if (a.N % 256 != 0) return -1;
+        *wstat = (a.N / 256) % 8 == 0;
+        const double c2 = cost(224, 256, 1.0), c3 = cost(256, 256, 1.0), c8 = cost(128, 256, 1.2);
+        return c2 <= c3 && c2 <= c8 ? 2 : (c3 <= c8 ? 3 : 8);
+    }
+    if (a.N % 160 == 0) return cost(224, 160, 1.0) <= cost(128, 160, 1.2) ? 0 : 1;     // class B
+    return -1;
+}
+

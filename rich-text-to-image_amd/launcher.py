@@ -27,6 +27,35 @@ def init_distributed(backend=None):
     return rank, local_rank, world
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(script, argv, nproc, require_gpus=True):
+    """`python bench.py --gpus N` without a wrapper: when no torch.distributed.run environment is present (WORLD_SIZE unset) and
+    N > 1, replace this process by `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P script argv...` - one rank per GPU, LOCAL_RANK selects the device.  Returns None when nothing has to be done
+    (N == 1 or already inside a launch); returns an error string when the box has fewer than N GPUs (the caller reports it);
+    otherwise does not return."""
+    import sys
+    if nproc <= 1 or "WORLD_SIZE" in os.environ:
+        return None
+    if require_gpus:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < nproc:
+            return f"need {nproc} GPUs on this node for --gpus {nproc}, found {have}"
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes fails without it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(env.get("MASTER_PORT") or free_port()), script] + list(argv)
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execvpe(cmd[0], cmd, env)
+
+
 def shard_round_robin(requests, rank, world):
     """Static round-robin of independent requests over ranks (request i -> rank i % world)."""
     return [r for i, r in enumerate(requests) if i % world == rank]

@@ -53,3 +53,33 @@ def test_single_process_is_a_noop():
     assert launcher.shard_round_robin([1, 2, 3], 0, 1) == [1, 2, 3]
     assert launcher.max_over_ranks(3.5) == 3.5
     assert launcher.broadcast_tensor(torch.zeros(4, dtype=torch.uint8)) == 0
+
+
+def test_bench_gpus2_self_launches_under_torch_distributed_run():
+    """`python bench.py --gpus 2` (no wrapper, no WORLD_SIZE) must re-execute itself under torch.distributed.run with one rank per
+    device; --dry-launch stops before the first engine call, so the whole launch path runs on CPU over gloo."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-launch"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout                       # rank 0 prints ONE line
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["weight_broadcast_calls"] == 1 and line["arena_received"] is True
+    assert line["max_over_ranks"] == 2.0 and line["requests_rank0"] == [0, 2]
+
+
+def test_bench_reports_missing_gpus_clearly():
+    """On a box with fewer GPUs than --gpus the bare command must not die on an assert: it says what is missing."""
+    import json
+    import subprocess
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 8:
+        return
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["value"] is None and "need 8 GPUs" in line["error"] and "need 8 GPUs" in out.stderr
