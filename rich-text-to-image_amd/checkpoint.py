@@ -3,7 +3,7 @@
 Replaces `StableDiffusionPipeline / AutoencoderKL / CLIPTextModel.from_pretrained` at rd.py:26-33 and xl.py:95-130.
 The UNet and VAE decoder go to the HIP engine; the CLIP text encoders (once per prompt set, off the hot path) run on the same
 operators through `clip_text_encoder.HipCLIPTextEncoder` (checked against transformers' CLIPTextModel on random weights).  No
-checkpoint exists offline, so the directory loaders themselves are untested here.
+real checkpoint exists offline: the loaders are exercised on synthetic diffusers-layout directories (tests/test_checkpoint_gpu.py).
 """
 import glob
 import json
@@ -130,9 +130,42 @@ def load_text_encoder(path, device=0, with_projection=False):
     return HipCLIPTextEncoder(load_state_dict_dir(path), _component_config(path), device=device, with_projection=with_projection)
 
 
-def load_pipeline(load_path, kind="SD", device=0, latent_hw=None, lora_path=None, lora_scale=1.0):
-    """kind 'SD' -> RegionDiffusion, 'SDXL' -> RegionDiffusionXL, from a diffusers-layout directory
-    (unet/, vae/, tokenizer[_2]/, text_encoder[_2]/).  `latent_hw` sizes the VAE plan (default: the model's native size).
+DEFAULT_REPO = {"SD": "runwayml/stable-diffusion-v1-5", "SDXL": "stabilityai/stable-diffusion-xl-base-1.0"}
+ENV_OVERRIDE = {"SD": "RTDIFF_SD_PATH", "SDXL": "RTDIFF_SDXL_PATH"}
+
+
+def resolve_checkpoint(name_or_path, kind="SD"):
+    """What `from_pretrained(name_or_path)` resolves at rd.py:26-33 / xl.py:105-120, without a network: a diffusers-layout directory.
+    Order: (1) `name_or_path` is a directory; (2) the environment override of the family (RTDIFF_SD_PATH / RTDIFF_SDXL_PATH) when
+    the name is the family's default hub id or None; (3) the Hugging Face hub cache (`$HUGGINGFACE_HUB_CACHE`, `$HF_HOME/hub`,
+    `~/.cache/huggingface/hub`): models--<org>--<name>/snapshots/<rev>/ - what a previous `from_pretrained` download left behind.
+    Raises FileNotFoundError naming everything that was tried (there is no silent fallback to random weights)."""
+    tried = []
+    name = name_or_path or DEFAULT_REPO[kind]
+    if os.path.isdir(name) and os.path.isdir(os.path.join(name, "unet")):
+        return name
+    tried.append(name)
+    if name == DEFAULT_REPO[kind] and os.environ.get(ENV_OVERRIDE[kind]):
+        p = os.environ[ENV_OVERRIDE[kind]]
+        if os.path.isdir(os.path.join(p, "unet")):
+            return p
+        tried.append(f"${ENV_OVERRIDE[kind]}={p}")
+    if "/" in name and not os.path.isabs(name):
+        roots = [os.environ.get("HUGGINGFACE_HUB_CACHE"), os.path.join(os.environ["HF_HOME"], "hub") if os.environ.get("HF_HOME") else None,
+                 os.path.expanduser("~/.cache/huggingface/hub")]
+        for root in [r for r in roots if r]:
+            snaps = sorted(glob.glob(os.path.join(root, "models--" + name.replace("/", "--"), "snapshots", "*")), key=os.path.getmtime)
+            for snap in reversed(snaps):
+                if os.path.isdir(os.path.join(snap, "unet")):
+                    return snap
+            tried.append(os.path.join(root, "models--" + name.replace("/", "--")))
+    raise FileNotFoundError(f"no diffusers-layout checkpoint for {name!r} ({kind}); tried: " + "; ".join(tried) +
+                            f". Pass a local directory (unet/, vae/, tokenizer*/, text_encoder*/) or set ${ENV_OVERRIDE[kind]}.")
+
+
+def load_components(load_path, kind="SD", device=0, latent_hw=None, lora_path=None, lora_scale=1.0):
+    """Everything the facade constructors need from a diffusers-layout directory (unet/, vae/, tokenizer[_2]/, text_encoder[_2]/) as
+    keyword arguments of RegionDiffusion / RegionDiffusionXL.  `latent_hw` sizes the VAE plan (default: the model's native size).
     `lora_path`: a LoRA .safetensors file merged into the UNet weights before they are bound (lora.merge_lora)."""
     from .engine import SD15_CONFIG, SD_VAE_CONFIG, SDXL_CONFIG, SDXL_VAE_CONFIG, VaeDecoder
     dev = torch.device(f"cuda:{device}")
@@ -148,10 +181,8 @@ def load_pipeline(load_path, kind="SD", device=0, latent_hw=None, lora_path=None
     vae = VaeDecoder(vae_cfg, hw[0], hw[1], device=device, state_dict=vae_sd)
     tok = ClipBPETokenizer.from_pretrained(load_path, "tokenizer")
     if kind == "SD":
-        from .region_diffusion import RegionDiffusion
         enc = load_text_encoder(os.path.join(load_path, "text_encoder"), device)
-        return RegionDiffusion(device, unet_state_dict=unet_sd, config=unet_cfg, vae=vae, tokenizer=tok, text_encoder=ClipEncoderSD(enc, dev))
-    from .region_diffusion_sdxl import RegionDiffusionXL
+        return dict(unet_state_dict=unet_sd, config=unet_cfg, vae=vae, tokenizer=tok, text_encoder=ClipEncoderSD(enc, dev))
     tok2 = ClipBPETokenizer.from_pretrained(load_path, "tokenizer_2")
     enc1 = load_text_encoder(os.path.join(load_path, "text_encoder"), device)
     enc2 = load_text_encoder(os.path.join(load_path, "text_encoder_2"), device, with_projection=True)
@@ -159,5 +190,15 @@ def load_pipeline(load_path, kind="SD", device=0, latent_hw=None, lora_path=None
     mi = os.path.join(load_path, "model_index.json")
     if os.path.exists(mi):
         fz = json.load(open(mi)).get("force_zeros_for_empty_prompt", True)
-    return RegionDiffusionXL(load_path, device, unet_state_dict=unet_sd, config=unet_cfg, vae=vae, tokenizer=tok, vae_scaling_factor=vae_cfg["scaling_factor"],
-                             text_encoders=ClipEncodersXL([tok, tok2], [enc1, enc2], dev, fz))
+    return dict(unet_state_dict=unet_sd, config=unet_cfg, vae=vae, tokenizer=tok, vae_scaling_factor=vae_cfg["scaling_factor"],
+                text_encoders=ClipEncodersXL([tok, tok2], [enc1, enc2], dev, fz))
+
+
+def load_pipeline(load_path, kind="SD", device=0, latent_hw=None, lora_path=None, lora_scale=1.0):
+    """kind 'SD' -> RegionDiffusion, 'SDXL' -> RegionDiffusionXL, from a diffusers-layout directory or hub id (resolve_checkpoint)."""
+    comp = load_components(resolve_checkpoint(load_path, kind), kind, device, latent_hw, lora_path, lora_scale)
+    if kind == "SD":
+        from .region_diffusion import RegionDiffusion
+        return RegionDiffusion(device, **comp)
+    from .region_diffusion_sdxl import RegionDiffusionXL
+    return RegionDiffusionXL(load_path, device, **comp)

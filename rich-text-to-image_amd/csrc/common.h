@@ -87,12 +87,15 @@ struct GemmArgs {
     int debug;                       // unused by the product kernels (kept so probe builds can pass flags without changing the ABI of the struct)
     int rows_per_stream;             // tokens ONE stream contributes to the batched dimension (0: unknown): keys the tile-class choice of
                                      // gemm16.hip so that a stream's result does not depend on the other streams of the launch
+    float* splitk_ws;                // optional split-K partial-sum scratch owned by the caller (engine workspace); null: per-(device, stream) fallback
+    size_t splitk_ws_floats;
     int weights_on_rows;             // 1: the V^T product (A = weight rows, W = token rows): tile-class choices key on M instead of N
     int split_tiles;                 // 128x128 output tiles of ONE batch entry's share of the problem (0: unknown).  The split-K rule
                                      // uses it instead of the actual tile count, so a stream's result does not depend on how many
                                      // other streams share the launch (batch invariance); see splitk_slices in gemm.hip
 };
 void launch_gemm(const GemmArgs& a, hipStream_t st);
+size_t gemm_splitk_scratch_floats(const GemmArgs& a);   // fp32 partial sums launch_gemm needs for this problem (0: not split)
 void gemm_force_config(int cfg);   // -1: shape-based choice; 0..8: force a gemm.hip tile configuration (also keeps gemm16.hip out)
 void gemm_set_debug(int d);        // bit 0: eligible 3x3 convolutions through the implicit-GEMM kernels; bit 1: keep gemm16.hip out
 // gemm16.hip: 16x16x32-MFMA family (224-row tiles, intra-tile K split); dense problems with K % 64 == 0 only

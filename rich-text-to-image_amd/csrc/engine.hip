@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstring>
 #include <functional>
+#include <algorithm>
 
 static thread_local std::string g_create_error;
 static thread_local std::string g_op_error;
@@ -380,31 +381,39 @@ struct rt_engine {
     bool dry() const { return ws.dry; }
     int cur_hw = 0;              // tokens per stream of the block being executed (0 outside the UNet forward): the split-K rule of
                                  // launch_gemm is keyed on ONE stream's share of a GEMM so that results are batch invariant
+    // split-K partial sums live in one engine-owned buffer sized by the dry pass of the plan (the former thread_local
+    // buffer inside gemm.hip was shared by every stream / device of the thread and grew with a hipMalloc in the middle of a forward)
+    float* splitk_buf = nullptr;
+    size_t splitk_floats = 0, splitk_need = 0;
+    bool run_gemm(GemmArgs& g) {        // false in the dry pass (only records the scratch the launch would need)
+        if (dry()) { splitk_need = std::max(splitk_need, gemm_splitk_scratch_floats(g)); return false; }
+        g.splitk_ws = splitk_buf; g.splitk_ws_floats = splitk_floats;
+        return true;
+    }
     void gemm(const bf16_t* A, int lda, const MatW& W, int M, void* out, int ldo, int epi, const void* res = nullptr,
               int ldres = 0, const float* temb = nullptr, int rows_per_batch = 0) {
-        if (dry()) return;
         GemmArgs g{}; g.A = A; g.W = W.w; g.bias = W.b; g.out = out; g.res = res; g.temb = temb; g.zero = zero;
         g.mode = A_DENSE; g.epi = epi; g.M = M; g.N = W.N; g.K = W.K; g.lda = lda; g.ldw = W.K; g.ldo = ldo;
         g.ldres = ldres; g.temb_ld = W.N; g.rows_per_batch = rows_per_batch;
         if (cur_hw > 0) { g.split_tiles = cdiv(cur_hw, 128) * cdiv(W.N, 128); g.rows_per_stream = cur_hw; }
+        if (!run_gemm(g)) return;
         prof_begin(RT_PROF_GEMM_DENSE, 2.0 * M * W.N * W.K);
         launch_gemm(g, stream);
         prof_end();
     }
     // V^T = Wv [HD, K] x X[M, K]^T -> [HD, M]
     void gemm_vt(const MatW& Wv, const bf16_t* X, int ldx, int M, bf16_t* out, int ldo) {
-        if (dry()) return;
         GemmArgs g{}; g.A = Wv.w; g.W = X; g.bias = nullptr; g.out = out; g.zero = zero;
         g.mode = A_DENSE; g.epi = EPI_BF16; g.M = Wv.N; g.N = M; g.K = Wv.K; g.lda = Wv.K; g.ldw = ldx; g.ldo = ldo;
         g.weights_on_rows = 1;
         if (cur_hw > 0) { g.split_tiles = cdiv(Wv.N, 128) * cdiv(cur_hw, 128); g.rows_per_stream = cur_hw; }
+        if (!run_gemm(g)) return;
         prof_begin(RT_PROF_GEMM_DENSE, 2.0 * M * Wv.N * Wv.K);
         launch_gemm(g, stream);
         prof_end();
     }
     void conv3(const bf16_t* in, int mode, const MatW& W, int B, int Hin, int Win, int CinP, void* out, int epi,
                const void* res = nullptr, const float* temb = nullptr) {
-        if (dry()) return;
         int Hout = Hin, Wout = Win;
         if (mode == A_CONV3_S2) { Hout = (Hin + 1) / 2; Wout = (Win + 1) / 2; }   // k3 s2 p1
         if (mode == A_CONV3_UP2) { Hout = Hin * 2; Wout = Win * 2; }
@@ -414,6 +423,7 @@ struct rt_engine {
         g.Hin = Hin; g.Win = Win; g.Cin = CinP; g.Hout = Hout; g.Wout = Wout;
         g.split_tiles = cdiv(Hout * Wout, 128) * cdiv(W.N, 128);
         RT_REQUIRE(W.K == 9 * CinP, "conv: weight/input channel mismatch");
+        if (!run_gemm(g)) return;
         prof_begin(RT_PROF_GEMM_CONV, 2.0 * g.M * W.N * W.K);
         launch_gemm(g, stream);
         prof_end();
@@ -823,7 +833,15 @@ int rt_create(const rt_config* cfg, int device, rt_engine** out) {
             FwdIn in{}; in.B = cfg->max_streams; in.h = cfg->latent_h; in.w = cfg->latent_w;
             for (int b = 0; b < in.B; ++b) { in.qk_src[b] = b; in.res_src[b] = b ? 0 : -1; in.prompt[b] = 0; }
             e->ws = Workspace(); e->ws.dry = true;
+            e->splitk_need = 0;
             e->unet_forward(in);
+            {   // the K / V^T cache GEMMs of rt_set_prompts (outside a forward: cur_hw == 0) at the largest prompt count
+                const int D = cfg->cross_attention_dim, P96 = cfg->max_prompts * 96;
+                e->for_each_tblock([&](TransformerP& t, TBlockP& k) {
+                    e->gemm(nullptr, D, k.k2, P96, nullptr, t.heads * t.DP, EPI_BF16);
+                    e->gemm_vt(k.v2, nullptr, D, P96, nullptr, P96);
+                });
+            }
             size_t peak = e->ws.peak;
             // set_prompts scratch
             size_t sp = (size_t)cfg->max_prompts * 96 * cfg->cross_attention_dim * 2 + (size_t)cfg->max_prompts * (cfg->projection_class_embeddings_input_dim + e->temb_dim) * 4 + (1 << 16);
@@ -832,6 +850,10 @@ int rt_create(const rt_config* cfg, int device, rt_engine** out) {
             e->ws = Workspace();
             HIP_CHECK(hipMalloc((void**)&e->ws.base, peak));
             e->ws.cap = peak;
+            if (e->splitk_need) {
+                HIP_CHECK(hipMalloc((void**)&e->splitk_buf, e->splitk_need * 4));
+                e->splitk_floats = e->splitk_need;
+            }
         }
         e->set_fontsize(nullptr, nullptr, 0);      // multiplier set 0/1 = plain softmax until rt_set_fontsize is called
         *out = e;
@@ -848,7 +870,7 @@ int rt_destroy(rt_engine* e) {
     if (e->arena_base) {
         (void)hipSetDevice(e->device); (void)hipStreamSynchronize(e->stream);
         for (auto& r : e->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
-        (void)hipFree(e->arena_base); (void)hipFree(e->sarena_base); (void)hipFree(e->ws.base); (void)hipFree(e->temb_tab_dev); (void)hipStreamDestroy(e->stream);
+        (void)hipFree(e->arena_base); (void)hipFree(e->sarena_base); (void)hipFree(e->ws.base); (void)hipFree(e->temb_tab_dev); (void)hipFree(e->splitk_buf); (void)hipStreamDestroy(e->stream);
     }
     delete e;
     return RT_OK;

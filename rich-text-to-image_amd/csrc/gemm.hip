@@ -1211,11 +1211,13 @@ static void launch_with_cfg(const GemmArgs& a, int cfg, hipStream_t st) {
 static int g_force_cfg = -1;
 static int g_conv_patch = 1;
 static int g_use16 = 1;
+static int g_splitk = 1;
 #ifdef RT_PROBE
 int g_conv3p_tn = 0;          // probe override of the patch kernel's column-tile count
 #endif
 // bit 0: route eligible convs through the implicit-GEMM kernels; bit 1: keep the 16x16x32 family (gemm16.hip) out (A/B tests)
-void gemm_set_debug(int flags) { g_conv_patch = (flags & 1) ? 0 : 1; g_use16 = (flags & 2) ? 0 : 1; }
+// bit 2: no split-K
+void gemm_set_debug(int flags) { g_conv_patch = (flags & 1) ? 0 : 1; g_use16 = (flags & 2) ? 0 : 1; g_splitk = (flags & 4) ? 0 : 1; }
 
 template <int EPI, bool UP2, int TN>
 static void launch_conv3p_tn(const GemmArgs& a, int ntm, hipStream_t st) {
@@ -1260,93 +1262,29 @@ static bool conv_patch_eligible(const GemmArgs& a) {
 }
 void gemm_force_config(int cfg) { g_force_cfg = cfg; }
 
-// ---------------------------------------------------------------------------------------------- in-situ tile tuner
-// All tile configurations produce bit-identical results, so the REAL launches of a shape can be used to rank them: while a shape is
-// being tuned, successive launches of it cycle through the admissible configurations, each bracketed by a pair of HIP events on
-// the caller's stream; the pairs are resolved lazily (hipEventQuery) at later launches and once every configuration has
-// RT_TUNE_SAMPLES samples the one with the lowest mean wins.  A UNet forward launches its dominant shapes 20-60 times, so they
-// settle within the first forward; nothing is launched twice, no scratch output is needed, and the ranking is taken where it
-// matters - between the layer's real neighbours, on weights that arrive cold from HBM.  (The stand-alone micro-benchmark this
-// replaces re-launched one problem on L2-warm operands: its picks for the GEGLU shape flipped between cfg 0 / 3 / 7 from run to
-// run, which were 199 / 213-216 / 213 us inside the step.)
-#define RT_TUNE_SAMPLES 4
-struct TuneState {
-    int best = -1;                       // final choice (-1: still tuning)
-    int cursor = 0;
-    int issued[RT_NCFG] = {}, n[RT_NCFG] = {};
-    float ms[RT_NCFG] = {};
-};
-struct TunePending { hipEvent_t e0, e1; TuneState* ts; int cfg; };
-struct Tuner {
-    typedef std::tuple<int, int, int, int, int> Key;
-    std::map<Key, TuneState> states;     // node-based: TuneState addresses are stable
-    std::vector<TunePending> pending;    // in stream order
-    std::vector<hipEvent_t> pool;
-    hipEvent_t get() {
-        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
-        hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); return e;
-    }
-    static bool admissible(const GemmArgs& a, int c) {
-        if (a.epi == EPI_GEGLU && !kCfg[c].geglu_ok) return false;
-        if (c == 7 && a.mode != A_DENSE) return false;          // the 8-phase kernel is dense-only
-        return true;
-    }
-    void finalize(const GemmArgs& a, TuneState& ts) {
-        float best_ms = 1e30f;
-        for (int c = 0; c < RT_NCFG; ++c) {
-            if (!admissible(a, c)) continue;
-            if (ts.n[c] < RT_TUNE_SAMPLES) return;
-            best_ms = std::min(best_ms, ts.ms[c] / ts.n[c]);
-        }
-        // within 2 % of the best mean the configurations are indistinguishable in the step time (the clock is power-managed,
-        // DESIGN.md 6.1): take the largest tile among them, which moves the fewest bytes through L2 / HBM per flop
-        int area = -1;
-        for (int c = 0; c < RT_NCFG; ++c) {
-            if (!admissible(a, c) || ts.ms[c] / ts.n[c] > best_ms * 1.02f) continue;
-            if (kCfg[c].BM * kCfg[c].BN > area) { area = kCfg[c].BM * kCfg[c].BN; ts.best = c; }
-        }
-    }
-    void drain() {                                              // resolve the completed event pairs (stream order: stop at the first busy one)
-        size_t k = 0;
-        for (; k < pending.size(); ++k) {
-            TunePending& q = pending[k];
-            if (hipEventQuery(q.e1) != hipSuccess) { (void)hipGetLastError(); break; }
-            float m = 0; HIP_CHECK(hipEventElapsedTime(&m, q.e0, q.e1));
-            q.ts->ms[q.cfg] += m; q.ts->n[q.cfg]++;
-            pool.push_back(q.e0); pool.push_back(q.e1);
-        }
-        pending.erase(pending.begin(), pending.begin() + k);
-    }
-};
-static thread_local Tuner g_tuner;
-
-// returns the configuration for this launch; *timed says whether the caller should bracket the launch with events (tune_begin / tune_end)
-static int pick_config(const GemmArgs& a, hipStream_t st, TuneState** timed) {
-    *timed = nullptr;
-    if (g_force_cfg >= 0) return (a.epi == EPI_GEGLU && !kCfg[g_force_cfg].geglu_ok) ? 0 : g_force_cfg;
-    if ((long)a.M * a.N < 256L * 256 * 64) return 0;                  // tiny problems: keep the small tile, skip tuning
-    TuneState& ts = g_tuner.states[Tuner::Key(a.mode, a.epi == EPI_GEGLU, a.M, a.N, a.K)];
-    if (ts.best >= 0) return ts.best;
-    g_tuner.drain();
-    g_tuner.finalize(a, ts);
-    if (ts.best >= 0) return ts.best;
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    (void)hipStreamIsCapturing(st, &cs);
-    const bool can_time = cs == hipStreamCaptureStatusNone && g_tuner.pending.size() < 4096;
-    for (int step = 0; can_time && step < RT_NCFG; ++step) {          // next admissible configuration that still needs samples
-        const int c = (ts.cursor + step) % RT_NCFG;
-        if (!Tuner::admissible(a, c) || ts.issued[c] >= RT_TUNE_SAMPLES) continue;
-        ts.cursor = (c + 1) % RT_NCFG;
-        ts.issued[c]++;
-        *timed = &ts;
-        return c;
-    }
-    // every sample is in flight (or events cannot be recorded here): best mean so far, else the default tile
-    int prov = a.epi == EPI_GEGLU ? 3 : 2;
-    float best_ms = 1e30f;
-    for (int c = 0; c < RT_NCFG; ++c)
-        if (ts.n[c] > 0 && ts.ms[c] / ts.n[c] < best_ms) { best_ms = ts.ms[c] / ts.n[c]; prov = c; }
-    return prov;
+// ---------------------------------------------------------------------------------------------- tile choice (gemm.hip kernels)
+// A pure function of the problem shape - no timing, no state (round 2 ranked the configurations in situ with HIP events on the
+// caller's stream: different runs / batch sizes ran different kernels, events were recorded on foreign devices' streams, and a
+// stream under capture could not be tuned).  All configurations of this file are bit-identical, so the rule only matters for speed.
+// What is left here after gemm16.hip took the dense K % 128 == 0 problems: the implicit-GEMM convolutions that are not patch-eligible
+// (conv_in / conv_out / stride-2 downsamplers / tiny maps), 1x1 shortcuts with K = 320 / 960, the text encoders, the VAE's 512-wide layers.
+static bool cfg_admissible(const GemmArgs& a, int c) {
+    if (a.epi == EPI_GEGLU && !kCfg[c].geglu_ok) return false;
+    if (c == 7 && a.mode != A_DENSE) return false;                  // the 8-phase kernel is dense-only
+    return true;
+}
+static int pick_config(const GemmArgs& a) {
+    if (g_force_cfg >= 0) return cfg_admissible(a, g_force_cfg) ? g_force_cfg : 0;
+    if ((long)a.M * a.N < 256L * 256 * 64) return 0;                  // small problems: 128x128 tiles, two workgroups per CU
+    auto wgs = [&](int c) { return (long)cdiv(a.M, kCfg[c].BM) * cdiv(a.N, kCfg[c].BN); };
+    int c;
+    if (a.epi == EPI_GEGLU) c = 3;
+    else if (a.N % 320 == 0 && wgs(8) >= 192) c = 8;
+    else if (a.N % 160 == 0) c = 2;
+    else if (a.N >= 1024 && a.mode == A_DENSE) c = 3;
+    else c = 1;
+    if (wgs(c) < 160 && wgs(0) > wgs(c)) c = 0;                      // a big tile that leaves > 1/3 of the CUs idle: smaller tiles
+    return c;
 }
 
 struct ReduceArgs {
@@ -1411,17 +1349,37 @@ static int splitk_slices(const GemmArgs& a) {
     return s < 2 ? 1 : s;
 }
 
+size_t gemm_splitk_scratch_floats(const GemmArgs& a) {
+    const int S = splitk_slices(a);
+    return S > 1 ? (size_t)S * a.M * ((a.N + 3) & ~3) : 0;
+}
+
+// Partial-sum scratch.  An engine hands in its own buffer (GemmArgs.splitk_ws, sized by the dry pass of its plan: nothing is
+// allocated inside a forward and the launch is capturable).  Stand-alone callers (rt_op_gemm, the text encoders) fall back to one
+// buffer per (device, stream): two streams never share partial sums, and growing it synchronises exactly the stream that uses it.
+static float* splitk_fallback_buffer(size_t need, hipStream_t st) {
+    struct Buf { float* p = nullptr; size_t floats = 0; };
+    static thread_local std::map<std::pair<int, hipStream_t>, Buf> bufs;
+    int dev = 0; HIP_CHECK(hipGetDevice(&dev));
+    Buf& b = bufs[std::make_pair(dev, st)];
+    if (need > b.floats) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(st, &cap);
+        if (cap != hipStreamCaptureStatusNone)
+            throw rt_error(RT_E_STATE, "gemm: split-K scratch must be provided (GemmArgs.splitk_ws) or warmed up before stream capture");
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (b.p) (void)hipFree(b.p);
+        b.p = nullptr; b.floats = 0;
+        HIP_CHECK(hipMalloc((void**)&b.p, need * 4));
+        b.floats = need;
+    }
+    return b.p;
+}
+
 static void launch_gemm_splitk(const GemmArgs& a, int S, hipStream_t st) {
-    static thread_local float* buf = nullptr;
-    static thread_local size_t buf_floats = 0;
     const int ldp = (a.N + 3) & ~3;
     const size_t slice = (size_t)a.M * ldp, need = slice * S;
-    if (need > buf_floats) {                                         // grows during warm-up only
-        HIP_CHECK(hipStreamSynchronize(st));
-        if (buf) (void)hipFree(buf);
-        HIP_CHECK(hipMalloc((void**)&buf, need * 4));
-        buf_floats = need;
-    }
+    float* buf = (a.splitk_ws && a.splitk_ws_floats >= need) ? a.splitk_ws : splitk_fallback_buffer(need, st);
     GemmArgs g = a;
     g.epi = EPI_F32; g.bias = nullptr; g.res = nullptr; g.temb = nullptr; g.out = buf; g.ldo = ldp;
     {
@@ -1475,9 +1433,9 @@ void launch_gemm(const GemmArgs& a, hipStream_t st) {
     if (a.bias) RT_REQUIRE(((uintptr_t)a.bias & 15) == 0, "gemm: bias must be 16-B aligned");
     if (a.temb) RT_REQUIRE(a.temb_ld % 4 == 0 && ((uintptr_t)a.temb & 15) == 0, "gemm: temb must be 16-B aligned");
     // In-place residual (out == res) is safe: every element is read and written by the same thread.
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    (void)hipStreamIsCapturing(st, &cap);
-    const int ksl = (g_force_cfg < 0 && cap == hipStreamCaptureStatusNone) ? splitk_slices(a) : 1;
+    // split-K is a function of the shape only (not of a forced tile configuration, not of stream capture): the same problem
+    // always takes the same path.  Debug bit 2 (rt_op_gemm_debug(4)) switches it off for A/B tests.
+    const int ksl = g_splitk ? splitk_slices(a) : 1;
     // patch convolutions that cannot fill the chip (< 128 workgroups) go through the split-K implicit GEMM as well
     const bool patch_underfilled = ksl > 1 && a.mode != A_DENSE;
     if (conv_patch_eligible(a) && !patch_underfilled) {
@@ -1497,12 +1455,5 @@ void launch_gemm(const GemmArgs& a, hipStream_t st) {
         const int v = gemm16_pick(a, a.weights_on_rows, &wstat);
         if (v >= 0) { launch_gemm16_variant(a, v, wstat, st); return; }
     }
-    TuneState* timed = nullptr;
-    const int cfg = pick_config(a, st, &timed);
-    if (!timed) { launch_with_cfg(a, cfg, st); return; }
-    TunePending q{g_tuner.get(), g_tuner.get(), timed, cfg};
-    HIP_CHECK(hipEventRecord(q.e0, st));
-    launch_with_cfg(a, cfg, st);
-    HIP_CHECK(hipEventRecord(q.e1, st));
-    g_tuner.pending.push_back(q);
+    launch_with_cfg(a, pick_config(a), st);
 }

@@ -29,6 +29,19 @@
 
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
+// probe builds only (tools/probes/gemm16_bench.hip -DRT_G16_TIMING): s_memtime stamps of wave 0 of every workgroup at kernel entry,
+// first tile landed, end of the K loop, end of the K-split exchange, all stores retired.  RT_G16_ABLATE: 1 = no LDS-DMA inside the
+// loop, 2 = no MFMA (operands kept alive), to see which of the two bounds the loop.
+#ifdef RT_G16_TIMING
+__device__ long long g_g16_times[8192 * 8];
+#define G16_T(i) { if (tid == 0) g_g16_times[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); }
+#else
+#define G16_T(i)
+#endif
+#ifndef RT_G16_ABLATE
+#define RT_G16_ABLATE 0
+#endif
+
 // LDS-DMA through a buffer descriptor: buffer_load_dwordx4 v(voff), s[rsrc], s(soff) offen lds.  `base` must be wave-uniform; the
 // descriptor is rebuilt from it at every call site (4 SALU moves, hoisted by the compiler).  Kept in a non-template __device__
 // function: the descriptor type exists in device compilation only and a kernel TEMPLATE that names it loses its host-side stub.
@@ -38,19 +51,20 @@ __device__ __forceinline__ void glds16_buf(const void* base, int voff_bytes, int
 }
 
 template <int EPI, int TMW, int TNW, int WM, int WN, int WK, int S>
-__global__ __launch_bounds__(512) void gemm16_kernel(GemmArgs p, int wstat) {
-    static_assert(WM * WN * WK == 8, "8 waves");
-    static_assert(WK == 1 || WK == 2, "K split over at most two waves");
-    constexpr int NW = 8;
+__global__ __launch_bounds__(WM * WN * WK * 64) void gemm16_kernel(GemmArgs p, int wstat) {
+    constexpr int NW = WM * WN * WK;                       // 8 waves (two per SIMD) or 4 waves (one per SIMD, 512 registers each)
+    static_assert(NW == 8 || NW == 4, "4 or 8 waves");
+    static_assert(WK == 1 || (WK == 2 && S == 3), "K split over at most two waves (3-slot ring)");
     constexpr int BM = WM * TMW * 16, BN = WN * TNW * 16;
     constexpr int STAGE = (BM + BN) * 128;                 // bytes per ring slot: A rows then W rows, 128 B (64 k) each
     constexpr int GA = BM / 8, GB = BN / 8, GT = GA + GB;  // 8-row groups = one wave-wide LDS-DMA each
     constexpr int PW = (GT + NW - 1) / NW;                 // LDS-DMA pieces per wave and K tile
     constexpr int KS = 2 / WK;                             // 32-deep k steps per K tile and wave
-    static_assert(EPI != EPI_GEGLU || TNW == 4, "GEGLU: a wave owns one packed 64-column block [32 value | 32 gate]");
+    static_assert(EPI != EPI_GEGLU || TNW % 4 == 0, "GEGLU: a wave owns whole packed 64-column blocks [32 value | 32 gate]");
     static_assert((S - 2) * PW <= 63 && S >= 2 && S <= 3, "ring depth");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
+    G16_T(0)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kh = WK == 2 ? (wave & 1) : 0;
     const int wq = WK == 2 ? (wave >> 1) : wave;
@@ -76,7 +90,7 @@ __global__ __launch_bounds__(512) void gemm16_kernel(GemmArgs p, int wstat) {
     }
     const int m0 = tm * BM, n0 = tn * BN;
 
-    // ---- loader: piece i of this wave copies 8-row group g = i*8 + wave of the (A rows | W rows) list.  Buffer-descriptor LDS-DMA
+    // ---- loader: piece i of this wave copies 8-row group g = i*NW + wave of the (A rows | W rows) list.  Buffer-descriptor LDS-DMA
     // (buffer_load_dwordx4 ... offen lds, guide T8): per piece ONE 32-bit VGPR byte offset, the K-tile offset is a scalar (soffset)
     // and the operand base sits in an SGPR descriptor - the flat form kept a 64-bit address per piece alive and spilled in the loop.
     const int lrow = lane >> 3, pslot = lane & 7;
@@ -96,16 +110,9 @@ __global__ __launch_bounds__(512) void gemm16_kernel(GemmArgs p, int wstat) {
         pisA[i] = isA;
         ldst[i] = (isA ? 0 : BM * 128) + gl * 1024;
     }
-    const int nk = p.K / BK16;                                       // host guarantees K % 64 == 0
-    // K tile t -> slot t % S.  Behind the last tile the copies re-read tile nk-1 into a free slot: the vmcnt bookkeeping stays uniform.
-    auto stage_piece = [&](int t, int slot_off, int i) {
-        const int tt = t < nk ? t : nk - 1;
-        char* dst = smem + slot_off + ldst[i];
-        glds16_buf(pisA[i] ? (const void*)p.A : (const void*)p.W, voff[i], tt * (BK16 * 2), dst);
-    };
-    auto stage = [&](int t) {
-#pragma unroll
-        for (int i = 0; i < PW; ++i) stage_piece(t, t * STAGE, i);     // prologue only: t < S
+    const int nk = p.K / BK16;                                       // host guarantees K % 128 == 0, K >= 256 (nk >= S + 1)
+    auto stage_piece = [&](int t, int slot_off, int i) {             // piece i of K tile t -> ring slot at slot_off
+        glds16_buf(pisA[i] ? (const void*)p.A : (const void*)p.W, voff[i], t * (BK16 * 2), smem + slot_off + ldst[i]);
     };
 
     // ---- fragments: lane (l15, q): row l15 of a 16-row tile, 16-B chunk c = 4*khalf + q of the 128-B row
@@ -126,10 +133,13 @@ __global__ __launch_bounds__(512) void gemm16_kernel(GemmArgs p, int wstat) {
 
     // ---- prologue: all S slots in flight; tile 0 landed; fragments of k step 0 in registers
 #pragma unroll
-    for (int s = 0; s < S; ++s) stage(s);
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int i = 0; i < PW; ++i) stage_piece(s, s * STAGE, i);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 1) * PW) : "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    G16_T(1)
     bf16x8 fa[TMW], fb[2][TNW];
 #pragma unroll
     for (int j = 0; j < TNW; ++j) fb[0][j] = *(const bf16x8*)(smem + boff[0] + j * 2048);
@@ -137,11 +147,14 @@ __global__ __launch_bounds__(512) void gemm16_kernel(GemmArgs p, int wstat) {
     for (int i = 0; i < TMW; ++i) fa[i] = *(const bf16x8*)(smem + aoff[0] + i * 2048);
 
     // One k step.  CUR: which W fragment set it multiplies.  KSI: k step inside the tile.  NEXT: 0 = no further step,
-    // 1 = next step is in the same K tile, 2 = next step opens K tile t+1 (wait + barrier, then refill tile t's slot with tile t+S).
+    // 1 = next step is in the same K tile, 2 = next step opens K tile t+1: wait for it (BEHIND = K tiles that may stay in flight
+    // behind it) + barrier, then - REFILL - copy tile t+S into tile t's slot.
     // cur_off / nxt_off: LDS byte offsets of the slots of tiles t and t+1 (scalars carried by the loop; no modulo arithmetic in
     // the loop: hipcc's strength reduction turned `% 3` into per-fragment VGPR induction variables that spilled).
-    auto kstep = [&](int t, int cur_off, int nxt_off, auto cur_c, auto ksi_c, auto next_c) {
+    auto kstep = [&](int t, int cur_off, int nxt_off, auto cur_c, auto ksi_c, auto next_c, auto refill_c, auto behind_c) {
         constexpr int CUR = decltype(cur_c)::value, KSI = decltype(ksi_c)::value, NEXT = decltype(next_c)::value;
+        constexpr bool REFILL = decltype(refill_c)::value != 0;
+        constexpr int BEHIND = decltype(behind_c)::value;
         constexpr int NKS = NEXT == 1 ? KSI + 1 : 0;                 // k step index of the next step inside its tile
         const int rd = __builtin_amdgcn_readfirstlane(NEXT == 2 ? nxt_off : cur_off);
         const char* na = smem + rd + aoff[NKS];
@@ -149,10 +162,16 @@ __global__ __launch_bounds__(512) void gemm16_kernel(GemmArgs p, int wstat) {
         // row 0 first: its operands were read a whole step ago, and the last fragment read of the previous step (issued behind
         // that step's last MFMA row) retires behind these MFMAs instead of in front of the barrier
 #pragma unroll
-        for (int j = 0; j < TNW; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[CUR][j], fa[0], acc[0][j], 0, 0, 0);
+        for (int j = 0; j < TNW; ++j) {
+#if RT_G16_ABLATE == 2
+            asm volatile("" ::"v"(fb[CUR][j]), "v"(fa[0]));
+#else
+            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[CUR][j], fa[0], acc[0][j], 0, 0, 0);
+#endif
+        }
         if constexpr (NEXT == 2) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // every fragment read of tile t is retired: its slot may be refilled
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * PW) : "memory");   // this wave's pieces of tile t+1 landed
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BEHIND * PW) : "memory");   // this wave's pieces of tile t+1 landed
             __builtin_amdgcn_s_barrier();
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -164,114 +183,168 @@ __global__ __launch_bounds__(512) void gemm16_kernel(GemmArgs p, int wstat) {
 #pragma unroll
         for (int i = 1; i < TMW; ++i) {
 #pragma unroll
-            for (int j = 0; j < TNW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[CUR][j], fa[i], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TNW; ++j) {
+#if RT_G16_ABLATE == 2
+                asm volatile("" ::"v"(fb[CUR][j]), "v"(fa[i]));
+#else
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[CUR][j], fa[i], acc[i][j], 0, 0, 0);
+#endif
+            }
             if constexpr (NEXT != 0) fa[i] = *(const bf16x8*)(na + i * 2048);
-            if constexpr (NEXT == 2) {
+            if constexpr (NEXT == 2 && REFILL) {
                 // LDS-DMA issue slots spread behind the MFMA rows (a piece costs its wave 60-200 cycles of issue under load)
                 constexpr int PPR = (PW + TMW - 2) / (TMW - 1);      // pieces per MFMA row
+#if RT_G16_ABLATE != 1
 #pragma unroll
                 for (int pc = 0; pc < PPR; ++pc) { const int pi = (i - 1) * PPR + pc; if (pi < PW) stage_piece(t + S, cur_off, pi); }
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
     using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>; using C2 = std::integral_constant<int, 2>;
+    using CS2 = std::integral_constant<int, S - 2>;
     int cur_off = 0, nxt_off = STAGE;
     auto advance = [&]() { cur_off = nxt_off; nxt_off = nxt_off + STAGE == S * STAGE ? 0 : nxt_off + STAGE; };
+    // Tiles t <= nk-S-1 refill their slot (steady state); the last S tiles do not, and the wait in front of tile t+1 allows exactly
+    // the min(S-2, nk-2-t) younger tiles that were issued: no dummy copies, nothing to drain behind the loop.
     if constexpr (KS == 1) {
+        // K-split class: CUR alternates per tile, so tiles run in pairs; the host guarantees an even tile count, S = 3, nk >= 4
         int t = 0;
-        for (; t + 2 < nk; t += 2) {
-            kstep(t, cur_off, nxt_off, C0{}, C0{}, C2{}); advance();
-            kstep(t + 1, cur_off, nxt_off, C1{}, C0{}, C2{}); advance();
+        for (; t + 6 <= nk; t += 2) {
+            kstep(t, cur_off, nxt_off, C0{}, C0{}, C2{}, C1{}, CS2{}); advance();
+            kstep(t + 1, cur_off, nxt_off, C1{}, C0{}, C2{}, C1{}, CS2{}); advance();
         }
-        // host guarantees an even number of K tiles for the K-split class (K % 128 == 0): one tail shape, no register shuffling
-        kstep(t, cur_off, nxt_off, C0{}, C0{}, C2{}); advance(); kstep(t + 1, cur_off, nxt_off, C1{}, C0{}, C0{});
+        kstep(t, cur_off, nxt_off, C0{}, C0{}, C2{}, C1{}, CS2{}); advance();            // t = nk-4: the last refill (tile nk-1)
+        kstep(t + 1, cur_off, nxt_off, C1{}, C0{}, C2{}, C0{}, C1{}); advance();         // nk-3: tile nk-1 may stay in flight
+        kstep(t + 2, cur_off, nxt_off, C0{}, C0{}, C2{}, C0{}, C0{}); advance();         // nk-2
+        kstep(t + 3, cur_off, nxt_off, C1{}, C0{}, C0{}, C0{}, C0{});                    // nk-1
     } else {
         int t = 0;
-        for (; t + 1 < nk; ++t) { kstep(t, cur_off, nxt_off, C0{}, C0{}, C1{}); kstep(t, cur_off, nxt_off, C1{}, C1{}, C2{}); advance(); }
-        kstep(t, cur_off, nxt_off, C0{}, C0{}, C1{}); kstep(t, cur_off, nxt_off, C1{}, C1{}, C0{});
+        for (; t + S < nk; ++t) {
+            kstep(t, cur_off, nxt_off, C0{}, C0{}, C1{}, C0{}, C0{});
+            kstep(t, cur_off, nxt_off, C1{}, C1{}, C2{}, C1{}, CS2{}); advance();
+        }
+        if constexpr (S == 3) {                                                          // t = nk-3
+            kstep(t, cur_off, nxt_off, C0{}, C0{}, C1{}, C0{}, C0{});
+            kstep(t, cur_off, nxt_off, C1{}, C1{}, C2{}, C0{}, C1{}); advance(); ++t;
+        }
+        kstep(t, cur_off, nxt_off, C0{}, C0{}, C1{}, C0{}, C0{});                        // t = nk-2
+        kstep(t, cur_off, nxt_off, C1{}, C1{}, C2{}, C0{}, C0{}); advance(); ++t;
+        kstep(t, cur_off, nxt_off, C0{}, C0{}, C1{}, C0{}, C0{});                        // t = nk-1
+        kstep(t, cur_off, nxt_off, C1{}, C1{}, C0{}, C0{}, C0{});
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the dummy copies behind the last tile
-    __syncthreads();                                                 // the ring is free: exchange buffers + transpose slabs
+    G16_T(2)
 
-    // ---- K-split reduction: kh = 0 ends up owning row tiles [0, H0), kh = 1 owns [H0, TMW).  Two passes through one LDS region.
-    constexpr int H0 = (TMW + 1) / 2;
-    if constexpr (WK == 2) {
-        static_assert(4 * H0 * TNW * 1024 <= S * STAGE, "exchange region");
-        char* xr = smem + (size_t)wq * (H0 * TNW * 1024) + lane * 16;
-        if (kh == 1) {
-#pragma unroll
-            for (int i = 0; i < H0; ++i)
-#pragma unroll
-                for (int j = 0; j < TNW; ++j) *(f32x4_t*)(xr + (i * TNW + j) * 1024) = acc[i][j];
-        }
-        __syncthreads();
-        if (kh == 0) {
-#pragma unroll
-            for (int i = 0; i < H0; ++i)
-#pragma unroll
-                for (int j = 0; j < TNW; ++j) acc[i][j] += *(const f32x4_t*)(xr + (i * TNW + j) * 1024);
-        }
-        __syncthreads();
-        if (kh == 0) {
-#pragma unroll
-            for (int i = H0; i < TMW; ++i)
-#pragma unroll
-                for (int j = 0; j < TNW; ++j) *(f32x4_t*)(xr + ((i - H0) * TNW + j) * 1024) = acc[i][j];
-        }
-        __syncthreads();
-        if (kh == 1) {
-            // acc(kh=0) + acc(kh=1) in that order in both halves: even k steps first
-#pragma unroll
-            for (int i = H0; i < TMW; ++i)
-#pragma unroll
-                for (int j = 0; j < TNW; ++j) acc[i][j] = *(const f32x4_t*)(xr + ((i - H0) * TNW + j) * 1024) + acc[i][j];
-        }
-        __syncthreads();
-    }
-
-    // ---- epilogue: lane (l15, q4) holds row l15 and columns 4*q4 .. +3 of every 16x16 tile.  Each wave transposes one 16-row tile
-    // at a time through its private slab and moves row-contiguous 16-B chunks to / from HBM (guide T21).
+    // ---- which 16-row tiles this wave finishes: K-split: kh = 0 owns row tiles [0, H0), kh = 1 owns [H0, TMW)
+    constexpr int H0 = WK == 2 ? (TMW + 1) / 2 : TMW;
+    auto owned = [&](int i) { return WK == 1 || ((i < H0) == (kh == 0)); };           // wave-uniform
     constexpr bool F16 = EPI == EPI_F16;
     constexpr bool F32 = EPI == EPI_F32 || F16;                      // fp32 slab; F16: fp16 in HBM (output and residual), rounded once
     constexpr int ES = F32 ? 4 : 2;
     constexpr int TNO = EPI == EPI_GEGLU ? TNW / 2 : TNW;            // 16-column output tiles per wave
-    constexpr int RS = TNO * 16 * ES + 16;                           // slab row stride (16-B pad: conflict-free 16-B column writes)
-    static_assert(8 * 16 * RS <= S * STAGE, "slabs");
-    char* slab = smem + (size_t)wave * 16 * RS;
     const int NO = EPI == EPI_GEGLU ? (p.N >> 1) : p.N;
     const int wcol0 = n0 + wn * TNW * 16;                            // first (packed) column of this wave
     const int ocol0 = EPI == EPI_GEGLU ? (wcol0 >> 1) : wcol0;
-    float bias_v[TNO][4], bias_g[TNO][4];
+    // fp16 residual of the owned tiles: requested NOW, ahead of the K-split exchange / the first slab transposes, so that its HBM
+    // round trip is paid once and in the shadow of that work (issued tile by tile inside the store loop it was paid TMW times:
+    // 14.5 k of the 51 k cycles of a 7168 x 1280 x 1280 launch, profiles/r3_gemm16_probe_v1_timing.txt)
+    constexpr int IPR = TNO * 16 / 8;                                // 8-column items per row
+    constexpr int NIT = (16 * IPR + 63) / 64;
+    // a rolling window of RW owned tiles (static register indices: the s-th owned tile of a wave is tile s or H0 + s)
+    constexpr int NOWN = WK == 2 ? H0 : TMW;                         // owned tiles of the kh = 0 half (kh = 1 owns TMW - H0 <= H0)
+    constexpr int RW = NOWN < 4 ? NOWN : 4;
+    uint4 rres[F16 ? RW : 1][F16 ? NIT : 1];
+    auto load_res = [&](int s_own, int slot) {                       // residual of the s_own-th owned tile -> window slot (static)
+        const int i = (WK == 2 && kh == 1) ? H0 + s_own : s_own;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = it * 64 + lane;
+            const int r = idx / IPR, c8 = idx - r * IPR;
+            int row = m0 + (wm * TMW + i) * 16 + r; if (row >= p.M) row = p.M - 1;
+            int col = ocol0 + c8 * 8; if (col >= NO) col = 0;
+            if (F16) rres[F16 ? slot : 0][F16 ? it : 0] = (r < 16 && i < TMW) ? *(const uint4*)((const f16_t*)p.res + (size_t)row * p.ldres + col) : uint4{0, 0, 0, 0};
+        }
+    };
+    if constexpr (F16) {
+        if (p.res) {
+#pragma unroll
+            for (int s_own = 0; s_own < RW; ++s_own) load_res(s_own, s_own);
+        }
+    }
+    // raw barriers from here on: a __syncthreads() carries s_waitcnt vmcnt(0) and would wait for the residual round trip
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                    // every wave left the ring: exchange buffers + transpose slabs
+
+    // ---- K-split reduction through LDS in ONE pass: every wave parks the partial sums of the row tiles its partner owns, one
+    // barrier, every wave adds its partner's partials to the tiles it owns (kh = 0 + kh = 1 in that order in both halves).
+    if constexpr (WK == 2) {
+        static_assert((NW / 2) * TMW * TNW * 1024 <= S * STAGE, "exchange region");
+        char* xr = smem + (size_t)wq * (TMW * TNW * 1024) + lane * 16;
+#pragma unroll
+        for (int i = 0; i < TMW; ++i) {
+            if (owned(i)) continue;
+#pragma unroll
+            for (int j = 0; j < TNW; ++j) *(f32x4_t*)(xr + (i * TNW + j) * 1024) = acc[i][j];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int i = 0; i < TMW; ++i) {
+            if (!owned(i)) continue;
+#pragma unroll
+            for (int j = 0; j < TNW; ++j) {
+                const f32x4_t o = *(const f32x4_t*)(xr + (i * TNW + j) * 1024);
+                acc[i][j] = kh == 0 ? acc[i][j] + o : o + acc[i][j];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                // the exchange region becomes the transpose slabs
+    }
+    G16_T(3)
+
+    // ---- epilogue: lane (l15, q4) holds row l15 and columns 4*q4 .. +3 of every 16x16 tile.  Each wave transposes one 16-row tile
+    // at a time through its private slab and moves row-contiguous 16-B chunks to / from HBM (guide T21).
+    constexpr int RS = TNO * 16 * ES + 16;                           // slab row stride (16-B pad: conflict-free 16-B column writes)
+    static_assert(NW * 16 * RS <= S * STAGE, "slabs");
+    char* slab = smem + (size_t)wave * 16 * RS;
+    float bias_v[TNO][4], bias_g[EPI == EPI_GEGLU ? TNO : 1][4];
 #pragma unroll
     for (int t = 0; t < TNO; ++t) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { bias_v[t][e] = 0.f; bias_g[t][e] = 0.f; }
-        const int col = wcol0 + t * 16 + 4 * q4;
+        for (int e = 0; e < 4; ++e) { bias_v[t][e] = 0.f; if (EPI == EPI_GEGLU) bias_g[t][e] = 0.f; }
         if (p.bias) {
             if constexpr (EPI == EPI_GEGLU) {
-                if (wcol0 + 64 <= p.N) {
+                // packed columns: per 64-block [32 value | 32 gate]; output tile t (16 columns) = value tile 4*(t/2) + t%2, gate + 2
+                const int col = wcol0 + ((t >> 1) * 4 + (t & 1)) * 16 + 4 * q4;
+                if (col + 32 + 4 <= p.N) {
                     const float4 b0 = *(const float4*)(p.bias + col), b1 = *(const float4*)(p.bias + col + 32);
                     bias_v[t][0] = b0.x; bias_v[t][1] = b0.y; bias_v[t][2] = b0.z; bias_v[t][3] = b0.w;
                     bias_g[t][0] = b1.x; bias_g[t][1] = b1.y; bias_g[t][2] = b1.z; bias_g[t][3] = b1.w;
                 }
-            } else if (col < p.N) {
-                const float4 b0 = *(const float4*)(p.bias + col);
-                bias_v[t][0] = b0.x; bias_v[t][1] = b0.y; bias_v[t][2] = b0.z; bias_v[t][3] = b0.w;
+            } else {
+                const int col = wcol0 + t * 16 + 4 * q4;
+                if (col < p.N) {
+                    const float4 b0 = *(const float4*)(p.bias + col);
+                    bias_v[t][0] = b0.x; bias_v[t][1] = b0.y; bias_v[t][2] = b0.z; bias_v[t][3] = b0.w;
+                }
             }
         }
     }
 #pragma unroll
     for (int i = 0; i < TMW; ++i) {
-        if (WK == 2 && ((i < H0) != (kh == 0))) continue;            // wave-uniform
+        if (!owned(i)) continue;
         // registers -> slab
 #pragma unroll
         for (int t = 0; t < TNO; ++t) {
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if constexpr (EPI == EPI_GEGLU) v[e] = (acc[i][t][e] + bias_v[t][e]) * gelu_erf(acc[i][t + 2][e] + bias_g[t][e]);
-                else v[e] = acc[i][t][e] + bias_v[t][e];
+                if constexpr (EPI == EPI_GEGLU) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int tv = (t >> 1) * 4 + (t & 1);
+                    v[e] = (acc[i][tv][e] + bias_v[t][e]) * gelu_erf(acc[i][tv + 2][e] + bias_g[t][e]);
+                } else v[e] = acc[i][t][e] + bias_v[t][e];
             }
             char* dst = slab + l15 * RS + (t * 16 + 4 * q4) * ES;
             if constexpr (F32) *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
@@ -280,18 +353,16 @@ __global__ __launch_bounds__(512) void gemm16_kernel(GemmArgs p, int wstat) {
         // slab -> HBM (LDS operations of one wave execute in order: no barrier)
         const int row0 = m0 + (wm * TMW + i) * 16;
         if constexpr (F16) {
-            constexpr int IPR = TNO * 16 / 8;                        // 8-column items per row
 #pragma unroll
-            for (int idx0 = 0; idx0 < 16 * IPR; idx0 += 64) {
-                const int idx = idx0 + lane;
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = it * 64 + lane;
                 const int r = idx / IPR, c8 = idx - r * IPR;
                 const int row = row0 + r, col = ocol0 + c8 * 8;
                 if (r >= 16 || row >= p.M || col >= NO) continue;
                 const float4 a0 = *(const float4*)(slab + r * RS + c8 * 32), a1 = *(const float4*)(slab + r * RS + c8 * 32 + 16);
                 float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
                 if (p.res) {
-                    const uint4 rq = *(const uint4*)((const f16_t*)p.res + (size_t)row * p.ldres + col);
-                    const f16_t* rh = (const f16_t*)&rq;
+                    const f16_t* rh = (const f16_t*)&rres[F16 ? ((i < H0 ? i : i - H0) % RW) : 0][it];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += (float)rh[e];
                 }
@@ -300,6 +371,9 @@ __global__ __launch_bounds__(512) void gemm16_kernel(GemmArgs p, int wstat) {
                 for (int e = 0; e < 8; ++e) oh[e] = (f16_t)v[e];
                 *(uint4*)((f16_t*)p.out + (size_t)row * p.ldo + col) = o;
             }
+            // the window slot of this tile is free: request the residual of the owned tile RW positions further on
+            const int s_own = i < H0 ? i : i - H0;                   // compile-time after unrolling
+            if (s_own + RW < NOWN && p.res) load_res(s_own + RW, s_own % RW);
         } else {
             constexpr int CPR = TNO * 16 * ES / 16;                  // 16-B chunks per row
 #pragma unroll
@@ -319,6 +393,10 @@ __global__ __launch_bounds__(512) void gemm16_kernel(GemmArgs p, int wstat) {
             }
         }
     }
+#ifdef RT_G16_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    G16_T(4)
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------- launch
@@ -334,6 +412,9 @@ static const G16Var kVar[RT_G16_NVAR] = {
     {160, 224, 2, 3, 0},   // 6  class B transposed: V^T = Wv X^T (rows = head channels, columns = tokens)
     {160, 128, 2, 3, 0},   // 7  class B transposed, 128 token columns
     {128, 256, 1, 3, 1},   // 8  class A, 128 rows
+    // (measured and dropped, profiles/r3_gemm16_probe_v2_timing.txt: FOUR-wave forms of 224x160 / 224x320 / 224x256 - one wave per
+    //  SIMD with its accumulators in AGPRs, no K split / no exchange - run their K loop at 46 k instead of 25.5 k cycles: a single
+    //  compiler-scheduled wave does not keep the matrix pipe fed.  The kernel template still takes WM*WN*WK == 4.)
 };
 
 template <int EPI, int TMW, int TNW, int WM, int WN, int WK, int S>
@@ -347,7 +428,7 @@ static void launch_v(const GemmArgs& a, int wstat, hipStream_t st) {
     }
     const int ntn = cdiv(a.N, BN), ntm = cdiv(a.M, BM);
     if (wstat && (ntn % 8 != 0)) wstat = 0;
-    hipLaunchKernelGGL((gemm16_kernel<EPI, TMW, TNW, WM, WN, WK, S>), dim3(ntm * ntn), dim3(512), LDS, st, a, wstat);
+    hipLaunchKernelGGL((gemm16_kernel<EPI, TMW, TNW, WM, WN, WK, S>), dim3(ntm * ntn), dim3(WM * WN * WK * 64), LDS, st, a, wstat);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -374,14 +455,14 @@ static void launch_e(const GemmArgs& a, int v, int wstat, hipStream_t st) {
 }
 
 bool gemm16_supported(const GemmArgs& a) {
-    if (a.mode != A_DENSE || a.K % (2 * BK16) != 0) return false;      // K % 128: the K-split class runs pairs of K tiles
+    if (a.mode != A_DENSE || a.K % (2 * BK16) != 0 || a.K < 4 * BK16) return false;      // K % 128 (the K-split class runs pairs of K tiles), >= 4 tiles
     if (!(a.epi == EPI_BF16 || a.epi == EPI_F32 || a.epi == EPI_F16 || a.epi == EPI_GEGLU)) return false;
     if (a.lda % 8 || a.ldw % 8) return false;
     return true;
 }
 
 void launch_gemm16_variant(const GemmArgs& a, int v, int wstat, hipStream_t st) {
-    RT_REQUIRE(gemm16_supported(a), "gemm16: problem outside the family's domain (dense, K % 128 == 0)");
+    RT_REQUIRE(gemm16_supported(a), "gemm16: problem outside the family's domain (dense, K % 128 == 0, K >= 256)");
     RT_REQUIRE(v >= 0 && v < RT_G16_NVAR, "gemm16: variant");
     switch (a.epi) {
         case EPI_BF16: launch_e<EPI_BF16>(a, v, wstat, st); break;
@@ -404,9 +485,10 @@ int gemm16_pick(const GemmArgs& a, int weights_on_rows, int* wstat) {
     const double nk = a.K / 64.0;
     // launch time model in units of one K tile of a 224x160 tile: whole rounds of 256 workgroups (one per CU) x (K tiles x tile
     // area + a fixed prologue / epilogue share); tiles of 128 rows feed the matrix pipe ~20 % worse per flop
+    // (measured, profiles/r3_gemm16_probe_v1.txt: the steady-state loop follows the bytes a K tile copies into LDS, (BM + BN) rows)
     auto cost = [&](int BMv, int BNv, double eff) {
         const long tiles = (long)cdiv(a.M, BMv) * cdiv(a.N, BNv);
-        return (double)((tiles + 255) / 256) * (nk * BMv * BNv / (224.0 * 160.0) * eff + 6.0);
+        return (double)((tiles + 255) / 256) * (nk * (BMv + BNv) / 384.0 * eff + 12.0);
     };
     if (weights_on_rows) {
         if (a.epi != EPI_BF16 || a.M % 160 != 0) return -1;
@@ -418,7 +500,26 @@ int gemm16_pick(const GemmArgs& a, int weights_on_rows, int* wstat) {
         const double c2 = cost(224, 256, 1.0), c3 = cost(256, 256, 1.0), c8 = cost(128, 256, 1.2);
         return c2 <= c3 && c2 <= c8 ? 2 : (c3 <= c8 ? 3 : 8);
     }
+    // Class A (bit-identical with the 32x32x16 kernels of gemm.hip as well: same k order, measured bit for bit) on 320-column tiles
+    // moves the fewest L2 -> LDS bytes per flop (7.6 B/kFLOP against 10.7 for 224x160) and wins wherever ONE stream contributes
+    // enough 320-wide tiles to fill the chip at the step's batch sizes; the 1280-channel projections (5 x 4 tiles per stream) do not:
+    // they take the K-split class B on 160-column tiles.  The decision uses rows_per_stream, never the batch.
+    const bool wide320 = a.N % 320 == 0 && (long)cdiv(rps, 224) * (a.N / 320) >= 32;
+    if (wide320) {
+        static const int cand[4][3] = {{224, 320, 4}, {224, 256, 2}, {256, 256, 3}, {128, 256, 8}};   // all class A: free choice
+        int best = -1; double bc = 1e300;
+        for (auto& c : cand) {
+            if (a.N % c[1] != 0) continue;
+            const double cc = cost(c[0], c[1], c[0] == 128 ? 1.2 : 1.0);
+            if (cc < bc) { bc = cc; best = c[2]; }
+        }
+        return best;
+    }
     if (a.N % 160 == 0) return cost(224, 160, 1.0) <= cost(128, 160, 1.2) ? 0 : 1;     // class B
     return -1;
 }
 
+
+#ifdef RT_G16_TIMING
+void gemm16_read_times(long long* dst, int n) { HIP_CHECK(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_g16_times), (size_t)n * 8)); }
+#endif

@@ -8,13 +8,21 @@ from .unet import HipUNet2DConditionModel
 
 
 class RegionDiffusion:
-    def __init__(self, device=0, unet_state_dict=None, config=None, vae=None, tokenizer=None, text_encoder=None):
-        """The reference downloads runwayml/stable-diffusion-v1-5 (rd.py:26-33); offline the caller passes the
-        UNet `state_dict` (reference key names) and, optionally, VAE / CLIP objects with the diffusers /
-        transformers call surface (`.decode(z).sample`, tokenizer(...), text_encoder(ids)[0])."""
+    def __init__(self, device=0, unet_state_dict=None, config=None, vae=None, tokenizer=None, text_encoder=None, load_path=None,
+                 latent_hw=None):
+        """`RegionDiffusion(device)` as sample.py:26-27 calls it: the reference loads runwayml/stable-diffusion-v1-5 there
+        (rd.py:26-33); here the same id is resolved to a local diffusers-layout directory (checkpoint.resolve_checkpoint:
+        `load_path` directory / $RTDIFF_SD_PATH / the Hugging Face hub cache) and UNet, VAE decoder, tokenizer and text encoder are
+        loaded from it.  Callers that hold the weights already pass `unet_state_dict` (reference key names) and, optionally, VAE /
+        CLIP objects with the diffusers / transformers call surface (`.decode(z).sample`, tokenizer(...), text_encoder(ids)[0])."""
         self.device_index = device if isinstance(device, int) else (torch.device(device).index or 0)
         self.device = torch.device(f"cuda:{self.device_index}")
         self.num_train_timesteps = 1000
+        if unet_state_dict is None:
+            from .checkpoint import load_components, resolve_checkpoint
+            comp = load_components(resolve_checkpoint(load_path, "SD"), "SD", self.device_index, latent_hw)
+            unet_state_dict, config = comp["unet_state_dict"], config or comp["config"]
+            vae, tokenizer, text_encoder = vae or comp["vae"], tokenizer or comp["tokenizer"], text_encoder or comp["text_encoder"]
         self.vae, self.tokenizer, self.text_encoder = vae, tokenizer, text_encoder
         self.unet = HipUNet2DConditionModel(config or SD15_CONFIG, unet_state_dict, self.device_index)
         self.scheduler = PNDMTables(self.num_train_timesteps)          # rd.py:35-36

@@ -17,10 +17,20 @@ class StableDiffusionXLPipelineOutput(dict):
 
 class RegionDiffusionXL:
     def __init__(self, load_path=None, device=0, unet_state_dict=None, config=None, vae=None, text_encoders=None,
-                 vae_scaling_factor=0.13025, tokenizer=None):
+                 vae_scaling_factor=0.13025, tokenizer=None, latent_hw=None):
+        """`RegionDiffusionXL(load_path="stabilityai/stable-diffusion-xl-base-1.0")` as sample.py:28-30 calls it (xl.py:105-120
+        loads every component from `load_path`): a diffusers-layout directory, or a hub id resolved to one without a network
+        (checkpoint.resolve_checkpoint: $RTDIFF_SDXL_PATH for the default id, then the Hugging Face hub cache).  Callers that hold
+        the weights pass `unet_state_dict` (+ optional vae / text_encoders / tokenizer) and `load_path` is not read."""
         self.device_index = device if isinstance(device, int) else (torch.device(device).index or 0)
         self.device = torch.device(f"cuda:{self.device_index}")
         self.device_type = "cuda"
+        if unet_state_dict is None:
+            from .checkpoint import load_components, resolve_checkpoint
+            comp = load_components(resolve_checkpoint(load_path, "SDXL"), "SDXL", self.device_index, latent_hw)
+            unet_state_dict, config = comp["unet_state_dict"], config or comp["config"]
+            vae, text_encoders, tokenizer = vae or comp["vae"], text_encoders or comp["text_encoders"], tokenizer or comp["tokenizer"]
+            vae_scaling_factor = comp["vae_scaling_factor"]
         self.unet = HipUNet2DConditionModel(config or SDXL_CONFIG, unet_state_dict, self.device_index)
         self.vae = vae
         self.text_encoders = text_encoders

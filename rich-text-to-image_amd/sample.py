@@ -87,7 +87,7 @@ def generate(model, param, model_type='SD', run_dir=None, color_guidance_weight=
 
 
 def main(argv=None):
-    """Flags of sample.py:118-133.  Checkpoints are read from --load_path (a diffusers-layout directory with safetensors)."""
+    """Flags of sample.py:118-133 (+ --load_path).  The model is constructed exactly as sample.py:24-32 does."""
     p = argparse.ArgumentParser()
     p.add_argument('--run_dir', type=str, default='results/')
     p.add_argument('--height', type=int, default=None)
@@ -103,13 +103,23 @@ def main(argv=None):
     p.add_argument('--segment_threshold', type=float, default=0.3)
     p.add_argument('--num_segments', type=int, default=9)
     p.add_argument('--inject_background', type=float, default=0.)
-    p.add_argument('--load_path', type=str, required=True)
+    p.add_argument('--load_path', type=str, default=None,
+                   help='diffusers-layout checkpoint directory; default: the hub ids of sample.py:26-30 resolved locally '
+                        '(checkpoint.resolve_checkpoint: $RTDIFF_SD_PATH / $RTDIFF_SDXL_PATH / the Hugging Face hub cache)')
     a = p.parse_args(argv)
-    from .checkpoint import load_pipeline
+    from .region_diffusion import RegionDiffusion
+    from .region_diffusion_sdxl import RegionDiffusionXL
     res = 512 if a.model == 'SD' else 1024
     # the VAE plan (decode + colour guidance workspace) is sized for the requested image, like the UNet engine
-    model = load_pipeline(a.load_path, 'SD' if a.model == 'SD' else 'SDXL',
-                          latent_hw=((a.height or res) // 8, (a.width or res) // 8))
+    hw = ((a.height or res) // 8, (a.width or res) // 8)
+    # sample.py:24-32
+    if a.model == 'SD':
+        device = torch.device('cuda')
+        model = RegionDiffusion(device, load_path=a.load_path, latent_hw=hw)
+    elif a.model == 'SDXL':
+        model = RegionDiffusionXL(load_path=a.load_path or "stabilityai/stable-diffusion-xl-base-1.0", latent_hw=hw)
+    else:
+        model = RegionDiffusionXL(load_path=a.load_path or "Linaqruf/animagine-xl", latent_hw=hw)
     param = {'text_input': json.loads(a.rich_text_json), 'height': a.height or res, 'width': a.width or res,
              'guidance_weight': a.guidance_weight, 'steps': a.sample_steps, 'noise_index': a.seed, 'negative_prompt': a.negative_prompt}
     plain, rich, t = generate(model, param, 'SD' if a.model == 'SD' else 'SDXL', a.run_dir, a.color_guidance_weight, a.inject_selfattn,

@@ -77,14 +77,12 @@ def test_load_pipeline_and_generate_from_disk(tmp_path):
     assert np.isfinite(rich.astype(np.float32)).all() and (rich != plain).any()
 
 
-def test_load_sdxl_pipeline_from_disk(tmp_path):
-    """SDXL layout: two tokenizers / text encoders (the second with projection), text_time conditioning, prompts as strings."""
+def _write_xl_dir(root):
+    """Synthetic SDXL-layout checkpoint: two tokenizers / text encoders (the second with projection), text_time conditioning."""
     from safetensors.torch import save_file
     from transformers import CLIPTextConfig, CLIPTextModel, CLIPTextModelWithProjection
     from oracle.unet import TINY_XL_CONFIG
     from rich_text_to_image_amd import clip_tokenizer as ct
-    from rich_text_to_image_amd.checkpoint import load_pipeline
-    root = str(tmp_path)
     for sub in ("unet", "vae", "tokenizer", "tokenizer_2", "text_encoder", "text_encoder_2"):
         os.makedirs(os.path.join(root, sub))
     lst = lambda d: {k: (list(v) if isinstance(v, tuple) else v) for k, v in d.items()}
@@ -110,6 +108,14 @@ def test_load_sdxl_pipeline_from_disk(tmp_path):
         json.dump(cfg.to_dict(), open(os.path.join(root, sub, "config.json"), "w"))
         save_file({("text_model." + k if not (k.startswith("text_model.") or k.startswith("text_projection")) else k): v.contiguous()
                    for k, v in enc.state_dict().items()}, os.path.join(root, sub, "model.safetensors"))
+    return e1, e2
+
+
+def test_load_sdxl_pipeline_from_disk(tmp_path):
+    """SDXL layout: two tokenizers / text encoders (the second with projection), text_time conditioning, prompts as strings."""
+    from rich_text_to_image_amd.checkpoint import load_pipeline
+    root = str(tmp_path)
+    e1, e2 = _write_xl_dir(root)
     m = load_pipeline(root, "SDXL", device=0, latent_hw=(128, 128))
     pe, ne, pp, npool = m.encode_prompt(["a night sky", "a red barn"], None)
     ids = m.tokenizer(["a night sky"], padding="max_length", max_length=77, truncation=True, return_tensors="pt").input_ids
@@ -175,3 +181,43 @@ def test_lora_checkpoint_merged_at_load_matches_oracle_on_merged_weights(tmp_pat
     print(f"LoRA-merged engine vs oracle on merged weights: rel-L2 {rel(got, ref):.3e}; adapter effect {rel(base, ref):.3e}")
     assert rel(base, ref) > 5 * 1.5e-2            # the adapter changes the model by much more than the tolerance ...
     assert rel(got, ref) < 1.5e-2                 # ... and the engine follows it
+
+
+def test_constructors_load_like_the_reference_sample_py(tmp_path, monkeypatch):
+    """sample.py:24-32 verbatim: `RegionDiffusion(device)` and `RegionDiffusionXL(load_path="stabilityai/stable-diffusion-xl-base-1.0")`
+    return LOADED pipelines (rd.py:16-47, xl.py:105-120).  Offline the hub ids resolve to local directories: $RTDIFF_SD_PATH for the
+    SD default, the Hugging Face hub cache layout for the SDXL id.  Then the reference's command line runs without --load_path."""
+    from rich_text_to_image_amd import sample
+    from rich_text_to_image_amd.region_diffusion import RegionDiffusion
+    from rich_text_to_image_amd.region_diffusion_sdxl import RegionDiffusionXL
+    _write_dir(str(tmp_path / "sd"))
+    monkeypatch.setenv("RTDIFF_SD_PATH", str(tmp_path / "sd"))
+    device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
+    model = RegionDiffusion(device)                                                    # sample.py:26-27
+    assert model.vae is not None and model.tokenizer is not None and model.text_encoder is not None
+    emb = model.get_text_embeds(["a night sky above a barn"], [""])
+    assert emb.shape == (2, 77, TINY_SD_CONFIG["cross_attention_dim"])
+    del model
+    js = json.dumps({"ops": [{"insert": "a "}, {"attributes": {"link": "a wooden fence covered in snow"}, "insert": "fence"},
+                             {"insert": " under a night sky\n"}]})
+    plain, rich = sample.main(["--model", "SD", "--rich_text_json", js, "--sample_steps", "12", "--seed", "3", "--num_segments", "4",
+                               "--run_dir", str(tmp_path / "out"), "--inject_selfattn", "0.2"])
+    assert plain.shape == rich.shape == (1, 512, 512, 3) and np.isfinite(rich.astype(np.float32)).all()
+    # same weights through the explicit directory: identical images (the constructor path IS the loader path)
+    plain2, rich2 = sample.main(["--load_path", str(tmp_path / "sd"), "--model", "SD", "--rich_text_json", js, "--sample_steps", "12",
+                                 "--seed", "3", "--num_segments", "4", "--run_dir", str(tmp_path / "out2"), "--inject_selfattn", "0.2"])
+    assert np.array_equal(rich, rich2) and np.array_equal(plain, plain2)
+    # SDXL: hub id -> hub cache layout
+    snap = tmp_path / "hf" / "hub" / "models--stabilityai--stable-diffusion-xl-base-1.0" / "snapshots" / "0123abcd"
+    os.makedirs(snap)
+    _write_xl_dir(str(snap))
+    monkeypatch.setenv("HF_HOME", str(tmp_path / "hf"))
+    monkeypatch.delenv("HUGGINGFACE_HUB_CACHE", raising=False)
+    xl = RegionDiffusionXL(load_path="stabilityai/stable-diffusion-xl-base-1.0")         # sample.py:28-29
+    assert xl.vae is not None and xl.text_encoders is not None and abs(xl.vae_scaling_factor - TINY_VAE_CONFIG["scaling_factor"]) < 1e-9
+    xl.masks = [torch.full((1, 4, 128, 128), 0.5), torch.full((1, 4, 128, 128), 0.5)]
+    img = xl.sample(["a night sky", "a red barn"], negative_prompt=[""], height=1024, width=1024, num_inference_steps=2, guidance_scale=5.0,
+                    run_rich_text=True, latents=torch.randn(1, 4, 128, 128, generator=torch.Generator().manual_seed(0)), output_type="np").images
+    assert img.shape == (1, 1024, 1024, 3)
+    with pytest.raises(FileNotFoundError, match="RTDIFF_SDXL_PATH"):                     # nothing to load: say what was tried, never random weights
+        RegionDiffusionXL(load_path="Linaqruf/animagine-xl")

@@ -229,3 +229,38 @@ def test_full_width_vae_decode_and_guidance_gradient_match_oracle():
     assert abs(loss - loss_ref) < 2e-2 * abs(loss_ref)
     assert rg < 5e-2 and ru < 5e-2
     v.close()
+
+
+def test_sdxl_vae_config5_size_decode_and_guidance_match_oracle():
+    """BASELINE config 5 at its own size: the SDXL VAE (scaling 0.13025, 128-256-512-512) on a 128x128 latent = 1024x1024 image:
+    decode, colour-guidance gradient and latent update (region_diffusion_sdxl.py:849-867; the reference decodes in fp32, :856)
+    against torch autograd through the fp32 oracle decoder on the host (~2 min of CPU work, ~25 GB of autograd state)."""
+    from oracle.vae import SDXL_VAE_CONFIG, OracleVAEDecoder, color_guidance_update, random_vae_state_dict
+    from rich_text_to_image_amd.engine import VaeDecoder
+    hw = 128
+    sd = random_vae_state_dict(SDXL_VAE_CONFIG, seed=7)
+    v = VaeDecoder(SDXL_VAE_CONFIG, hw, hw, device=0, state_dict=sd)
+    o = OracleVAEDecoder(SDXL_VAE_CONFIG, sd)
+    g = torch.Generator().manual_seed(3)
+    lat, eps = torch.randn(1, 4, hw, hw, generator=g), torch.randn(1, 4, hw, hw, generator=g)
+    # 10 colour spans + the remainder mask, as sample.py hands them over for a 10-segment prompt (n_color + 1 masks, n_color targets)
+    masks = [(torch.rand(1, 1, 8 * hw, 8 * hw, generator=g) ** 2).repeat(1, 4, 1, 1) for _ in range(3)]
+    rgb = [torch.rand(1, 3, 1, 1, generator=g) for _ in range(2)]
+    mall = torch.rand(1, 4, hw, hw, generator=g)
+    alpha, sc, wgt = 0.37, SDXL_VAE_CONFIG["scaling_factor"], 0.5
+    assert abs(sc - 0.13025) < 1e-9
+    torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
+    new_ref, grad_ref, loss_ref = color_guidance_update(o, lat, eps, alpha, sc, masks, rgb, wgt, mall)
+    with torch.no_grad():
+        x0 = (lat - eps * (1 - alpha) ** 0.5) / alpha ** 0.5
+        ref = o.decode(x0 / sc)
+    out = v.decode((x0 / sc).to(DEV))
+    r = rel_l2(out, ref)
+    lat_g = lat.clone().to(DEV)
+    loss, grad = v.color_guidance(lat_g, eps.to(DEV), alpha, hw, hw, masks, rgb, wgt, mall, want_grad=True)
+    rg, ru = rel_l2(grad, grad_ref), rel_l2(lat_g.cpu() - lat, new_ref - lat)
+    print(f"SDXL VAE 128x128 -> 1024x1024: decode rel-L2 {r:.3e}; loss {loss:.4f} vs {loss_ref:.4f}; grad rel-L2 {rg:.3e}; update rel-L2 {ru:.3e}")
+    assert r < 2e-2
+    assert abs(loss - loss_ref) < 2e-2 * abs(loss_ref)
+    assert rg < 5e-2 and ru < 5e-2
+    v.close()

@@ -7,6 +7,9 @@ static const struct { int BM, BN; } kVar[RT_G16_NVAR] = {{224, 160}, {128, 160},
 #include <vector>
 #include <cstring>
 #include <cmath>
+#ifdef RT_G16_TIMING
+void gemm16_read_times(long long* dst, int n);
+#endif
 
 __global__ void diff_kernel(const void* a, const void* b, size_t n, int kind /*0 bf16, 1 f32, 2 f16*/, float* out /* [maxdiff, maxref] as uint bits */) {
     float md = 0.f, mr = 0.f;
@@ -23,7 +26,7 @@ __global__ void diff_kernel(const void* a, const void* b, size_t n, int kind /*0
     atomicMax((unsigned*)out + 1, __float_as_uint(mr));
 }
 
-struct Case { const char* name; int M, N, K, epi, res, vt; int old_cfgs[3]; int new_vars[4]; int wstat_both; };
+struct Case { const char* name; int M, N, K, epi, res, vt; int old_cfgs[3]; int new_vars[6]; int wstat_both; };
 
 int main(int argc, char** argv) {
     const size_t A_ELEMS = (size_t)28672 * 5120, W_ELEMS = (size_t)28672 * 5120, O_BYTES = (size_t)28672 * 5120 * 4;
@@ -48,23 +51,23 @@ int main(int argc, char** argv) {
 
     // name, M, N, K, epi, residual, weights_on_rows, {old configs}, {new variants}, try wstat 0 and 1
     const Case cases[] = {
-        {"attn.to_out / to_q 1280 (f16 trunk + res)", 7168, 1280, 1280, EPI_F16, 1, 0, {2, 0, -1}, {0, 1, -1, -1}, 0},
-        {"attn2.to_q 1280 (bf16)", 7168, 1280, 1280, EPI_BF16, 0, 0, {2, 0, -1}, {0, 1, -1, -1}, 0},
-        {"ff.net.2 1280 (K = 5120, f16 + res)", 7168, 1280, 5120, EPI_F16, 1, 0, {2, 6, -1}, {0, -1, -1, -1}, 0},
-        {"attn1 Q|K 1280 (N = 2560)", 7168, 2560, 1280, EPI_BF16, 0, 0, {2, 3, -1}, {0, 2, 3, -1}, 0},
-        {"attn1 Q|K 1280, 4 streams", 4096, 2560, 1280, EPI_BF16, 0, 0, {2, 3, -1}, {0, 1, 3, -1}, 0},
-        {"GEGLU 1280", 7168, 10240, 1280, EPI_GEGLU, 0, 0, {3, 7, -1}, {2, 3, -1, -1}, 1},
-        {"GEGLU 640", 28672, 5120, 640, EPI_GEGLU, 0, 0, {3, 7, -1}, {2, 3, -1, -1}, 1},
-        {"to_out / to_q 640 (f16 + res)", 28672, 640, 640, EPI_F16, 1, 0, {8, 2, -1}, {0, 4, 1, -1}, 0},
-        {"to_q 640 (bf16)", 28672, 640, 640, EPI_BF16, 0, 0, {8, 2, -1}, {0, 4, -1, -1}, 0},
-        {"ff.net.2 640 (K = 2560)", 28672, 640, 2560, EPI_F16, 1, 0, {8, 2, -1}, {0, 4, -1, -1}, 0},
-        {"attn1 Q|K 640 (N = 1280)", 28672, 1280, 640, EPI_BF16, 0, 0, {2, 8, 3}, {0, 4, 2, -1}, 0},
-        {"V^T 1280", 1280, 7168, 1280, EPI_BF16, 0, 1, {2, 0, -1}, {6, 7, -1, -1}, 0},
-        {"V^T 640", 640, 28672, 640, EPI_BF16, 0, 1, {2, 0, -1}, {6, 7, -1, -1}, 0},
-        {"ragged rows (M = 5000), f32 + res", 5000, 1280, 1280, EPI_F32, 1, 0, {2, -1, -1}, {0, 1, -1, -1}, 0},
-        {"5 streams 1280", 5120, 1280, 1280, EPI_F16, 1, 0, {2, 0, -1}, {0, 1, -1, -1}, 0},
-        {"4096^3 bf16", 4096, 4096, 4096, EPI_BF16, 0, 0, {3, 7, -1}, {3, 2, 5, -1}, 1},
-        {"8192x4096x4096 bf16", 8192, 4096, 4096, EPI_BF16, 0, 0, {3, 7, -1}, {3, 5, -1, -1}, 0},
+        {"attn.to_out / to_q 1280 (f16 trunk + res)", 7168, 1280, 1280, EPI_F16, 1, 0, {2, -1, -1}, {0, -1, 1, -1, -1, -1}, 0},
+        {"attn2.to_q 1280 (bf16)", 7168, 1280, 1280, EPI_BF16, 0, 0, {2, -1, -1}, {0, -1, -1, -1, -1, -1}, 0},
+        {"ff.net.2 1280 (K = 5120, f16 + res)", 7168, 1280, 5120, EPI_F16, 1, 0, {2, -1, -1}, {0, -1, -1, -1, -1, -1}, 0},
+        {"attn1 Q|K 1280 (N = 2560)", 7168, 2560, 1280, EPI_BF16, 0, 0, {2, -1, -1}, {0, -1, 4, -1, 2, -1}, 0},
+        {"attn1 Q|K 1280, 4 streams", 4096, 2560, 1280, EPI_BF16, 0, 0, {2, -1, -1}, {4, 1, 3, -1, -1, -1}, 0},
+        {"GEGLU 1280", 7168, 10240, 1280, EPI_GEGLU, 0, 0, {3, -1, -1}, {2, -1, 3, -1, -1, -1}, 1},
+        {"GEGLU 640", 28672, 5120, 640, EPI_GEGLU, 0, 0, {3, -1, -1}, {2, -1, 3, -1, -1, -1}, 0},
+        {"to_out / to_q 640 (f16 + res)", 28672, 640, 640, EPI_F16, 1, 0, {8, -1, -1}, {0, 4, -1, -1, -1, -1}, 0},
+        {"to_q 640 (bf16)", 28672, 640, 640, EPI_BF16, 0, 0, {8, -1, -1}, {0, 4, -1, -1, -1, -1}, 0},
+        {"ff.net.2 640 (K = 2560)", 28672, 640, 2560, EPI_F16, 1, 0, {8, -1, -1}, {0, 4, -1, -1, -1, -1}, 0},
+        {"attn1 Q|K 640 (N = 1280)", 28672, 1280, 640, EPI_BF16, 0, 0, {8, -1, -1}, {0, 4, 2, -1, -1, -1}, 0},
+        {"V^T 1280", 1280, 7168, 1280, EPI_BF16, 0, 1, {2, -1, -1}, {6, 7, -1, -1, -1, -1}, 0},
+        {"V^T 640", 640, 28672, 640, EPI_BF16, 0, 1, {0, -1, -1}, {6, 7, -1, 4, -1, -1}, 0},
+        {"ragged rows (M = 5000), f32 + res", 5000, 1280, 1280, EPI_F32, 1, 0, {2, -1, -1}, {0, 1, -1, -1, -1, -1}, 0},
+        {"5 streams 1280", 5120, 1280, 1280, EPI_F16, 1, 0, {2, 0, -1}, {0, 1, -1, -1, -1, -1}, 0},
+        {"4096^3 bf16", 4096, 4096, 4096, EPI_BF16, 0, 0, {3, 7, -1}, {3, -1, -1, -1, -1, -1}, 0},
+        {"8192x4096x4096 bf16", 8192, 4096, 4096, EPI_BF16, 0, 0, {7, -1, -1}, {3, -1, -1, -1, -1, -1}, 0},
     };
     for (const Case& c : cases) {
         if (quick && c.M * (long)c.N > 40000000L) continue;
@@ -82,7 +85,7 @@ int main(int argc, char** argv) {
         launch_with_cfg(g, c.old_cfgs[0], 0);
         struct V { int is_new, id, wstat; float best, sum; int n; } vs[16]; int nv = 0;
         for (int i = 0; i < 3; ++i) if (c.old_cfgs[i] >= 0) vs[nv++] = V{0, c.old_cfgs[i], 0, 1e30f, 0.f, 0};
-        for (int i = 0; i < 4; ++i) if (c.new_vars[i] >= 0) {
+        for (int i = 0; i < 6; ++i) if (c.new_vars[i] >= 0) {
             vs[nv++] = V{1, c.new_vars[i], 0, 1e30f, 0.f, 0};
             if (c.wstat_both) vs[nv++] = V{1, c.new_vars[i], 1, 1e30f, 0.f, 0};
         }
@@ -112,6 +115,21 @@ int main(int argc, char** argv) {
                 float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
                 vs[i].best = std::min(vs[i].best, ms); vs[i].sum += ms; vs[i].n++;
             }
+#ifdef RT_G16_TIMING
+        for (int i = 0; i < nv; ++i) {
+            if (vs[i].id < 0 || !vs[i].is_new) continue;
+            run(vs[i], out1); hipDeviceSynchronize();
+            const int nwg = cdiv(c.M, kVar[vs[i].id].BM) * cdiv(c.N, kVar[vs[i].id].BN);
+            std::vector<long long> t((size_t)nwg * 8);
+            gemm16_read_times(t.data(), nwg * 8);
+            double seg[4] = {0, 0, 0, 0};
+            for (int w = 0; w < nwg; ++w) {
+                for (int k = 0; k < 4; ++k) seg[k] += (double)(t[w * 8 + k + 1] - t[w * 8 + k]);
+            }
+            printf("    timing v%d%s: prologue %6.0f | loop %7.0f | drain+exchange %6.0f | epilogue %6.0f cycles (mean over %d WGs)\n",
+                   vs[i].id, vs[i].wstat ? "w" : "", seg[0] / nwg, seg[1] / nwg, seg[2] / nwg, seg[3] / nwg, nwg);
+        }
+#endif
         for (int i = 0; i < nv; ++i) {
             if (vs[i].id < 0) continue;
             const double fl = 2.0 * c.M * c.N * c.K;
