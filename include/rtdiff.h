@@ -139,6 +139,15 @@ int rt_op_attention(const void* Q, int ldq, const void* K, int ldk, const void* 
                     const int* q_src_host, const int* k_src_host, const int* v_src_host, const int* wset_host,
                     const float* wabs, const float* wsgn, int B, int H, int N, int NK, int nk_valid, int DP, int cross,
                     void* stream);
+/* The SDXL cross-attention block the north star names, as one call (replaces attn2 of BasicTransformerBlock, models/attention.py:169-189,
+ * processor arithmetic models/attention_processor.py:476-545, font-size softmax :386-401):
+ *   trunk_out[B*N, C] (fp16) = trunk_in + to_out(softmax_fs(to_q(x) K[prompt]^T) V[prompt]) + bo
+ * x bf16 [B*N, C] (LayerNorm output); wq bf16 [H*DP, C] head-padded and pre-scaled by d^-1/2 log2 e; wo bf16 [C, H*DP]; bo fp32 [C] or NULL;
+ * kcache bf16 [P*96, H*DP], vtcache bf16 [H*DP, ldvt] (77 keys padded to 96 per prompt); prompt_host / wset_host: per batch entry the
+ * prompt index and the multiplier set (0 plain softmax, 1 font-size) in wabs / wsgn [2, 96]; q_scratch, o_scratch bf16 [B*N, H*DP]. */
+int rt_op_cross_attn_block(const void* x, const void* wq, const void* wo, const float* bo, const void* kcache, const void* vtcache, int ldvt,
+                           const int* prompt_host, const int* wset_host, const float* wabs, const float* wsgn, const void* trunk_in_f16,
+                           void* trunk_out_f16, void* q_scratch, void* o_scratch, int B, int N, int C, int H, int DP, void* stream);
 /* in_type: 0 fp32, 1 bf16 (x2 must be NULL), 2 fp16 - the element type of x1 / x2 (the UNet trunk is fp16) */
 int rt_op_groupnorm(const void* x1, const void* x2, int in_type, int C1, int C2, int G, int B, int HW,
                     const float* gamma, const float* beta, float eps, int silu, void* out_bf16, void* raw_out_bf16,
@@ -165,11 +174,12 @@ int rt_op_causal_attention(const void* q, const void* k, const void* v, int ld, 
 int rt_op_attention_probs_avg(const void* Q, int ldq, long long q_row0, const void* K, int ldk, long long k_row0, float* out,
                               int H, int N, int NK, int NKpad, int NKrows, int DP, int accumulate, void* stream);
 const char* rt_op_last_error(void);
-/* GEMM tile configuration: -1 = tuned per shape (default); 0..8 force one (tests / micro-benchmarks).
- * All configurations give bit-identical results, which is what lets the tuner rank them on the REAL launches: while a shape is
- * being tuned, successive launches of it cycle through the configurations between pairs of HIP events (csrc/gemm.hip). */
+/* GEMM tile choice: -1 (default) = a pure function of the problem shape (csrc/gemm16.hip: 16x16x32-MFMA family, 224-row tiles;
+ * csrc/gemm.hip: 32x32x16 family for everything else) - no timing, no per-process state; 0..8 = force one tile configuration of
+ * gemm.hip (tests / micro-benchmarks; all of them give bit-identical results). */
 int rt_op_gemm_force_config(int cfg);
-int rt_op_gemm_debug(int flags);   /* bit 0: send patch-eligible 3x3 convs through the implicit-GEMM kernels instead (A/B tests) */
+/* A/B switches: bit 0 patch-eligible 3x3 convs through the implicit-GEMM kernels; bit 1 keep gemm16.hip out; bit 2 no split-K */
+int rt_op_gemm_debug(int flags);
 
 /* ---- VAE decoder: colour guidance (rd.py:151-168, xl.py:849-867) and plain decode (rd.py:227-236) ----
  * AutoencoderKL.decoder + post_quant_conv (diffusers 0.18.2, third party: architecture restated in oracle/vae.py).

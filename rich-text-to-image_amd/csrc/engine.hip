@@ -1093,6 +1093,32 @@ int rt_op_attention(const void* Q, int ldq, const void* K, int ldk, const void* 
         launch_attention(a, (hipStream_t)stream);
     })
 }
+// The block BASELINE.json's north star names: attn2 of a BasicTransformerBlock (models/attention.py:169-189) with the reference
+// processor's arithmetic (models/attention_processor.py:476-545; font-size softmax :386-401) as ONE call:
+//   trunk_out = trunk_in + to_out( softmax_fs( to_q(x) K[prompt]^T ) V[prompt] ) + b_out
+// K / V^T come from the per-prompt cache (77 keys padded to 96; step invariant), Q and O live in caller-provided scratch.  Three
+// launches (to_q GEMM, 96-key attention, to_out GEMM + fp16 residual): why they are not one kernel is measured in DESIGN.md 4.7.
+int rt_op_cross_attn_block(const void* x, const void* wq, const void* wo, const float* bo, const void* kcache, const void* vtcache, int ldvt,
+                           const int* prompt_host, const int* wset_host, const float* wabs, const float* wsgn, const void* trunk_in,
+                           void* trunk_out, void* q_scratch, void* o_scratch, int B, int N, int C, int H, int DP, void* stream) {
+    OP_TRY({
+        RT_REQUIRE(B >= 1 && B <= RT_MAXB && N > 0 && C % 8 == 0 && H > 0 && DP % 32 == 0, "rt_op_cross_attn_block: shape");
+        hipStream_t st = (hipStream_t)stream;
+        const int M = B * N, HD = H * DP;
+        GemmArgs g{}; g.A = (const bf16_t*)x; g.W = (const bf16_t*)wq; g.out = q_scratch; g.zero = op_zero_page(); g.mode = A_DENSE; g.epi = EPI_BF16;
+        g.M = M; g.N = HD; g.K = C; g.lda = C; g.ldw = C; g.ldo = HD; g.rows_per_stream = N; g.split_tiles = cdiv(N, 128) * cdiv(HD, 128);
+        launch_gemm(g, st);
+        AttnArgs a{}; a.Q = (const bf16_t*)q_scratch; a.ldq = HD; a.K = (const bf16_t*)kcache; a.ldk = HD; a.VT = (const bf16_t*)vtcache; a.ldvt = ldvt;
+        a.O = (bf16_t*)o_scratch; a.ldo = HD; a.wabs = wabs; a.wsgn = wsgn;
+        for (int b = 0; b < B; ++b) { a.q_src[b] = b; a.k_src[b] = prompt_host ? prompt_host[b] : 0; a.v_src[b] = a.k_src[b]; a.wset[b] = wset_host ? wset_host[b] : 0; }
+        a.B = B; a.H = H; a.N = N; a.NK = 96; a.nk_valid = 77; a.DP = DP; a.cross = 1;
+        launch_attention(a, st);
+        GemmArgs o{}; o.A = (const bf16_t*)o_scratch; o.W = (const bf16_t*)wo; o.bias = bo; o.out = trunk_out; o.res = trunk_in; o.zero = op_zero_page();
+        o.mode = A_DENSE; o.epi = EPI_F16; o.M = M; o.N = C; o.K = HD; o.lda = HD; o.ldw = HD; o.ldo = C; o.ldres = C; o.rows_per_stream = N;
+        o.split_tiles = cdiv(N, 128) * cdiv(C, 128);
+        launch_gemm(o, st);
+    })
+}
 int rt_op_groupnorm(const void* x1, const void* x2, int in_bf16, int C1, int C2, int G, int B, int HW, const float* gamma,
                     const float* beta, float eps, int silu, void* out, void* raw, void* stream) {
     OP_TRY({

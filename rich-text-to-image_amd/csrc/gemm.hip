@@ -1212,12 +1212,15 @@ static int g_force_cfg = -1;
 static int g_conv_patch = 1;
 static int g_use16 = 1;
 static int g_splitk = 1;
+static int g_conv16 = 1;
 #ifdef RT_PROBE
 int g_conv3p_tn = 0;          // probe override of the patch kernel's column-tile count
 #endif
 // bit 0: route eligible convs through the implicit-GEMM kernels; bit 1: keep the 16x16x32 family (gemm16.hip) out (A/B tests)
-// bit 2: no split-K
-void gemm_set_debug(int flags) { g_conv_patch = (flags & 1) ? 0 : 1; g_use16 = (flags & 2) ? 0 : 1; g_splitk = (flags & 4) ? 0 : 1; }
+// bit 2: no split-K; bit 3: stride-1 3x3 convolutions stay on the patch kernel (conv3p_kernel) instead of gemm16.hip's implicit GEMM
+void gemm_set_debug(int flags) {
+    g_conv_patch = (flags & 1) ? 0 : 1; g_use16 = (flags & 2) ? 0 : 1; g_splitk = (flags & 4) ? 0 : 1; g_conv16 = (flags & 8) ? 0 : 1;
+}
 
 template <int EPI, bool UP2, int TN>
 static void launch_conv3p_tn(const GemmArgs& a, int ntm, hipStream_t st) {
@@ -1438,6 +1441,12 @@ void launch_gemm(const GemmArgs& a, hipStream_t st) {
     const int ksl = g_splitk ? splitk_slices(a) : 1;
     // patch convolutions that cannot fill the chip (< 128 workgroups) go through the split-K implicit GEMM as well
     const bool patch_underfilled = ksl > 1 && a.mode != A_DENSE;
+    if (a.mode == A_CONV3 && ksl == 1 && g_force_cfg < 0 && g_use16 && g_conv16 && g_conv_patch) {
+        // stride-1 3x3 convolutions with Cin % 64 == 0: implicit GEMM on the 16x16x32 family's main loop (gemm16.hip, MODE = A_CONV3)
+        int wstat = 0;
+        const int v = gemm16_pick(a, 0, &wstat);
+        if (v >= 0) { launch_gemm16_variant(a, v, 0, st); return; }
+    }
     if (conv_patch_eligible(a) && !patch_underfilled) {
         if (a.mode == A_CONV3_UP2) { if (a.epi == EPI_F16) launch_conv3p<EPI_F16, true>(a, st); else launch_conv3p<EPI_F32, true>(a, st); }
         else switch (a.epi) {

@@ -45,12 +45,18 @@ __device__ long long g_g16_times[8192 * 8];
 // LDS-DMA through a buffer descriptor: buffer_load_dwordx4 v(voff), s[rsrc], s(soff) offen lds.  `base` must be wave-uniform; the
 // descriptor is rebuilt from it at every call site (4 SALU moves, hoisted by the compiler).  Kept in a non-template __device__
 // function: the descriptor type exists in device compilation only and a kernel TEMPLATE that names it loses its host-side stub.
-__device__ __forceinline__ void glds16_buf(const void* base, int voff_bytes, int soff_bytes, void* lds_wave_base) {
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+__device__ __forceinline__ void glds16_buf(const void* base, int voff_bytes, int soff_bytes, void* lds_wave_base, unsigned range_bytes = 0x7fffffffu) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, range_bytes, 0x00020000);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff_bytes, soff_bytes, 0, 0);
 }
+#define RT_G16_OOB 0x7fff0000       // a voffset beyond every descriptor range used here: the lane's 16 bytes arrive as zeros
 
-template <int EPI, int TMW, int TNW, int WM, int WN, int WK, int S>
+// MODE = A_CONV3: 3x3 stride-1 pad-1 convolution as an implicit GEMM on the SAME main loop (M = pixels of the NHWC activation,
+// K tile t = (tap t / nch, 64-channel chunk t % nch), weights packed [Cout][tap][Cin] as everywhere else): only the A loader differs -
+// the lane's pixel address shifted by the tap, with the padding taps sent out of the descriptor's range so that they read as zeros.
+// It re-reads every input pixel nine times (from L2), which the patch kernel of gemm.hip avoids, but runs the 224-row / K-split
+// main loop whose LDS array is not the bottleneck: 32^2 x 1280 -> 1280 for 7 streams is a 7168 x 1280 x 11520 GEMM.
+template <int MODE, int EPI, int TMW, int TNW, int WM, int WN, int WK, int S>
 __global__ __launch_bounds__(WM * WN * WK * 64) void gemm16_kernel(GemmArgs p, int wstat) {
     constexpr int NW = WM * WN * WK;                       // 8 waves (two per SIMD) or 4 waves (one per SIMD, 512 registers each)
     static_assert(NW == 8 || NW == 4, "4 or 8 waves");
@@ -94,9 +100,10 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void gemm16_kernel(GemmArgs p, i
     // (buffer_load_dwordx4 ... offen lds, guide T8): per piece ONE 32-bit VGPR byte offset, the K-tile offset is a scalar (soffset)
     // and the operand base sits in an SGPR descriptor - the flat form kept a 64-bit address per piece alive and spilled in the loop.
     const int lrow = lane >> 3, pslot = lane & 7;
-    int voff[PW];                       // byte offset of this lane's 16-B chunk at k0 = 0
+    int voff[PW];                       // byte offset of this lane's 16-B chunk at k0 = 0 (conv: of its pixel's channel vector)
     int ldst[PW];                       // LDS byte offset of the group inside a ring slot (wave-uniform)
     bool pisA[PW];                      // wave-uniform
+    int tapmask[MODE == A_CONV3 ? PW : 1];   // conv, A pieces: bit t set <=> tap t of this lane's pixel lies inside the image
 #pragma unroll
     for (int i = 0; i < PW; ++i) {
         int g = i * NW + wave; if (g > GT - 1) g = GT - 1;          // tail duplicates copy the same bytes to the same place
@@ -106,13 +113,40 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void gemm16_kernel(GemmArgs p, i
         const int lim = isA ? p.M : p.N;
         if (row >= lim) row = lim - 1;
         const int key = ((gl << 2) | (lrow >> 1)) & 7;              // (tile row >> 1) & 7
-        voff[i] = (row * (isA ? p.lda : p.ldw) + ((pslot ^ key) << 3)) * 2;
+        if (MODE == A_CONV3 && isA) {
+            const int b = row / p.rows_per_batch, pix = row - b * p.rows_per_batch;
+            const int y = pix / p.Win, x = pix - y * p.Win;
+            voff[i] = (row * p.Cin + ((pslot ^ key) << 3)) * 2;     // NHWC, stride 1: output pixel index == input pixel index
+            int m = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                if (yy >= 0 && yy < p.Hin && xx >= 0 && xx < p.Win) m |= 1 << t;
+            }
+            tapmask[MODE == A_CONV3 ? i : 0] = m;
+        } else {
+            voff[i] = (row * (isA ? p.lda : p.ldw) + ((pslot ^ key) << 3)) * 2;
+            if (MODE == A_CONV3) tapmask[MODE == A_CONV3 ? i : 0] = 0;
+        }
         pisA[i] = isA;
         ldst[i] = (isA ? 0 : BM * 128) + gl * 1024;
     }
-    const int nk = p.K / BK16;                                       // host guarantees K % 128 == 0, K >= 256 (nk >= S + 1)
+    const int nk = p.K / BK16;                                       // host guarantees K % 128 == 0 / conv: 9 * Cin / 64, nk >= S + 1
+    // conv: (tap, chunk) of the NEXT K tile to be issued, carried as scalars (tiles are issued strictly in order)
+    const int nch = MODE == A_CONV3 ? p.Cin / BK16 : 1;
+    const unsigned a_range = MODE == A_CONV3 ? (unsigned)p.M * (unsigned)p.Cin * 2u : 0x7fffffffu;
+    int is_tap = 0, is_chunk = 0, is_ky = 0, is_kx = 0;
     auto stage_piece = [&](int t, int slot_off, int i) {             // piece i of K tile t -> ring slot at slot_off
-        glds16_buf(pisA[i] ? (const void*)p.A : (const void*)p.W, voff[i], t * (BK16 * 2), smem + slot_off + ldst[i]);
+        if (MODE == A_CONV3 && pisA[i]) {
+            const int shift = ((is_ky - 1) * p.Win + (is_kx - 1)) * p.Cin * 2;          // scalar
+            const int vo = ((tapmask[MODE == A_CONV3 ? i : 0] >> is_tap) & 1) ? voff[i] + shift : RT_G16_OOB;
+            glds16_buf(p.A, vo, is_chunk * (BK16 * 2), smem + slot_off + ldst[i], a_range);
+        } else {
+            glds16_buf(pisA[i] ? (const void*)p.A : (const void*)p.W, voff[i], t * (BK16 * 2), smem + slot_off + ldst[i]);
+        }
+    };
+    auto tile_issued = [&]() {                                       // every piece of a K tile went out: advance (tap, chunk)
+        if (MODE == A_CONV3) { if (++is_chunk == nch) { is_chunk = 0; ++is_tap; if (++is_kx == 3) { is_kx = 0; ++is_ky; } } }
     };
 
     // ---- fragments: lane (l15, q): row l15 of a 16-row tile, 16-B chunk c = 4*khalf + q of the 128-B row
@@ -133,9 +167,11 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void gemm16_kernel(GemmArgs p, i
 
     // ---- prologue: all S slots in flight; tile 0 landed; fragments of k step 0 in registers
 #pragma unroll
-    for (int s = 0; s < S; ++s)
+    for (int s = 0; s < S; ++s) {
 #pragma unroll
         for (int i = 0; i < PW; ++i) stage_piece(s, s * STAGE, i);
+        tile_issued();
+    }
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 1) * PW) : "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -201,6 +237,7 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void gemm16_kernel(GemmArgs p, i
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (NEXT == 2 && REFILL) tile_issued();
     };
     using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>; using C2 = std::integral_constant<int, 2>;
     using CS2 = std::integral_constant<int, S - 2>;
@@ -240,6 +277,7 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void gemm16_kernel(GemmArgs p, i
     constexpr int H0 = WK == 2 ? (TMW + 1) / 2 : TMW;
     auto owned = [&](int i) { return WK == 1 || ((i < H0) == (kh == 0)); };           // wave-uniform
     constexpr bool F16 = EPI == EPI_F16;
+    constexpr bool TEMB = EPI == EPI_BF16_TEMB;                      // bf16 out + the per-image time-embedding row (resnet.py:611-613)
     constexpr bool F32 = EPI == EPI_F32 || F16;                      // fp32 slab; F16: fp16 in HBM (output and residual), rounded once
     constexpr int ES = F32 ? 4 : 2;
     constexpr int TNO = EPI == EPI_GEGLU ? TNW / 2 : TNW;            // 16-column output tiles per wave
@@ -346,6 +384,14 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void gemm16_kernel(GemmArgs p, i
                     v[e] = (acc[i][tv][e] + bias_v[t][e]) * gelu_erf(acc[i][tv + 2][e] + bias_g[t][e]);
                 } else v[e] = acc[i][t][e] + bias_v[t][e];
             }
+            if constexpr (TEMB) {
+                int row = m0 + (wm * TMW + i) * 16 + l15; if (row >= p.M) row = p.M - 1;
+                const int col = wcol0 + t * 16 + 4 * q4;
+                if (col < p.N) {
+                    const float4 tv = *(const float4*)(p.temb + (size_t)(row / p.rows_per_batch) * p.temb_ld + col);
+                    v[0] += tv.x; v[1] += tv.y; v[2] += tv.z; v[3] += tv.w;
+                }
+            }
             char* dst = slab + l15 * RS + (t * 16 + 4 * q4) * ES;
             if constexpr (F32) *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
             else { uint2 w; w.x = pack_bf16x2(v[0], v[1]); w.y = pack_bf16x2(v[2], v[3]); *(uint2*)dst = w; }
@@ -417,44 +463,58 @@ static const G16Var kVar[RT_G16_NVAR] = {
     //  compiler-scheduled wave does not keep the matrix pipe fed.  The kernel template still takes WM*WN*WK == 4.)
 };
 
-template <int EPI, int TMW, int TNW, int WM, int WN, int WK, int S>
+template <int MODE, int EPI, int TMW, int TNW, int WM, int WN, int WK, int S>
 static void launch_v(const GemmArgs& a, int wstat, hipStream_t st) {
     constexpr int BM = WM * TMW * 16, BN = WN * TNW * 16;
     constexpr int LDS = S * (BM + BN) * 128;
     static bool attr = false;
     if (!attr) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)gemm16_kernel<EPI, TMW, TNW, WM, WN, WK, S>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        HIP_CHECK(hipFuncSetAttribute((const void*)gemm16_kernel<MODE, EPI, TMW, TNW, WM, WN, WK, S>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr = true;
     }
     const int ntn = cdiv(a.N, BN), ntm = cdiv(a.M, BM);
     if (wstat && (ntn % 8 != 0)) wstat = 0;
-    hipLaunchKernelGGL((gemm16_kernel<EPI, TMW, TNW, WM, WN, WK, S>), dim3(ntm * ntn), dim3(WM * WN * WK * 64), LDS, st, a, wstat);
+    hipLaunchKernelGGL((gemm16_kernel<MODE, EPI, TMW, TNW, WM, WN, WK, S>), dim3(ntm * ntn), dim3(WM * WN * WK * 64), LDS, st, a, wstat);
     HIP_CHECK(hipGetLastError());
 }
 
-template <int EPI>
+template <int MODE, int EPI>
 static void launch_e(const GemmArgs& a, int v, int wstat, hipStream_t st) {
     switch (v) {
-        case 2: launch_v<EPI, 7, 4, 2, 4, 1, 2>(a, wstat, st); return;
-        case 3: launch_v<EPI, 8, 4, 2, 4, 1, 2>(a, wstat, st); return;
-        case 8: launch_v<EPI, 4, 4, 2, 4, 1, 3>(a, wstat, st); return;
+        case 2: launch_v<MODE, EPI, 7, 4, 2, 4, 1, 2>(a, wstat, st); return;
+        case 3: if constexpr (MODE == A_DENSE) { launch_v<MODE, EPI, 8, 4, 2, 4, 1, 2>(a, wstat, st); return; } break;
+        case 8: if constexpr (MODE == A_DENSE) { launch_v<MODE, EPI, 4, 4, 2, 4, 1, 3>(a, wstat, st); return; } break;
         default: break;
     }
     if constexpr (EPI != EPI_GEGLU) {
         switch (v) {
-            case 0: launch_v<EPI, 7, 5, 2, 2, 2, 3>(a, wstat, st); return;
-            case 1: launch_v<EPI, 4, 5, 2, 2, 2, 3>(a, wstat, st); return;
-            case 4: launch_v<EPI, 7, 5, 2, 4, 1, 2>(a, wstat, st); return;
-            case 5: launch_v<EPI, 8, 5, 2, 4, 1, 2>(a, wstat, st); return;
-            case 6: launch_v<EPI, 5, 7, 2, 2, 2, 3>(a, wstat, st); return;
-            case 7: launch_v<EPI, 5, 4, 2, 2, 2, 3>(a, wstat, st); return;
+            case 0: launch_v<MODE, EPI, 7, 5, 2, 2, 2, 3>(a, wstat, st); return;
+            case 4: launch_v<MODE, EPI, 7, 5, 2, 4, 1, 2>(a, wstat, st); return;
             default: break;
         }
+        if constexpr (MODE == A_DENSE) {
+            switch (v) {
+                case 1: launch_v<MODE, EPI, 4, 5, 2, 2, 2, 3>(a, wstat, st); return;
+                case 5: launch_v<MODE, EPI, 8, 5, 2, 4, 1, 2>(a, wstat, st); return;
+                case 6: launch_v<MODE, EPI, 5, 7, 2, 2, 2, 3>(a, wstat, st); return;
+                case 7: launch_v<MODE, EPI, 5, 4, 2, 2, 2, 3>(a, wstat, st); return;
+                default: break;
+            }
+        }
     }
-    throw rt_error(RT_E_INVALID, "gemm16: variant cannot run this epilogue");
+    throw rt_error(RT_E_INVALID, "gemm16: variant cannot run this operand mode / epilogue");
 }
 
+static bool conv16_geometry(const GemmArgs& a) {
+    return a.mode == A_CONV3 && a.Hin == a.Hout && a.Win == a.Wout && a.Cin % BK16 == 0 && a.K == 9 * a.Cin && a.rows_per_batch == a.Hout * a.Wout &&
+           a.M % a.rows_per_batch == 0 && (long)a.M * a.Cin * 2 < (long)RT_G16_OOB;
+}
 bool gemm16_supported(const GemmArgs& a) {
+    if (a.mode == A_CONV3) {
+        if (!conv16_geometry(a)) return false;
+        if (!(a.epi == EPI_BF16 || a.epi == EPI_F32 || a.epi == EPI_F16 || a.epi == EPI_BF16_TEMB)) return false;
+        return a.ldw % 8 == 0;
+    }
     if (a.mode != A_DENSE || a.K % (2 * BK16) != 0 || a.K < 4 * BK16) return false;      // K % 128 (the K-split class runs pairs of K tiles), >= 4 tiles
     if (!(a.epi == EPI_BF16 || a.epi == EPI_F32 || a.epi == EPI_F16 || a.epi == EPI_GEGLU)) return false;
     if (a.lda % 8 || a.ldw % 8) return false;
@@ -462,13 +522,23 @@ bool gemm16_supported(const GemmArgs& a) {
 }
 
 void launch_gemm16_variant(const GemmArgs& a, int v, int wstat, hipStream_t st) {
-    RT_REQUIRE(gemm16_supported(a), "gemm16: problem outside the family's domain (dense, K % 128 == 0, K >= 256)");
+    RT_REQUIRE(gemm16_supported(a), "gemm16: problem outside the family's domain (dense K % 128 == 0, K >= 256; or a 3x3 stride-1 convolution with Cin % 64 == 0)");
     RT_REQUIRE(v >= 0 && v < RT_G16_NVAR, "gemm16: variant");
+    if (a.mode == A_CONV3) {
+        RT_REQUIRE(kVar[v].WK == 1 || (a.K / BK16) % 2 == 0, "gemm16: the K-split class needs an even number of K tiles");
+        switch (a.epi) {
+            case EPI_BF16: launch_e<A_CONV3, EPI_BF16>(a, v, wstat, st); break;
+            case EPI_F32: launch_e<A_CONV3, EPI_F32>(a, v, wstat, st); break;
+            case EPI_F16: launch_e<A_CONV3, EPI_F16>(a, v, wstat, st); break;
+            default: launch_e<A_CONV3, EPI_BF16_TEMB>(a, v, wstat, st); break;
+        }
+        return;
+    }
     switch (a.epi) {
-        case EPI_BF16: launch_e<EPI_BF16>(a, v, wstat, st); break;
-        case EPI_F32: launch_e<EPI_F32>(a, v, wstat, st); break;
-        case EPI_F16: launch_e<EPI_F16>(a, v, wstat, st); break;
-        default: launch_e<EPI_GEGLU>(a, v, wstat, st); break;
+        case EPI_BF16: launch_e<A_DENSE, EPI_BF16>(a, v, wstat, st); break;
+        case EPI_F32: launch_e<A_DENSE, EPI_F32>(a, v, wstat, st); break;
+        case EPI_F16: launch_e<A_DENSE, EPI_F16>(a, v, wstat, st); break;
+        default: launch_e<A_DENSE, EPI_GEGLU>(a, v, wstat, st); break;
     }
 }
 
@@ -480,7 +550,7 @@ int gemm16_pick(const GemmArgs& a, int weights_on_rows, int* wstat) {
     *wstat = 0;
     if (!gemm16_supported(a)) return -1;
     const int batched = weights_on_rows ? a.N : a.M;                 // extent of the token dimension
-    const int rps = a.rows_per_stream > 0 ? a.rows_per_stream : batched;
+    const int rps = a.mode == A_CONV3 ? a.rows_per_batch : (a.rows_per_stream > 0 ? a.rows_per_stream : batched);
     if (rps < 256) return -1;                                        // small maps stay on gemm.hip (128x128 tiles / split-K)
     const double nk = a.K / 64.0;
     // launch time model in units of one K tile of a 224x160 tile: whole rounds of 256 workgroups (one per CU) x (K tiles x tile
@@ -490,6 +560,14 @@ int gemm16_pick(const GemmArgs& a, int weights_on_rows, int* wstat) {
         const long tiles = (long)cdiv(a.M, BMv) * cdiv(a.N, BNv);
         return (double)((tiles + 255) / 256) * (nk * (BMv + BNv) / 384.0 * eff + 12.0);
     };
+    if (a.mode == A_CONV3) {
+        // same classes as the dense problems of the same width; the K-split class needs an even K-tile count (Cin / 64 even)
+        const bool wide = a.N % 320 == 0 && (long)cdiv(rps, 224) * (a.N / 320) >= 32;
+        if (wide) return 4;
+        if (a.N % 160 == 0 && (a.K / BK16) % 2 == 0) return 0;
+        if (a.N % 256 == 0) return 2;
+        return -1;
+    }
     if (weights_on_rows) {
         if (a.epi != EPI_BF16 || a.M % 160 != 0) return -1;
         return cost(160, 224, 1.0) <= cost(160, 128, 1.2) ? 6 : 7;

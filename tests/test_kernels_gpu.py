@@ -371,6 +371,44 @@ def test_attention_against_reference_module_golden():
     report("reference Attention module y_inj (real_attn_probs)", y[B:], g["y_inj"], atol=3e-2, rtol=3e-2)
 
 
+def test_cross_attn_block_op_against_reference_module_golden():
+    """rt_op_cross_attn_block = to_q -> attention over the cached 77 keys (font-size softmax) -> to_out + bias + fp16 trunk residual in
+    one C-ABI call, against the outputs of the UNMODIFIED reference Attention module (golden y_plain / y_fs incl. a negative font
+    size) plus the residual the BasicTransformerBlock adds around it (attention.py:169-189)."""
+    import ctypes as C
+    import os
+    from rich_text_to_image_amd.engine import load_library, _ptr
+    g = torch.load(os.path.join(os.path.dirname(__file__), "golden", "attention_ops.pt"))
+    lib = load_library()
+    H, d, DP = 2, 32, 32
+    qs = d ** -0.5 * math.log2(math.e)
+    x, ctx, sd = g["x"], g["ctx"], g["cross_sd"]
+    B, N, Cc = x.shape
+    assert (g["font_size"] < 0).any()
+    k = F.linear(ctx, sd["to_k.weight"]); v = F.linear(ctx, sd["to_v.weight"])
+    Kp = torch.zeros(B, 96, H * d); Kp[:, :77] = k
+    Vp = torch.zeros(B, 96, H * d); Vp[:, :77] = v
+    K = _pack_heads(Kp.reshape(B * 96, -1), H, d, DP); VT = _pack_heads(Vp.reshape(B * 96, -1), H, d, DP).t().contiguous()
+    wq = _pack_heads(sd["to_q.weight"].t().contiguous(), H, d, DP, qs).t().contiguous()          # [H*DP, C], pre-scaled
+    wo = torch.zeros(Cc, H * DP); wo.reshape(Cc, H, DP)[:, :, :d] = sd["to_out.0.weight"].reshape(Cc, H, d)
+    wo, bo = bf(wo), sd["to_out.0.bias"].float().to(DEV).contiguous()
+    wabs = torch.zeros(2, 96); wabs[:, :77] = 1.0
+    wsgn = torch.ones(2, 96)
+    wabs[1, g["word_pos"]] = g["font_size"].abs(); wsgn[1, g["word_pos"]] = g["font_size"].sign()
+    wabs, wsgn = wabs.to(DEV), wsgn.to(DEV)
+    xb = bf(x.reshape(B * N, Cc))
+    trunk = (rnd(B * N, Cc, seed=5) * 2).to(DEV).to(torch.float16).contiguous()
+    q = torch.empty(B * N, H * DP, device=DEV, dtype=torch.bfloat16); o = torch.empty_like(q)
+    ia = lambda vals: (C.c_int * B)(*vals)
+    for name, ws in (("y_plain", [0, 0]), ("y_fs", [1, 1])):
+        out = torch.empty_like(trunk)
+        rc = lib.rt_op_cross_attn_block(_ptr(xb), _ptr(wq), _ptr(wo), _ptr(bo), _ptr(K), _ptr(VT), VT.stride(0), ia([0, 1]), ia(ws), _ptr(wabs),
+                                        _ptr(wsgn), _ptr(trunk), _ptr(out), _ptr(q), _ptr(o), B, N, Cc, H, DP, None)
+        assert rc == 0, lib.rt_op_last_error().decode()
+        torch.cuda.synchronize()
+        report(f"rt_op_cross_attn_block {name}", out.float().cpu(), g[name].reshape(B * N, Cc) + trunk.float().cpu(), atol=3e-2, rtol=3e-2)
+
+
 # ----------------------------------------------------------------------------------------------- norms
 @pytest.mark.parametrize("B,HW,C1,C2,G,silu,bf16in", [(2, 256, 64, 0, 8, True, False), (3, 1024, 320, 0, 32, True, False),
                                                       (2, 64, 1280, 640, 32, True, False), (2, 4096, 640, 320, 32, True, False),

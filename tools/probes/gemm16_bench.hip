@@ -139,6 +139,45 @@ int main(int argc, char** argv) {
         }
         fflush(stdout);
     }
+    {   // 3x3 stride-1 convolutions: patch kernel (gemm.hip conv3p_kernel) against the implicit GEMM of gemm16.hip
+        struct Cv { int B, H, W, Cin, Cout, epi, v; } cs[] = {{7, 32, 32, 1280, 1280, EPI_BF16, 0}, {7, 32, 32, 2560, 1280, EPI_F16, 0}, {7, 32, 32, 1920, 1280, EPI_BF16, 0},
+            {7, 64, 64, 640, 640, EPI_BF16, 4}, {7, 64, 64, 1280, 640, EPI_F16, 4}, {7, 64, 64, 960, 640, EPI_BF16, 4}, {7, 128, 128, 320, 320, EPI_BF16, 4},
+            {7, 128, 128, 640, 320, EPI_F16, 4}, {3, 20, 24, 128, 320, EPI_BF16, 4}};
+        for (auto c : cs) {
+            GemmArgs g{}; g.A = A; g.W = W; g.zero = zero; g.mode = A_CONV3; g.epi = c.epi; g.bias = bias;
+            g.M = c.B * c.H * c.W; g.N = c.Cout; g.K = 9 * c.Cin; g.ldw = g.K; g.ldo = c.Cout; g.rows_per_batch = c.H * c.W;
+            g.Hin = g.Hout = c.H; g.Win = g.Wout = c.W; g.Cin = c.Cin;
+            if (c.epi == EPI_F16) { g.res = resid; g.ldres = c.Cout; }
+            const size_t nout = (size_t)g.M * g.ldo;
+            const int kind = c.epi == EPI_F16 ? 2 : 0;
+            printf("conv3x3 %dx%dx%dx%d -> %d  (%.1f GFLOP)\n", c.B, c.H, c.W, c.Cin, c.Cout, 2.0 * g.M * g.N * g.K * 1e-9);
+            auto run = [&](int which, void* o) {
+                GemmArgs q = g; q.out = o;
+                if (which == 0) {
+                    if (c.H % 16 || c.W % 16) launch_with_cfg(q, 2, 0);
+                    else if (c.epi == EPI_F16) launch_conv3p<EPI_F16, false>(q, 0); else launch_conv3p<EPI_BF16, false>(q, 0);
+                } else launch_gemm16_variant(q, c.v, 0, 0);
+            };
+            hipMemset(out0, 0, nout * 2); hipMemset(out1, 0xff, nout * 2);
+            run(0, out0); run(1, out1);
+            hipMemset(dstat, 0, 8);
+            hipLaunchKernelGGL(diff_kernel, dim3(1024), dim3(256), 0, 0, out0, out1, nout, kind, dstat);
+            float hs[2]; hipMemcpy(hs, dstat, 8, hipMemcpyDeviceToHost);
+            printf("    check v%d: max|diff| %.4g  max|ref| %.4g  rel %.2e %s\n", c.v, hs[0], hs[1], hs[0] / (hs[1] + 1e-30f), hs[0] / (hs[1] + 1e-30f) < 1e-2f ? "OK" : "MISMATCH");
+            for (int which = 0; which < 2; ++which) {
+                float best = 1e30f;
+                for (int round = 0; round < 3; ++round) {
+                    run(which, out1);
+                    hipEventRecord(e0, 0);
+                    for (int r = 0; r < 8; ++r) run(which, out1);
+                    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+                    float ms; hipEventElapsedTime(&ms, e0, e1); best = std::min(best, ms / 8);
+                }
+                printf("    %s  min %7.1f us (%5.0f TF)\n", which == 0 ? "patch kernel " : "gemm16 conv  ", best * 1e3, 2.0 * g.M * g.N * g.K / (best * 1e-3) / 1e12);
+            }
+            fflush(stdout);
+        }
+    }
     // what the shape-based rule picks
     printf("pick:");
     for (const Case& c : cases) {
