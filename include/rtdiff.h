@@ -62,7 +62,7 @@ typedef struct rt_engine rt_engine;
 int rt_create(const rt_config* cfg, int device, rt_engine** out);   /* RegionDiffusion.__init__ rd.py:16-47, xl.py:56-134 */
 int rt_destroy(rt_engine* e);
 const char* rt_last_error(rt_engine* e);                             /* e may be NULL: last error of failed rt_create */
-int rt_set_stream(rt_engine* e, void* hip_stream);
+int rt_set_stream(rt_engine* e, void* hip_stream);   /* NULL: back to the stream rt_create made.  A step call is hipGraph-capturable on it (tests/test_engine_gpu.py) */
 int rt_synchronize(rt_engine* e);
 
 /* weights: names are the reference UNet's state_dict keys (unet.load_state_dict, rd.py:32, xl.py:115) --- */
@@ -139,6 +139,13 @@ int rt_op_attention(const void* Q, int ldq, const void* K, int ldk, const void* 
                     const int* q_src_host, const int* k_src_host, const int* v_src_host, const int* wset_host,
                     const float* wabs, const float* wsgn, int B, int H, int N, int NK, int nk_valid, int DP, int cross,
                     void* stream);
+/* One tile variant of the 16x16x32-MFMA GEMM family (csrc/gemm16.hip; tests / micro-benchmarks - rt_op_gemm picks by shape):
+ * 0: 224x160 K-split  1: 128x160 K-split  2: 224x256  3: 256x256  4: 224x320  5: 256x320  6: 160x224 K-split (V^T)  7: 160x128 K-split
+ * 8: 128x256;  -1: the variant the shape rule picks.  Variants {2,3,4,5,8} (class A) give the same bits as each other and as every
+ * tile configuration of csrc/gemm.hip; {0,1} and {6,7} (class B: two K halves summed at the end) are bit-identical pairs.
+ * Dense only, K % 128 == 0, K >= 256; epi as rt_op_gemm (0, 1, 3, 4). */
+int rt_op_gemm16_variant(const void* A, const void* W, const float* bias, void* out, const void* res, int epi, int M, int N, int K, int lda,
+                         int ldw, int ldo, int ldres, int weights_on_rows, int variant, int wstat, void* stream);
 /* The SDXL cross-attention block the north star names, as one call (replaces attn2 of BasicTransformerBlock, models/attention.py:169-189,
  * processor arithmetic models/attention_processor.py:476-545, font-size softmax :386-401):
  *   trunk_out[B*N, C] (fp16) = trunk_in + to_out(softmax_fs(to_q(x) K[prompt]^T) V[prompt]) + bo

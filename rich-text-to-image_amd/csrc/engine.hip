@@ -138,7 +138,8 @@ void launch_background_blend(float* lat, const float* lat_ref, const float* mask
 struct rt_engine {
     rt_config cfg;
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;       // the stream every launch of this engine goes to
+    hipStream_t own_stream = nullptr;   // created by rt_create; rt_set_stream(NULL) returns to it
     std::string err;
 
     Arena arena;                 // packed weights only (this is what a multi-GPU launch broadcasts)
@@ -821,6 +822,7 @@ int rt_create(const rt_config* cfg, int device, rt_engine** out) {
         }
         HIP_CHECK(hipSetDevice(device));
         HIP_CHECK(hipStreamCreate(&e->stream));
+        e->own_stream = e->stream;
         HIP_CHECK(hipMalloc((void**)&e->arena_base, e->arena_bytes));
         HIP_CHECK(hipMemset(e->arena_base, 0, e->arena_bytes));
         HIP_CHECK(hipMalloc((void**)&e->sarena_base, e->sarena_bytes));
@@ -870,7 +872,7 @@ int rt_destroy(rt_engine* e) {
     if (e->arena_base) {
         (void)hipSetDevice(e->device); (void)hipStreamSynchronize(e->stream);
         for (auto& r : e->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
-        (void)hipFree(e->arena_base); (void)hipFree(e->sarena_base); (void)hipFree(e->ws.base); (void)hipFree(e->temb_tab_dev); (void)hipFree(e->splitk_buf); (void)hipStreamDestroy(e->stream);
+        (void)hipFree(e->arena_base); (void)hipFree(e->sarena_base); (void)hipFree(e->ws.base); (void)hipFree(e->temb_tab_dev); (void)hipFree(e->splitk_buf); (void)hipStreamDestroy(e->own_stream);
     }
     delete e;
     return RT_OK;
@@ -880,7 +882,7 @@ const char* rt_last_error(rt_engine* e) { return e ? e->err.c_str() : g_create_e
 
 static void need_device(rt_engine* e) { if (!e->arena_base) throw rt_error(RT_E_STATE, "engine has no device (weight-table-only)"); }
 
-int rt_set_stream(rt_engine* e, void* s) { RT_TRY(e, { need_device(e); e->stream = (hipStream_t)s; }) }
+int rt_set_stream(rt_engine* e, void* s) { RT_TRY(e, { need_device(e); e->stream = s ? (hipStream_t)s : e->own_stream; }) }
 int rt_synchronize(rt_engine* e) { RT_TRY(e, { need_device(e); HIP_CHECK(hipStreamSynchronize(e->stream)); }) }
 
 int rt_weight_count(rt_engine* e) { return (int)e->slots.size(); }
@@ -1091,6 +1093,16 @@ int rt_op_attention(const void* Q, int ldq, const void* K, int ldk, const void* 
         for (int b = 0; b < B; ++b) { a.q_src[b] = q_src ? q_src[b] : b; a.k_src[b] = k_src ? k_src[b] : b; a.v_src[b] = v_src ? v_src[b] : b; a.wset[b] = wset ? wset[b] : 0; }
         a.B = B; a.H = H; a.N = N; a.NK = NK; a.nk_valid = nk_valid; a.DP = DP; a.cross = cross;
         launch_attention(a, (hipStream_t)stream);
+    })
+}
+// One tile variant of the 16x16x32 family (csrc/gemm16.hip) on a dense problem - tests and micro-benchmarks; rt_op_gemm picks by shape.
+int rt_op_gemm16_variant(const void* A, const void* W, const float* bias, void* out, const void* res, int epi, int M, int N, int K, int lda,
+                         int ldw, int ldo, int ldres, int weights_on_rows, int variant, int wstat, void* stream) {
+    OP_TRY({
+        GemmArgs g{}; g.A = (const bf16_t*)A; g.W = (const bf16_t*)W; g.bias = bias; g.out = out; g.res = res; g.zero = op_zero_page();
+        g.mode = A_DENSE; g.epi = epi; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldo = ldo; g.ldres = ldres; g.weights_on_rows = weights_on_rows;
+        if (variant < 0) { int ws = 0; variant = gemm16_pick(g, weights_on_rows, &ws); wstat = ws; RT_REQUIRE(variant >= 0, "rt_op_gemm16_variant: the family has no tile for this shape"); }
+        launch_gemm16_variant(g, variant, wstat, (hipStream_t)stream);
     })
 }
 // The block BASELINE.json's north star names: attn2 of a BasicTransformerBlock (models/attention.py:169-189) with the reference

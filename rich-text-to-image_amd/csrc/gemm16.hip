@@ -369,6 +369,9 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void gemm16_kernel(GemmArgs p, i
             }
         }
     }
+#ifdef RT_G16_TIMING
+    { float bsum = 0.f; for (int t = 0; t < TNO; ++t) bsum += bias_v[t][0]; asm volatile("" ::"v"(bsum)); G16_T(5) }
+#endif
 #pragma unroll
     for (int i = 0; i < TMW; ++i) {
         if (!owned(i)) continue;
@@ -438,8 +441,12 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void gemm16_kernel(GemmArgs p, i
                 }
             }
         }
+#ifdef RT_G16_TIMING
+        if (i == (WK == 2 && kh == 1 ? H0 : 0)) G16_T(6)
+#endif
     }
 #ifdef RT_G16_TIMING
+    G16_T(7)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     G16_T(4)
 #endif

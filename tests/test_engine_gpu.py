@@ -161,6 +161,49 @@ def test_rich_text_loop_matches_reference_golden(which, tiny_xl, tiny_sd):
     assert torch.equal(outs[False], outs[True]) or rel_l2(outs[True], outs[False]) < 1e-6
 
 
+def test_region_step_is_hipgraph_capturable(tiny_xl):
+    """no allocation, no synchronisation, no stream-side bookkeeping inside a step call.  An injected rich-text step
+    (7 streams: font-size softmax, Q/K + ResNet-feature injection, masks, CFG, Euler update) is captured into a HIP graph on a
+    side stream and replayed from the same latents: bit-identical to the eager step.  (Round 2's in-situ tile tuner recorded events
+    on the stream and the split-K scratch grew with hipMalloc + a stream sync: neither survives capture.)"""
+    cfg, sd, eng = tiny_xl
+    g = _gold("tiny_xl_euler")
+    inp, steps = g["inputs"], g["steps"]
+    sched = OracleEuler(); sched.set_timesteps(steps)
+    eng.set_prompts(inp["embeds"].to(DEV), inp["pooled"].to(DEV), inp["time_ids"])
+    eng.set_masks(inp["masks"].repeat(1, 4, 1, 1).to(DEV))
+    eng.set_fontsize(inp["word_pos"], inp["font_size"])
+    lat0 = (inp["latents"] * sched.init_noise_sigma).to(DEV)
+    hw = lat0.shape[2]
+
+    def reset():
+        eng.set_schedule(0, sched.timesteps.tolist(), sched.sigmas.tolist(), steps)
+        eng.set_latents(lat0)
+
+    reset()
+    eng.region_step(0, g["guidance_scale"], g["inject_selfattn"], g["inject_background"], xl=True)       # eager (also warms one-time state)
+    eager = eng.read_latents(hw, hw).clone()
+    side = torch.cuda.Stream()
+    eng.synchronize()
+    eng.set_stream(side.cuda_stream)
+    try:
+        reset()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            eng.region_step(0, g["guidance_scale"], g["inject_selfattn"], g["inject_background"], xl=True)
+        for _ in range(2):                                   # replay twice from the same latents
+            reset()
+            torch.cuda.synchronize()
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(eng.read_latents(hw, hw), eager)
+    finally:
+        torch.cuda.synchronize()
+        eng.set_stream(None)
+    reset()
+
+
 def test_engine_is_deterministic(tiny_sd):
     cfg, sd, eng = tiny_sd
     g = _gold("tiny_sd_plms")

@@ -115,10 +115,110 @@ def test_gemm_tile_configurations_are_bit_identical(cfg):
         lib.rt_op_gemm_force_config(-1)
 
 
-def test_gemm_in_situ_tuning_is_invisible():
-    """The tuner ranks the tile configurations on the real launches of a shape (each launch of a shape under tuning takes the next
-    configuration, bracketed by HIP events): 48 launches of one in-place-residual problem - more than 8 configurations x 4 samples -
-    must all give the same bits, before, while and after the shape settles (a shape no other test uses, so tuning starts here)."""
+def _gemm16(A, W, bias, epi, variant, res=None, wstat=0, vt=0):
+    from rich_text_to_image_amd.engine import load_library, _ptr
+    lib = load_library()
+    M, K = A.shape
+    N = W.shape[0]
+    out = torch.empty(M, N // 2 if epi == 3 else N, device=DEV, dtype={1: torch.float32, 4: torch.float16}.get(epi, torch.bfloat16))
+    rc = lib.rt_op_gemm16_variant(_ptr(A), _ptr(W), _ptr(bias), _ptr(out), _ptr(res), epi, M, N, K, K, K, out.stride(0),
+                                  res.stride(0) if res is not None else 0, vt, variant, wstat, None)
+    assert rc == 0, lib.rt_op_last_error().decode()
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("M,N,K", [(7168, 1280, 1280), (5000, 640, 256), (448, 2560, 640), (4096, 1280, 5120)])
+def test_gemm16_family_classes_and_reference(M, N, K):
+    """csrc/gemm16.hip (16x16x32 MFMA, 224-row tiles).  Class A variants (one ascending k sum) must give the bits of gemm.hip's
+    32x32x16 kernels and of each other, whatever the tile; class B variants (K split over two waves: even + odd 32-deep k steps)
+    must agree with each other bit for bit and with fp32 torch to rounding; all epilogues (bf16, fp32 + residual, fp16 trunk +
+    residual) incl. ragged rows."""
+    from rich_text_to_image_amd.engine import load_library
+    lib = load_library()
+    A, W = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=K ** -0.5))
+    bias = rnd(N, seed=3).to(DEV)
+    res32 = rnd(M, N, seed=4).to(DEV)
+    res16 = res32.to(torch.float16)
+    ref = A.float() @ W.float().t() + bias
+    try:
+        lib.rt_op_gemm_force_config(0)
+        old = gemm(A, W, bias, epi=1, res=res32)                          # gemm.hip, 128x128 tiles
+    finally:
+        lib.rt_op_gemm_force_config(-1)
+    cls_a = [v for v in (2, 3, 4, 8) if N % {2: 256, 3: 256, 4: 320, 8: 256}[v] == 0]
+    for v in cls_a:
+        out = _gemm16(A, W, bias, 1, v, res=res32)
+        assert torch.equal(out, old), f"class A variant {v} differs from gemm.hip at {M}x{N}x{K}: max {(out - old).abs().max().item()}"
+    b0 = _gemm16(A, W, bias, 1, 0, res=res32)
+    b1 = _gemm16(A, W, bias, 1, 1, res=res32)
+    assert torch.equal(b0, b1), f"class B variants differ at {M}x{N}x{K}"
+    report(f"gemm16 class B f32+res {M}x{N}x{K}", b0, ref + res32, **F32_OUT)
+    report(f"gemm16 class B bf16 {M}x{N}x{K}", _gemm16(A, W, bias, 0, 0), ref, **BF16_OUT)
+    report(f"gemm16 class B f16 trunk {M}x{N}x{K}", _gemm16(A, W, bias, 4, 0, res=res16), ref + res16.float(), atol=4e-3, rtol=1.5e-3)
+    if cls_a:
+        report(f"gemm16 class A f16 trunk {M}x{N}x{K}", _gemm16(A, W, bias, 4, cls_a[0], res=res16), ref + res16.float(), atol=4e-3, rtol=1.5e-3)
+    # V^T form (weights on the rows of the output): class B transposed, both column tilings
+    if M % 160 == 0 or N % 160 == 0:
+        Wv, X = (A, W) if M % 160 == 0 else (W, A)
+        t6 = _gemm16(Wv, X, None, 0, 6, vt=1)
+        t7 = _gemm16(Wv, X, None, 0, 7, vt=1)
+        assert torch.equal(t6, t7)
+        report("gemm16 V^T", t6, Wv.float() @ X.float().t(), **BF16_OUT)
+
+
+def test_gemm16_geglu_epilogue_and_w_stationary_mapping():
+    M, C = 1000, 256
+    A = bf(rnd(M, C, seed=7))
+    Wfull = rnd(8 * C, C, seed=8, scale=C ** -0.5)
+    bfull = rnd(8 * C, seed=9)
+    half = 4 * C
+    rows = []
+    for blk in range(half // 32):
+        rows += list(range(blk * 32, blk * 32 + 32)) + list(range(half + blk * 32, half + blk * 32 + 32))
+    Wp, bp = bf(Wfull[rows]), bfull[rows].to(DEV).contiguous()
+    h = A.float() @ bf(Wfull).float().t() + bfull.to(DEV)
+    a, g = h.chunk(2, dim=-1)
+    outs = [_gemm16(A, Wp, bp, 3, v, wstat=ws) for v in (2, 3, 8) for ws in (0, 1)]
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])                                   # tile shape and tile -> XCD mapping do not change a bit
+    report("gemm16 GEGLU", outs[0], a * F.gelu(g), **BF16_OUT)
+    assert torch.equal(outs[0], gemm(A, Wp, bp, epi=3))                  # what rt_op_gemm picks (and gemm.hip's GEGLU) agree bit for bit
+
+
+@pytest.mark.parametrize("B,H,W_,Cin,Cout,epi", [(2, 32, 32, 128, 320, 0), (3, 20, 24, 128, 160, 4), (1, 64, 64, 192, 640, 2), (8, 32, 32, 256, 256, 1)])
+def test_conv3x3_on_the_gemm16_main_loop(B, H, W_, Cin, Cout, epi):
+    """3x3 stride-1 convolutions with Cin % 64 == 0 run as an implicit GEMM on gemm16.hip's main loop (padding taps read as zeros
+    through the buffer descriptor's range check): against F.conv2d, against the patch kernel it replaces (rt_op_gemm_debug(8)),
+    for images whose sides are not multiples of 16 as well, with the resnet epilogues (time embedding, fp16 trunk + residual)."""
+    from rich_text_to_image_amd.engine import load_library
+    lib = load_library()
+    x = rnd(B, Cin, H, W_, seed=20); w = rnd(Cout, Cin, 3, 3, seed=21, scale=(9 * Cin) ** -0.5)
+    bias = rnd(Cout, seed=22).to(DEV)
+    ref = F.conv2d(x.to(torch.bfloat16).float().to(DEV), w.to(torch.bfloat16).float().to(DEV), bias, padding=1).permute(0, 2, 3, 1).reshape(B * H * W_, Cout)
+    xin, wp = bf(x.permute(0, 2, 3, 1)), bf(_conv_weight_packed(w))
+    kw = {}
+    if epi == 2:
+        temb = rnd(B, Cout, seed=23).to(DEV)
+        kw = dict(temb=temb); ref = (ref.reshape(B, H * W_, Cout) + temb[:, None, :]).reshape(B * H * W_, Cout)
+    if epi in (1, 4):
+        res = rnd(B * H * W_, Cout, seed=24).to(DEV)
+        res = res.to(torch.float16) if epi == 4 else res
+        kw = dict(res=res); ref = ref + res.float()
+    out = gemm(xin, wp, bias, epi=epi, mode=1, conv=(H, W_), **kw)
+    tol = {0: BF16_OUT, 2: BF16_OUT, 1: F32_OUT, 4: dict(atol=4e-3, rtol=1.5e-3)}[epi]
+    report(f"conv3x3 gemm16 {B}x{H}x{W_}x{Cin}->{Cout} epi{epi}", out, ref, **tol)
+    try:
+        lib.rt_op_gemm_debug(8)
+        old = gemm(xin, wp, bias, epi=epi, mode=1, conv=(H, W_), **kw)
+    finally:
+        lib.rt_op_gemm_debug(0)
+    report("conv3x3 gemm16 vs the kernels it replaces", out, old.float(), **tol)
+
+
+def test_gemm_repeated_launches_are_bit_identical():
+    """(Round 2 ranked tile configurations in situ with HIP events; the choice is now a pure function of the shape.)  48 launches of
+    one in-place-residual problem must all give the same bits."""
     M, N, K = 4352, 1280, 704
     A, W = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=K ** -0.5))
     h0 = rnd(M, N, seed=4).to(DEV)

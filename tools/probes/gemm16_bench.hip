@@ -122,12 +122,13 @@ int main(int argc, char** argv) {
             const int nwg = cdiv(c.M, kVar[vs[i].id].BM) * cdiv(c.N, kVar[vs[i].id].BN);
             std::vector<long long> t((size_t)nwg * 8);
             gemm16_read_times(t.data(), nwg * 8);
-            double seg[4] = {0, 0, 0, 0};
+            double seg[4] = {0, 0, 0, 0}, e5 = 0, e6 = 0, e7 = 0;
             for (int w = 0; w < nwg; ++w) {
                 for (int k = 0; k < 4; ++k) seg[k] += (double)(t[w * 8 + k + 1] - t[w * 8 + k]);
+                e5 += (double)(t[w * 8 + 5] - t[w * 8 + 3]); e6 += (double)(t[w * 8 + 6] - t[w * 8 + 5]); e7 += (double)(t[w * 8 + 7] - t[w * 8 + 3]);
             }
-            printf("    timing v%d%s: prologue %6.0f | loop %7.0f | drain+exchange %6.0f | epilogue %6.0f cycles (mean over %d WGs)\n",
-                   vs[i].id, vs[i].wstat ? "w" : "", seg[0] / nwg, seg[1] / nwg, seg[2] / nwg, seg[3] / nwg, nwg);
+            printf("    timing v%d%s: prologue %6.0f | loop %7.0f | drain+exchange %6.0f | epilogue %6.0f cycles (mean over %d WGs) [epilogue: bias wait %5.0f | first row tile %5.0f | all stores issued %6.0f]\n",
+                   vs[i].id, vs[i].wstat ? "w" : "", seg[0] / nwg, seg[1] / nwg, seg[2] / nwg, seg[3] / nwg, nwg, e5 / nwg, e6 / nwg, e7 / nwg);
         }
 #endif
         for (int i = 0; i < nv; ++i) {
