@@ -76,6 +76,7 @@ def cpu_baseline(sd_cpu, threads, x, ctx, pooled, tid, t):
     from oracle.unet import SDXL_CONFIG, OracleUNet
     # pick the thread count on a cheap proxy (one GEGLU-sized fp32 matmul): oversubscribed NUMA boxes are
     # slower with every hardware thread than with a subset
+    threads_max = threads
     a, b = torch.randn(4096, 1280), torch.randn(1280, 10240)
     best = (1e9, threads)
     cand = sorted({t for t in (16, 32, 64, 96, 128, threads) if t <= threads})
@@ -92,7 +93,9 @@ def cpu_baseline(sd_cpu, threads, x, ctx, pooled, tid, t):
         t0 = time.perf_counter()
         ref = o.forward(x, t, ctx, added)
         dt = time.perf_counter() - t0
-    return dict(value=1.0 / (7 * dt), unit="steps/s", cores=threads, kind="port", cpu=cpu_model_name(),
+    return dict(value=1.0 / (7 * dt), unit="steps/s", cores=threads, cores_physical=threads_max,
+                cores_note=f"{threads} of {threads_max} physical cores (thread count picked by a matmul probe over {cand}: the fastest, so the baseline is not handicapped by oversubscription)",
+                kind="port", cpu=cpu_model_name(),
                 sample=f"1 batch-1 SDXL UNet forward (fp32 oracle, {dt:.2f} s) x 7 forwards/step extrapolated",
                 forward_seconds=dt), ref
 
@@ -202,6 +205,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--elide", action="store_true", help="skip reference forwards that cannot influence the output")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="warm up, then run ONLY the two event-profiled steps (one injected, one not) and print the line without the "
+                         "timing / micro-benchmark legs: the command the rocprofv3 --pmc passes wrap (tools/pmc_passes.sh), so that the "
+                         "counters and `roofline.flops_per_launch` describe the same launches")
     ap.add_argument("--dry-launch", action="store_true",
                     help="exercise the multi-rank launch path only (rendezvous, one arena-sized broadcast, barrier, max-over-ranks) "
                          "on the gloo backend without touching a GPU, and print the JSON line with value = null (CPU test of --gpus N)")
@@ -288,10 +295,10 @@ def main():
     launcher.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run(args.steps)
+    run(0 if args.roofline_only else args.steps)
     eng.synchronize()
     torch.cuda.synchronize()
-    dt_local = time.perf_counter() - t0
+    dt_local = max(time.perf_counter() - t0, 1e-9)
     launcher.barrier()
     dt = launcher.max_over_ranks(dt_local, device=dev if world > 1 else "cpu")
     final = eng.read_latents(hw, hw)
@@ -301,29 +308,42 @@ def main():
     # stream for one injected step (i=0) and one non-injected step (i=nsched-1)
     roof = None
     prof = None
+    step_flops = None
     if rank == 0:
         reset()
-        eng.profile_enable(True)
-        eng.region_step(0, gs, isa, ibg, xl=True, elide=False)
-        eng.region_step(nsched - 1, gs, isa, ibg, xl=True, elide=False)
-        prof = eng.profile_read()
-        eng.profile_enable(False)
+        per_step = []
+        for i_prof in (0, nsched - 1):                       # one injected (t > 500) and one non-injected step
+            eng.profile_enable(True)
+            eng.region_step(i_prof, gs, isa, ibg, xl=True, elide=False)
+            per_step.append(eng.profile_read())
+            eng.profile_enable(False)
+        prof = {k: {f: per_step[0][k][f] + per_step[1][k][f] for f in ("launches", "total_ms", "total_flops")} for k in per_step[0]}
+        # MFMA FLOPs the engine actually executed per step (GEMM + convolution + attention launches; the region streams of an
+        # injected step skip their Q|K projections): weights the whole-step rate by the timed schedule's own mix of the two kinds
+        f_inj, f_non = (sum(v["total_flops"] for v in ps.values()) for ps in per_step)
+        idx = [sched_index(i, args.steps) for i in range(args.steps)]
+        n_inj = sum(1 for i in idx if ts[i] > (1.0 - isa) * 1000.0)
+        step_flops = dict(injected=f_inj, non_injected=f_non, timed_injected_steps=n_inj, timed_steps=len(idx),
+                          mean=(n_inj * f_inj + (len(idx) - n_inj) * f_non) / max(1, len(idx)))
         dom = max(prof, key=lambda k: prof[k]["total_ms"])
         p = prof[dom]
         achieved = p["total_flops"] / (p["total_ms"] * 1e-3) / 1e12
-        # HBM-side bytes per launch of the dominant kernel class come from separate rocprofv3 --pmc passes
-        # (FETCH_SIZE / WRITE_SIZE cannot be read from inside the process); tools/pmc_traffic.py writes the file
+        # HBM-side bytes per launch of the dominant kernel class come from separate rocprofv3 --pmc passes over
+        # `bench.py --roofline-only` (FETCH_SIZE / WRITE_SIZE cannot be read from inside the process); tools/pmc_traffic.py keeps
+        # the dispatches of the two profiled steps only, i.e. the launches `flops_per_launch` is averaged over
         traffic = None
+        tfile = None
         try:
-            tfile = next(f for f in ("r2_pmc_traffic.json", "r1_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            tfile = next(f for f in ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
             tj = json.load(open(os.path.join(ROOT, "profiles", tfile)))
             cls = {"gemm_kernel<A_DENSE>": "gemm_dense", "gemm_kernel<A_CONV3*>": "gemm_conv", "attn_kernel<self>": "attn_self",
                    "attn_kernel<cross>": "attn_cross"}[dom]
             traffic = tj["classes"][cls]["hbm_bytes_per_launch"]
         except Exception:
             pass
-        roof = dict(bound="mfma", kernel=dom, achieved=achieved, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
-                    frac=achieved / PEAK_BF16_TFLOPS, traffic=traffic, traffic_source=f"profiles/{tfile} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 FETCH correction)" if traffic else None,
+        roof = dict(bound="mfma", kernel=dom + " (dense GEMM launches: gemm16_kernel<A_DENSE> / gemm_kernel<A_DENSE>)" if dom == "gemm_kernel<A_DENSE>" else dom,
+                    achieved=achieved, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+                    frac=achieved / PEAK_BF16_TFLOPS, traffic=traffic, traffic_source=f"profiles/{tfile} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py --roofline-only`, the dispatches of the two profiled steps; gfx950 x2 FETCH correction)" if traffic else None,
                     launches=p["launches"],
                     avg_launch_us=p["total_ms"] * 1e3 / max(1, p["launches"]),
                     flops_per_launch=p["total_flops"] / max(1, p["launches"]),
@@ -335,7 +355,7 @@ def main():
     # the background-blend step the uncond_ref / text_ref forwards are dead in the reference too).  Same
     # final latents; NOT the headline value (the reference runs those forwards).
     elided = None
-    if not args.elide:
+    if not args.elide and not args.roofline_only:
         reset()
         for i in range(min(2, nsched)):
             eng.region_step(i, gs, isa, ibg, xl=True, elide=True)
@@ -351,7 +371,7 @@ def main():
         elided = dict(value=world * args.steps / dt_e, ms_per_step=dt_e / args.steps * 1e3, identical_latents=same)
 
     xblock = None
-    if rank == 0:
+    if rank == 0 and not args.roofline_only:
         try:
             xblock = cross_attention_block(dev)
         except Exception as ex:          # the headline line must still print
@@ -359,7 +379,7 @@ def main():
 
     cpu = None
     parity = None
-    if rank == 0 and not args.no_cpu_baseline and sd_cpu is not None:
+    if rank == 0 and not args.no_cpu_baseline and not args.roofline_only and sd_cpu is not None:
         threads = max(1, min(os.cpu_count() or 1, 256))
         try:
             phys = len({l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("core id")}) * \
@@ -379,19 +399,21 @@ def main():
                       config="SDXL-base full architecture, 1 UNet forward (latent 128x128, t=801, negative-prompt stream) vs the fp32 CPU oracle")
 
     if rank == 0:
-        value = world * args.steps / dt
-        step_tflop = 7 * SDXL_FWD_GFLOP / 1e3
+        value = None if args.roofline_only else world * args.steps / dt
+        # executed MFMA FLOPs per step (profile leg) rather than 7 x the nominal forward: injected steps skip the region streams' Q|K GEMMs
+        step_tflop = step_flops["mean"] / 1e12 if step_flops else 7 * SDXL_FWD_GFLOP / 1e3
         line = {
             "metric": "denoising steps/sec (SDXL 1024^2, 50-step, 4 regions)",
             "value": value, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": None if args.roofline_only else dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "SDXL RegionDiffusionXL 1024x1024, R=4 regions, inject_selfattn=0.5, 50-step Euler, "
                                    "CFG 5.0, 7 UNet forwards/step batched, random-init SDXL-base weights",
                        "global_batch": world, "parallelism": f"seed-parallel x{world} (1 weight broadcast, no per-step collectives)",
                        "elide_dead_forwards": bool(args.elide)},
-            "whole_step_tflops_per_gpu": step_tflop / (dt / args.steps),
-            "whole_step_mfma_frac": step_tflop / (dt / args.steps) / PEAK_BF16_TFLOPS,
+            "whole_step_tflops_per_gpu": None if args.roofline_only else step_tflop / (dt / args.steps),
+            "whole_step_mfma_frac": None if args.roofline_only else step_tflop / (dt / args.steps) / PEAK_BF16_TFLOPS,
+            "executed_flops_per_step": step_flops, "nominal_tflop_per_step": 7 * SDXL_FWD_GFLOP / 1e3,
             "weight_broadcast_s": bcast_s, "weight_broadcast_calls": launcher.LAST_BROADCAST_CALLS, "finite": finite,
             "roofline": roof, "cpu_baseline": cpu, "parity": parity, "cross_attention_block": xblock, "elide_dead_forwards_timing": elided,
             "timed_schedule_indices": [sched_index(i, args.steps) for i in range(min(args.steps, nsched))],

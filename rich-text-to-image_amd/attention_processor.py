@@ -57,9 +57,13 @@ class LazyProbsAvg:
         if self._t is None:
             proc, Q, K, B, H, N, NK, NKpad, DP, cross = self._args
             out = torch.empty(B, N, NK, device=Q.device, dtype=torch.float32)
+            # K holds NKpad rows per batch entry (cross: 77 keys padded to 96; self: NKpad == NK rows).  The store kernel wants the
+            # key count padded to a multiple of 32 and the number of key ROWS that exist: a self-attention map over a token grid
+            # that is a multiple of 8 but not of 32 (20x20 = 400) pads the count, not the rows
+            pad32 = (NKpad + 31) // 32 * 32
             for b in range(B):
                 proc._chk(proc.lib.rt_op_attention_probs_avg(_ptr(Q), Q.stride(0), b * N, _ptr(K), K.stride(0), b * NKpad, _ptr(out[b]),
-                                                             H, N, NK, NKpad, NKpad, DP, 0, None))
+                                                             H, N, NK, pad32, NKpad, DP, 0, None))
             self._t = out
         return self._t
 

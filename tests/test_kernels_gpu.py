@@ -143,9 +143,11 @@ def test_gemm16_family_classes_and_reference(M, N, K):
     ref = A.float() @ W.float().t() + bias
     try:
         lib.rt_op_gemm_force_config(0)
-        old = gemm(A, W, bias, epi=1, res=res32)                          # gemm.hip, 128x128 tiles
+        lib.rt_op_gemm_debug(4)                                           # (a small problem would otherwise take gemm.hip's split-K path)
+        old = gemm(A, W, bias, epi=1, res=res32)                          # gemm.hip, 128x128 tiles, one ascending k sum
     finally:
         lib.rt_op_gemm_force_config(-1)
+        lib.rt_op_gemm_debug(0)
     cls_a = [v for v in (2, 3, 4, 8) if N % {2: 256, 3: 256, 4: 320, 8: 256}[v] == 0]
     for v in cls_a:
         out = _gemm16(A, W, bias, 1, v, res=res32)
@@ -610,6 +612,22 @@ def test_attn_processor_seam_matches_reference_module_golden():
     report("processor probs_avg of a real tensor", maps_r[0].detach().cpu(), g["p_self_avg"], atol=2e-3, rtol=5e-2)
     with pytest.raises(TypeError):
         proc(selfa, x2, real_attn_probs=torch.zeros(4, 128, 256, device=DEV))
+
+
+def test_attn_processor_probs_avg_on_a_token_grid_not_divisible_by_32():
+    """20x20 = 400 tokens: the ragged self-attention kernel takes it (N % 8 == 0); the head-averaged map the token-map hooks read
+    (rd.py:414-426) must too - the store kernel pads the key COUNT to 416, not the key rows."""
+    from rich_text_to_image_amd.attention_processor import HipAttnProcessor
+    C_, H, N = 64, 2, 400
+    sd = {"to_q.weight": rnd(C_, C_, seed=1, scale=C_ ** -0.5), "to_k.weight": rnd(C_, C_, seed=2, scale=C_ ** -0.5),
+          "to_v.weight": rnd(C_, C_, seed=3, scale=C_ ** -0.5), "to_out.0.weight": rnd(C_, C_, seed=4, scale=C_ ** -0.5), "to_out.0.bias": rnd(C_, seed=5)}
+    x = rnd(1, N, C_, seed=6).to(DEV)
+    y, maps = HipAttnProcessor()(_StubAttention(sd, H), x)
+    q = F.linear(x.float().cpu(), sd["to_q.weight"]).reshape(1, N, H, -1).permute(0, 2, 1, 3)
+    k = F.linear(x.float().cpu(), sd["to_k.weight"]).reshape(1, N, H, -1).permute(0, 2, 1, 3)
+    ref = torch.softmax(q @ k.transpose(-1, -2) * q.shape[-1] ** -0.5, -1).mean(1)
+    assert maps[0].shape == (1, N, N)
+    report("probs_avg 400 tokens", maps[0].detach().cpu(), ref, atol=2e-3, rtol=5e-2)
 
 
 @pytest.mark.parametrize("which", ["xl", "sd"])

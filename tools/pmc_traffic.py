@@ -6,10 +6,25 @@ import sqlite3
 import sys
 
 
-def per_kernel(db_path, counter):
+CLASSES = {"gemm_dense": lambda n: "gemm" in n and ("<0," in n), "gemm_conv": lambda n: ("gemm" in n and "<0," not in n) or "conv3p" in n,
+           "attn_self": lambda n: "attn_kernel" in n and "false" in n, "attn_cross": lambda n: "attn_kernel" in n and "true" in n}
+BENCH_CLASS = {"gemm_dense": "gemm_kernel<A_DENSE>", "gemm_conv": "gemm_kernel<A_CONV3*>", "attn_self": "attn_kernel<self>", "attn_cross": "attn_kernel<cross>"}
+
+
+def per_kernel(db_path, counter, keep_last=None):
+    """keep_last: {class: L} - keep only the LAST L dispatches of each kernel class (the two event-profiled steps of
+    `bench.py --roofline-only` are the last launches of the run), so counters and flops_per_launch describe the same launches."""
     db = sqlite3.connect(db_path)
     rows = db.execute("select kernel_name, dispatch_id, sum(value), max(duration) from counters_collection where counter_name=? "
-                      "group by kernel_name, dispatch_id", (counter,)).fetchall()
+                      "group by kernel_name, dispatch_id order by dispatch_id", (counter,)).fetchall()
+    if keep_last:
+        by_cls = {}
+        for r in rows:
+            for c, pred in CLASSES.items():
+                if pred(r[0]):
+                    by_cls.setdefault(c, []).append(r)
+                    break
+        rows = [r for c, rs in by_cls.items() for r in (rs[-keep_last[c]:] if c in keep_last else rs)]
     agg = {}
     for name, _, v, dur in rows:
         a = agg.setdefault(name, [0, 0.0, 0.0])
@@ -17,8 +32,12 @@ def per_kernel(db_path, counter):
     return agg
 
 
-def main(fetch_db, write_db, out):
-    f, w = per_kernel(fetch_db, "FETCH_SIZE"), per_kernel(write_db, "WRITE_SIZE")
+def main(fetch_db, write_db, out, bench_json=None):
+    keep = None
+    if bench_json:
+        line = json.loads([l for l in open(bench_json) if l.startswith("{")][-1])
+        keep = {c: line["roofline"]["per_kernel"][b]["launches"] for c, b in BENCH_CLASS.items() if b in line["roofline"]["per_kernel"]}
+    f, w = per_kernel(fetch_db, "FETCH_SIZE", keep), per_kernel(write_db, "WRITE_SIZE", keep)
     res = {}
     for name in sorted(set(f) | set(w), key=lambda n: -(f.get(n, [0, 0, 0])[2])):
         fn, fv, fd = f.get(name, [0, 0.0, 0.0])
@@ -27,8 +46,7 @@ def main(fetch_db, write_db, out):
             continue
         res[name] = dict(launches=fn, avg_us=fd / fn / 1e3, fetch_kib_per_launch=fv / fn, write_kib_per_launch=wv / wn,
                          hbm_bytes_per_launch=(2 * fv / fn + wv / wn) * 1024)
-    classes = {"gemm_dense": lambda n: "gemm" in n and ("<0," in n), "gemm_conv": lambda n: ("gemm" in n and "<0," not in n) or "conv3p" in n,
-               "attn_self": lambda n: "attn_kernel" in n and "false" in n, "attn_cross": lambda n: "attn_kernel" in n and "true" in n}
+    classes = CLASSES
     summary = {}
     for c, pred in classes.items():
         ks = [v for n, v in res.items() if pred(n)]
@@ -36,10 +54,10 @@ def main(fetch_db, write_db, out):
         if nl:
             summary[c] = dict(launches=nl, hbm_bytes_per_launch=sum(k["hbm_bytes_per_launch"] * k["launches"] for k in ks) / nl,
                               avg_us=sum(k["avg_us"] * k["launches"] for k in ks) / nl)
-    json.dump(dict(note=__doc__, classes=summary, kernels=res), open(out, "w"), indent=1)
+    json.dump(dict(note=__doc__, launches_kept=keep, classes=summary, kernels=res), open(out, "w"), indent=1)
     for c, v in summary.items():
         print(f"{c:12s} launches={v['launches']:6d} avg={v['avg_us']:8.1f} us  HBM-side bytes/launch={v['hbm_bytes_per_launch'] / 1e6:9.1f} MB")
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:5])
