@@ -198,6 +198,8 @@ typedef struct rt_vae_config {
     int norm_groups;
     float scaling_factor;                 /* 0.18215 (SD) / 0.13025 (SDXL) */
     int latent_h, latent_w;               /* largest latent the workspace is sized for */
+    int precise;                          /* 1: fp32-class contractions (operands as bf16 hi + lo pairs, three MFMA passes): what the SDXL
+                                           * pipeline of the reference asks for (xl.py:856 decodes in fp32); 0: one bf16 pass */
 } rt_vae_config;
 typedef struct rt_vae rt_vae;
 int rt_vae_create(const rt_vae_config* cfg, int device, rt_vae** out);

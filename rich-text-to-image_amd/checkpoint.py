@@ -178,7 +178,7 @@ def load_components(load_path, kind="SD", device=0, latent_hw=None, lora_path=No
     unet_cfg = unet_config(os.path.join(load_path, "unet"), SD15_CONFIG if kind == "SD" else SDXL_CONFIG)
     vae_cfg = vae_config(os.path.join(load_path, "vae"), SD_VAE_CONFIG if kind == "SD" else SDXL_VAE_CONFIG)
     hw = latent_hw or ((64, 64) if kind == "SD" else (128, 128))
-    vae = VaeDecoder(vae_cfg, hw[0], hw[1], device=device, state_dict=vae_sd)
+    vae = VaeDecoder(vae_cfg, hw[0], hw[1], device=device, state_dict=vae_sd, precise=(kind == "SDXL"))   # xl.py:856 / :918-938: fp32 VAE
     tok = ClipBPETokenizer.from_pretrained(load_path, "tokenizer")
     if kind == "SD":
         enc = load_text_encoder(os.path.join(load_path, "text_encoder"), device)

@@ -47,6 +47,10 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
 }
+// "low part" of a value whose high part is its bf16 rounding: v ~= bf16(v) + bf16(v - bf16(v)) to 2^-17 relative.  The precise mode
+// of the VAE engine (vae.hip) multiplies such pairs with three bf16 MFMA passes (hi*hi + lo*hi + hi*lo, fp32 accumulation).
+__device__ __forceinline__ float bf16_residual(float v) { return v - bf16_to_f32(f32_to_bf16(v)); }
+__device__ __forceinline__ uint32_t pack_bf16x2_lo(float a, float b) { return pack_bf16x2(bf16_residual(a), bf16_residual(b)); }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
@@ -142,6 +146,8 @@ struct GroupNormArgs {
     int silu;
     bf16_t* out;                       // [B, HW, C1+C2] normalised (+SiLU)
     bf16_t* raw_out;                   // optional: un-normalised bf16 copy of the (concatenated) input
+    bf16_t* out_lo;                    // optional low parts of out / raw_out (precise VAE mode: operand = hi + lo)
+    bf16_t* raw_lo;
     float* partial;                    // workspace [B, nchunk, G, 2]
     int nchunk, rows_per_chunk;        // from groupnorm_nchunk / groupnorm_rows_per_chunk
     int fuse_finalize;                 // 1 (UNet forward, nchunk <= 128): every block of the apply kernel reduces the per-chunk partials
@@ -156,7 +162,7 @@ int groupnorm_nchunk(int HW);
 void launch_layernorm(const void* x, int x_f16 /* 0: fp32 rows, 1: fp16 rows (UNet trunk) */, const float* gamma, const float* beta,
                       bf16_t* out, int rows, int C, float eps, hipStream_t st);
 void launch_cast_f16_bf16(const f16_t* x, bf16_t* out, size_t n, hipStream_t st);
-void launch_cast_f32_bf16(const float* x, bf16_t* out, size_t n, hipStream_t st);
+void launch_cast_f32_bf16(const float* x, bf16_t* out, size_t n, hipStream_t st, bf16_t* out_lo = nullptr);
 // out[b][n] (+)= sum_k act(a[b][k]) * W[n][k] + bias[n];  B <= 8
 void launch_small_linear(const float* a, int lda, const bf16_t* W, int ldw, const float* bias, float* out, int ldo,
                          int B, int N, int K, int silu_in, int accumulate, hipStream_t st);
@@ -188,6 +194,7 @@ struct PackArgs {
     long s_r, s_co, s_ci;
     float scale;
     long s_base;                      // constant source offset (flipped conv taps for the backward-data weights)
+    int lo_part;                      // 1: store the low part bf16(v - bf16(v)) instead of bf16(v) (precise VAE mode)
 };
 void launch_pack(const PackArgs& a, hipStream_t st);
 
@@ -206,6 +213,8 @@ void launch_prep_latents(const PrepArgs& a, hipStream_t st);
 struct GroupNormBwdArgs {
     const void* x; int x_bf16;         // forward input [B, HW, C]
     const bf16_t* dA;                  // gradient wrt the (activated) output [B, HW, C]
+    const bf16_t* dA_lo;               // optional low part of dA (precise mode)
+    bf16_t* out_bf16_lo;               // optional low part of out_bf16
     const float* fwd_partial;          // forward statistics partials [B, nchunk, G, 2]
     float* bwd_partial;                // workspace [B, nchunk, G, 2]
     const float* gamma; const float* beta; float eps;
@@ -217,14 +226,15 @@ struct GroupNormBwdArgs {
 void launch_groupnorm_bwd(const GroupNormBwdArgs& a, hipStream_t st);
 void launch_gn_finalize(float* partial, int B, int nchunk, int G, double n, float eps, int mode, hipStream_t st);
 void launch_transpose_bf16(const bf16_t* in, bf16_t* out, int R, int C, hipStream_t st);        // [R,C] -> [C,R]
-void launch_softmax_rows(const float* s, bf16_t* p, int rows, int cols, float scale, hipStream_t st);
+void launch_softmax_rows(const float* s, bf16_t* p, int rows, int cols, float scale, hipStream_t st, bf16_t* p_lo = nullptr);
 // dS = scale * P o (dP - rowsum(dP o P))   (bf16 out)
-void launch_softmax_bwd(const bf16_t* p, const float* dp, bf16_t* ds, int rows, int cols, float scale, hipStream_t st);
+void launch_softmax_bwd(const bf16_t* p, const float* dp, bf16_t* ds, int rows, int cols, float scale, hipStream_t st, const bf16_t* p_lo = nullptr,
+                        bf16_t* ds_lo = nullptr);
 void launch_sumpool2x2(const float* in, float* out, int B, int H, int W, int C, hipStream_t st);   // [B,2H,2W,C] -> [B,H,W,C]
 void launch_add_f32(const float* a, const float* b, float* out, size_t n, hipStream_t st);
 // per pixel: out[pix][0..7] = bf16(W[4x4] * (in[c][pix] * scale) + b), channels 4..7 zero  (post_quant_conv 1x1)
 void launch_pq_conv_fwd(const float* lat_nchw, const float* eps_nchw, float c_lat, float c_eps, const float* W, const float* b,
-                        bf16_t* out, int HW, hipStream_t st);
+                        bf16_t* out, int HW, hipStream_t st, bf16_t* out_lo = nullptr);
 // dlat[c][pix] = sum_o W[o][c] * dz[pix][o] * gscale ;  lat -= dlat * weight * mask_all
 void launch_pq_conv_bwd_update(const float* dz, int ldz, const float* W, float gscale, float weight, const float* mask_all,
                                float* lat_nchw, float* grad_out /* optional [4,HW] */, int HW, hipStream_t st);
@@ -236,6 +246,7 @@ struct ColorLossArgs {
     float* partial;                    // [nblk, n, 4] workspace
     int nblk;
     bf16_t* dimg;                      // [HWi, 8] bf16 gradient wrt the decoder output
+    bf16_t* dimg_lo;                   // optional low part (precise mode)
     float* loss_out;                   // [1] optional
 };
 void launch_color_loss_grad(const ColorLossArgs& a, hipStream_t st);

@@ -2,18 +2,19 @@
 #include "common.h"
 #include <hip/hip_fp16.h>
 
-__global__ void cast_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, size_t n4) {
+__global__ void cast_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, bf16_t* __restrict__ out_lo, size_t n4) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         const float4 v = ((const float4*)x)[i];
         uint2 o; o.x = pack_bf16x2(v.x, v.y); o.y = pack_bf16x2(v.z, v.w);
         ((uint2*)out)[i] = o;
+        if (out_lo) { uint2 l; l.x = pack_bf16x2_lo(v.x, v.y); l.y = pack_bf16x2_lo(v.z, v.w); ((uint2*)out_lo)[i] = l; }
     }
 }
-void launch_cast_f32_bf16(const float* x, bf16_t* out, size_t n, hipStream_t st) {
+void launch_cast_f32_bf16(const float* x, bf16_t* out, size_t n, hipStream_t st, bf16_t* out_lo) {
     RT_REQUIRE(n % 4 == 0, "cast: n must be a multiple of 4");
     const size_t n4 = n / 4;
     int grid = (int)((n4 + 255) / 256); if (grid > 2048) grid = 2048; if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(cast_kernel, dim3(grid), dim3(256), 0, st, x, out, n4);
+    hipLaunchKernelGGL(cast_kernel, dim3(grid), dim3(256), 0, st, x, out, out_lo, n4);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -59,7 +60,7 @@ __global__ void pack_kernel(PackArgs p) {
             v *= p.scale;
         }
         if (p.dst_f32) ((float*)p.dst)[(size_t)r * p.ld_dst + c] = v;
-        else ((bf16_t*)p.dst)[(size_t)r * p.ld_dst + c] = f32_to_bf16(v);
+        else ((bf16_t*)p.dst)[(size_t)r * p.ld_dst + c] = f32_to_bf16(p.lo_part ? bf16_residual(v) : v);
     }
 }
 void launch_pack(const PackArgs& a, hipStream_t st) {

@@ -158,6 +158,14 @@ __device__ __forceinline__ void storev(bf16_t* dst, const float (&y)[VW]) {
         *(uint2*)dst = o;
     }
 }
+// low parts of the same values (precise VAE mode)
+template <int VW>
+__device__ __forceinline__ void storev_lo(bf16_t* dst, const float (&y)[VW]) {
+    float r[VW];
+#pragma unroll
+    for (int e = 0; e < VW; ++e) r[e] = bf16_residual(y[e]);
+    storev<VW>(dst, r);
+}
 template <int BF16IN, int VW>
 __global__ __launch_bounds__(512) void gn_apply_kernel(GroupNormArgs p) {
     __shared__ float mean[32], rstd[32];
@@ -223,6 +231,8 @@ __global__ __launch_bounds__(512) void gn_apply_kernel(GroupNormArgs p) {
                 }
                 storev<VW>(p.out + row * C + c, y);
                 if (p.raw_out) storev<VW>(p.raw_out + row * C + c, v[u]);
+                if (p.out_lo) storev_lo<VW>(p.out_lo + row * C + c, y);
+                if (p.raw_lo) storev_lo<VW>(p.raw_lo + row * C + c, v[u]);
             }
         }
     }

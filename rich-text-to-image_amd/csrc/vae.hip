@@ -7,7 +7,14 @@
 // incl. its torch-autograd gradient).  Only d(loss)/d(latents) is needed: no weight gradients, and the UNet is not
 // differentiated (noise_pred is a constant in predict_x0).
 // All contractions (3x3 convs, their backward-data = 3x3 conv with flipped/transposed weights, linears, attention
-// score/PV GEMMs and their adjoints) run on the MFMA GEMM of gemm.hip with bf16 operands and fp32 accumulation.
+// score/PV GEMMs and their adjoints) run on the MFMA GEMMs of gemm16.hip / gemm.hip with bf16 operands and fp32 accumulation.
+//
+// PRECISE mode (rt_vae_config.precise, round 3): the SDXL pipeline of the reference decodes this VAE in fp32
+// (models/region_diffusion_sdxl.py:856 `.to(dtype=torch.float32)`).  gfx950 has no fast fp32 matrix path (the f32-input MFMA runs
+// at 1/16 of the bf16 rate), so fp32-class products are built from bf16 MFMAs: every operand is kept as a PAIR
+// (hi = bf16(v), lo = bf16(v - hi), together 16 mantissa bits) and every contraction is three passes, hi*hi + lo*hi + hi*lo,
+// accumulated in fp32 in the same output (the lo*lo term is 2^-18 relative and dropped).  Everything between contractions
+// (GroupNorm, SiLU, softmax, residual adds, the loss) already runs in fp32.  Three times the MFMA work of the default mode.
 #include "common.h"
 #include "../../include/rtdiff.h"
 #include "vae.h"
@@ -29,15 +36,16 @@ struct Arena2 {
     }
 };
 struct NormW { float* g = nullptr; float* b = nullptr; int C = 0; };
-struct MatW { bf16_t* w = nullptr; float* b = nullptr; int N = 0, K = 0; };
+struct MatW { bf16_t* w = nullptr; bf16_t* w_lo = nullptr; float* b = nullptr; int N = 0, K = 0; };   // w_lo: precise mode only
+struct BT { bf16_t* hi = nullptr; bf16_t* lo = nullptr; };                                                // a bf16 operand (+ its low part)
 struct VConv { MatW f, b; int cin = 0, cout = 0, cinP = 0, coutP = 0; };
 struct VLin { MatW f, b; };
 struct VRes { std::string name; NormW n1, n2; VConv c1, c2; bool has_sc = false; VLin sc; int cin = 0, cout = 0; };
 struct VAttn { NormW gn; VLin q, k, v, o; int C = 0; };
 struct Slot { std::string name; std::vector<int64_t> shape; std::vector<PackArgs> packs; bool bound = false; };
 
-struct ResSaved { const float* x; float* part1; bf16_t* h2; float* part2; int H, W; };
-struct AttnSaved { const float* x; float* part; bf16_t *q, *k, *v, *P; int N; };
+struct ResSaved { const float* x; float* part1; const void* h2; bool h2_bf16; float* part2; int H, W; };
+struct AttnSaved { const float* x; float* part; BT q, k, v, P; int N; };
 }  // namespace
 
 struct rt_vae {
@@ -49,6 +57,7 @@ struct rt_vae {
     char* arena_base = nullptr; size_t arena_bytes = 0;
     char* ws_base = nullptr; size_t ws_cap = 0, ws_off = 0, ws_peak = 0;
     bool dry = false;
+    bool precise = false;
     bf16_t* zero = nullptr;
     std::vector<Slot> slots;
     std::map<std::string, int> slot_index;
@@ -73,6 +82,7 @@ struct rt_vae {
     }
     float* f32(size_t n) { return (float*)walloc(n * 4); }
     bf16_t* b16(size_t n) { return (bf16_t*)walloc(n * 2); }
+    BT bt(size_t n) { BT t; t.hi = b16(n); t.lo = precise ? b16(n) : nullptr; return t; }
 
     // ---------------------------------------------------------------- plan
     void add_slot(const std::string& name, std::vector<int64_t> shape, std::vector<PackArgs> packs) {
@@ -99,7 +109,13 @@ struct rt_vae {
         pf.ci_valid = Cin; pf.s_r = (long)Cin * 9; pf.s_co = 1; pf.s_ci = 9; pf.scale = 1.f;
         PackArgs pb{}; pb.dst = c.b.w; pb.rows = Cin; pb.cols = c.b.K; pb.ld_dst = c.b.K; pb.row_map = PACK_ROWS_ID; pb.c_inner = c.coutP;
         pb.ci_valid = Cout; pb.s_r = 9; pb.s_co = -1; pb.s_ci = (long)Cin * 9; pb.s_base = 8; pb.scale = 1.f;
-        add_slot(n + ".weight", {Cout, Cin, 3, 3}, {pf, pb});
+        std::vector<PackArgs> packs{pf, pb};
+        if (precise) {
+            c.f.w_lo = (bf16_t*)arena.alloc((size_t)CoutN * c.f.K * 2); c.b.w_lo = (bf16_t*)arena.alloc((size_t)CinN * c.b.K * 2);
+            PackArgs lf = pf; lf.dst = c.f.w_lo; lf.lo_part = 1; PackArgs lb = pb; lb.dst = c.b.w_lo; lb.lo_part = 1;
+            packs.push_back(lf); packs.push_back(lb);
+        }
+        add_slot(n + ".weight", {Cout, Cin, 3, 3}, packs);
         add_slot(n + ".bias", {Cout}, {pk_vec(c.f.b, Cout)});
         return c;
     }
@@ -112,7 +128,13 @@ struct rt_vae {
         PackArgs pb{}; pb.dst = l.b.w; pb.rows = K; pb.cols = N; pb.ld_dst = N; pb.row_map = PACK_ROWS_ID; pb.c_inner = N; pb.ci_valid = N;
         pb.s_r = 1; pb.s_ci = K; pb.scale = 1.f;
         std::vector<int64_t> shp = conv1x1 ? std::vector<int64_t>{N, K, 1, 1} : std::vector<int64_t>{N, K};
-        add_slot(n + ".weight", shp, {pf, pb});
+        std::vector<PackArgs> packs{pf, pb};
+        if (precise) {
+            l.f.w_lo = (bf16_t*)arena.alloc((size_t)N * K * 2); l.b.w_lo = (bf16_t*)arena.alloc((size_t)N * K * 2);
+            PackArgs lf = pf; lf.dst = l.f.w_lo; lf.lo_part = 1; PackArgs lb = pb; lb.dst = l.b.w_lo; lb.lo_part = 1;
+            packs.push_back(lf); packs.push_back(lb);
+        }
+        add_slot(n + ".weight", shp, packs);
         if (bias) { l.f.b = (float*)arena.alloc((size_t)N * 4); add_slot(n + ".bias", {N}, {pk_vec(l.f.b, N)}); }
         return l;
     }
@@ -128,6 +150,7 @@ struct rt_vae {
     void build_plan() {
         slots.clear(); slot_index.clear(); up_res.clear(); up_conv.clear();
         G = cfg.norm_groups;
+        precise = cfg.precise != 0;
         const int n = cfg.n_blocks;
         zero = (bf16_t*)arena.alloc(256);
         pq_w = (float*)arena.alloc(16 * 4); pq_b = (float*)arena.alloc(4 * 4);
@@ -158,128 +181,177 @@ struct rt_vae {
     void require_bound() { for (auto& s : slots) if (!s.bound) throw rt_error(RT_E_MISSING_WEIGHT, "vae weight not bound: " + s.name); }
 
     // ---------------------------------------------------------------- launch helpers
-    void gemm(const bf16_t* A, int lda, const MatW& W, int M, void* out, int ldo, int epi, const float* res = nullptr, int ldres = 0, bool bias = true) {
-        if (dry) return;
-        GemmArgs g{}; g.A = A; g.W = W.w; g.bias = bias ? W.b : nullptr; g.out = out; g.res = res; g.zero = zero; g.mode = A_DENSE; g.epi = epi;
-        g.M = M; g.N = W.N; g.K = W.K; g.lda = lda; g.ldw = W.K; g.ldo = ldo; g.ldres = ldres;
+    void gemm1(const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias, int M, int N, int K, void* out, int ldo, int epi,
+               const float* res, int ldres) {
+        GemmArgs g{}; g.A = A; g.W = W; g.bias = bias; g.out = out; g.res = res; g.zero = zero; g.mode = A_DENSE; g.epi = epi;
+        g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldo = ldo; g.ldres = ldres;
         launch_gemm(g, stream);
     }
-    // raw operands (attention score / PV GEMMs)
-    void gemm_raw(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, int N, int K, void* out, int ldo, int epi) {
-        if (dry) return;
-        GemmArgs g{}; g.A = A; g.W = W; g.out = out; g.zero = zero; g.mode = A_DENSE; g.epi = epi; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldo = ldo;
-        launch_gemm(g, stream);
-    }
-    void conv3(const bf16_t* in, int mode, const MatW& W, int H, int Wd, int CinP, void* out, int epi, const float* res = nullptr, bool bias = true) {
-        if (dry) return;
+    void conv1(const bf16_t* in, int mode, const bf16_t* W, const float* bias, int N, int K, int H, int Wd, int CinP, void* out, int epi, const float* res) {
         int Ho = H, Wo = Wd;
         if (mode == A_CONV3_UP2) { Ho = 2 * H; Wo = 2 * Wd; }
-        GemmArgs g{}; g.A = in; g.W = W.w; g.bias = bias ? W.b : nullptr; g.out = out; g.res = res; g.zero = zero; g.mode = mode; g.epi = epi;
-        g.M = Ho * Wo; g.N = W.N; g.K = W.K; g.ldw = W.K; g.ldo = W.N; g.ldres = W.N; g.rows_per_batch = Ho * Wo; g.Hin = H; g.Win = Wd; g.Cin = CinP;
+        GemmArgs g{}; g.A = in; g.W = W; g.bias = bias; g.out = out; g.res = res; g.zero = zero; g.mode = mode; g.epi = epi;
+        g.M = Ho * Wo; g.N = N; g.K = K; g.ldw = K; g.ldo = N; g.ldres = N; g.rows_per_batch = Ho * Wo; g.Hin = H; g.Win = Wd; g.Cin = CinP;
         g.Hout = Ho; g.Wout = Wo;
-        RT_REQUIRE(W.K == 9 * CinP, "vae conv: weight/input channel mismatch");
+        RT_REQUIRE(K == 9 * CinP, "vae conv: weight/input channel mismatch");
         launch_gemm(g, stream);
     }
-    float* gn_fwd(const void* x, bool x_bf16, int C, int HW, const NormW& n, bool silu, bf16_t* out, bf16_t* raw) {
+    void split(const float* x, BT o, size_t n) { if (!dry) launch_cast_f32_bf16(x, o.hi, n, stream, o.lo); }
+    BT castb(const float* x, size_t n) { BT o = bt(n); split(x, o, n); return o; }
+    // fp32 temporaries of the precise mode live only until they are split into a pair: the bump pointer goes back on scope exit
+    // (everything is ordered on one stream, so the next user of the bytes runs after the split)
+    struct Scratch { rt_vae* v; size_t mark; explicit Scratch(rt_vae* v_) : v(v_), mark(v_->ws_off) {} ~Scratch() { v->ws_off = mark; } };
+    // ---- dense  out(fp32) = A W^T (+bias) (+res): one pass, or hi*hi + lo*hi + hi*lo accumulated in place (precise)
+    void gemm_f32(BT A, int lda, const MatW& W, int M, float* out, int ldo, const float* res = nullptr, int ldres = 0, bool bias = true) {
+        if (dry) return;
+        gemm1(A.hi, lda, W.w, W.K, bias ? W.b : nullptr, M, W.N, W.K, out, ldo, EPI_F32, res, ldres);
+        if (precise) {
+            gemm1(A.lo, lda, W.w, W.K, nullptr, M, W.N, W.K, out, ldo, EPI_F32, out, ldo);
+            gemm1(A.hi, lda, W.w_lo, W.K, nullptr, M, W.N, W.K, out, ldo, EPI_F32, out, ldo);
+        }
+    }
+    // ---- dense with a bf16 operand as the result (precise: fp32 result, then split into the pair)
+    BT gemm_b(BT A, int lda, const MatW& W, int M, bool bias = true) {
+        const size_t n = (size_t)M * W.N;
+        if (precise) { BT o = bt(n); Scratch sc(this); float* t = f32(n); gemm_f32(A, lda, W, M, t, W.N, nullptr, 0, bias); split(t, o, n); return o; }
+        BT o = bt(n);
+        if (!dry) gemm1(A.hi, lda, W.w, W.K, bias ? W.b : nullptr, M, W.N, W.K, o.hi, W.N, EPI_BF16, nullptr, 0);
+        return o;
+    }
+    // ---- raw operands (attention score / PV products): both sides are pairs
+    void raw_f32(BT A, int lda, BT W, int ldw, int M, int N, int K, float* out, int ldo) {
+        if (dry) return;
+        gemm1(A.hi, lda, W.hi, ldw, nullptr, M, N, K, out, ldo, EPI_F32, nullptr, 0);
+        if (precise) {
+            gemm1(A.lo, lda, W.hi, ldw, nullptr, M, N, K, out, ldo, EPI_F32, out, ldo);
+            gemm1(A.hi, lda, W.lo, ldw, nullptr, M, N, K, out, ldo, EPI_F32, out, ldo);
+        }
+    }
+    BT raw_b(BT A, int lda, BT W, int ldw, int M, int N, int K) {
+        const size_t n = (size_t)M * N;
+        if (precise) { BT o = bt(n); Scratch sc(this); float* t = f32(n); raw_f32(A, lda, W, ldw, M, N, K, t, N); split(t, o, n); return o; }
+        BT o = bt(n);
+        if (!dry) gemm1(A.hi, lda, W.hi, ldw, nullptr, M, N, K, o.hi, N, EPI_BF16, nullptr, 0);
+        return o;
+    }
+    // ---- 3x3 convolutions
+    void conv_f32(BT in, int mode, const MatW& W, int H, int Wd, int CinP, float* out, const float* res = nullptr, bool bias = true) {
+        if (dry) return;
+        conv1(in.hi, mode, W.w, bias ? W.b : nullptr, W.N, W.K, H, Wd, CinP, out, EPI_F32, res);
+        if (precise) {
+            conv1(in.lo, mode, W.w, nullptr, W.N, W.K, H, Wd, CinP, out, EPI_F32, out);
+            conv1(in.hi, mode, W.w_lo, nullptr, W.N, W.K, H, Wd, CinP, out, EPI_F32, out);
+        }
+    }
+    BT conv_b(BT in, int mode, const MatW& W, int H, int Wd, int CinP, bool bias = true) {
+        const size_t n = (size_t)H * Wd * W.N;                     // (only stride-1 same-size convolutions produce operands)
+        if (precise) { BT o = bt(n); Scratch sc(this); float* t = f32(n); conv_f32(in, mode, W, H, Wd, CinP, t, nullptr, bias); split(t, o, n); return o; }
+        BT o = bt(n);
+        if (!dry) conv1(in.hi, mode, W.w, bias ? W.b : nullptr, W.N, W.K, H, Wd, CinP, o.hi, EPI_BF16, nullptr);
+        return o;
+    }
+    float* gn_fwd(const void* x, bool x_bf16, int C, int HW, const NormW& n, bool silu, BT out, BT raw) {
         const int nchunk = groupnorm_nchunk(HW);
         float* part = f32((size_t)nchunk * G * 2);
         if (dry) return part;
         GroupNormArgs a{}; a.x1 = x; a.in_bf16 = x_bf16; a.C1 = C; a.C2 = 0; a.G = G; a.B = 1; a.HW = HW; a.gamma = n.g; a.beta = n.b; a.eps = 1e-6f;
-        a.silu = silu; a.out = out; a.raw_out = raw; a.partial = part; a.nchunk = nchunk; a.rows_per_chunk = groupnorm_rows_per_chunk(HW);
+        a.silu = silu; a.out = out.hi; a.out_lo = out.lo; a.raw_out = raw.hi; a.raw_lo = raw.lo; a.partial = part; a.nchunk = nchunk;
+        a.rows_per_chunk = groupnorm_rows_per_chunk(HW);
         launch_groupnorm(a, stream);
         return part;
     }
-    void gn_bwd(const void* x, bool x_bf16, const bf16_t* dA, const float* fwd_part, int C, int HW, const NormW& n, bool silu, const float* add,
-                float* out, bf16_t* out_b) {
+    void gn_bwd(const void* x, bool x_bf16, BT dA, const float* fwd_part, int C, int HW, const NormW& n, bool silu, const float* add,
+                float* out, BT out_b) {
         const int nchunk = groupnorm_nchunk(HW);
         float* bp = f32((size_t)nchunk * G * 2);
         if (dry) return;
-        GroupNormBwdArgs a{}; a.x = x; a.x_bf16 = x_bf16; a.dA = dA; a.fwd_partial = fwd_part; a.bwd_partial = bp; a.gamma = n.g; a.beta = n.b; a.eps = 1e-6f;
-        a.silu = silu; a.C = C; a.G = G; a.B = 1; a.HW = HW; a.nchunk = nchunk; a.rows_per_chunk = groupnorm_rows_per_chunk(HW); a.add = add; a.out = out;
-        a.out_bf16 = out_b;
+        GroupNormBwdArgs a{}; a.x = x; a.x_bf16 = x_bf16; a.dA = dA.hi; a.dA_lo = dA.lo; a.fwd_partial = fwd_part; a.bwd_partial = bp; a.gamma = n.g; a.beta = n.b;
+        a.eps = 1e-6f; a.silu = silu; a.C = C; a.G = G; a.B = 1; a.HW = HW; a.nchunk = nchunk; a.rows_per_chunk = groupnorm_rows_per_chunk(HW); a.add = add;
+        a.out = out; a.out_bf16 = out_b.hi; a.out_bf16_lo = out_b.lo;
         launch_groupnorm_bwd(a, stream);
     }
-    bf16_t* cast(const float* x, size_t n) { bf16_t* o = b16(n); if (!dry) launch_cast_f32_bf16(x, o, n, stream); return o; }
+    BT transp(BT in, int R, int C) {
+        BT o = bt((size_t)R * C);
+        if (!dry) { launch_transpose_bf16(in.hi, o.hi, R, C, stream); if (in.lo) launch_transpose_bf16(in.lo, o.lo, R, C, stream); }
+        return o;
+    }
 
     // ---------------------------------------------------------------- blocks
     float* res_fwd(const VRes& r, const float* x, int H, int W, ResSaved* sv) {
         const size_t HW = (size_t)H * W;
-        bf16_t* h1 = b16(HW * r.cin);
-        bf16_t* raw = r.has_sc ? b16(HW * r.cin) : nullptr;
+        BT h1 = bt(HW * r.cin);
+        BT raw = r.has_sc ? bt(HW * r.cin) : BT{};
         float* p1 = gn_fwd(x, false, r.cin, (int)HW, r.n1, true, h1, raw);
-        bf16_t* h2 = b16(HW * r.cout);
-        conv3(h1, A_CONV3, r.c1.f, H, W, r.cin, h2, EPI_BF16);
-        bf16_t* h3 = b16(HW * r.cout);
-        float* p2 = gn_fwd(h2, true, r.cout, (int)HW, r.n2, true, h3, nullptr);
+        BT h3 = bt(HW * r.cout);
+        const void* h2; float* p2;
+        if (precise) {              // conv1 output stays fp32: it is the input of a GroupNorm, not of a contraction
+            float* h2f = f32(HW * r.cout);
+            conv_f32(h1, A_CONV3, r.c1.f, H, W, r.cin, h2f);
+            p2 = gn_fwd(h2f, false, r.cout, (int)HW, r.n2, true, h3, BT{});
+            h2 = h2f;
+        } else {
+            BT h2b = conv_b(h1, A_CONV3, r.c1.f, H, W, r.cin);
+            p2 = gn_fwd(h2b.hi, true, r.cout, (int)HW, r.n2, true, h3, BT{});
+            h2 = h2b.hi;
+        }
         float* out = f32(HW * r.cout);
         const float* resid = x;
-        if (r.has_sc) { gemm(raw, r.cin, r.sc.f, (int)HW, out, r.cout, EPI_F32); resid = out; }
-        conv3(h3, A_CONV3, r.c2.f, H, W, r.cout, out, EPI_F32, resid);
-        if (sv) { sv->x = x; sv->part1 = p1; sv->h2 = h2; sv->part2 = p2; sv->H = H; sv->W = W; }
+        if (r.has_sc) { gemm_f32(raw, r.cin, r.sc.f, (int)HW, out, r.cout); resid = out; }
+        conv_f32(h3, A_CONV3, r.c2.f, H, W, r.cout, out, resid);
+        if (sv) { sv->x = x; sv->part1 = p1; sv->h2 = h2; sv->h2_bf16 = !precise; sv->part2 = p2; sv->H = H; sv->W = W; }
         return out;
     }
     float* res_bwd(const VRes& r, const ResSaved& sv, const float* dOut) {
         const int H = sv.H, W = sv.W; const size_t HW = (size_t)H * W;
-        bf16_t* dOb = cast(dOut, HW * r.cout);
-        bf16_t* dH3 = b16(HW * r.cout);
-        conv3(dOb, A_CONV3, r.c2.b, H, W, r.cout, dH3, EPI_BF16, nullptr, false);
-        bf16_t* dH2 = b16(HW * r.cout);
-        gn_bwd(sv.h2, true, dH3, sv.part2, r.cout, (int)HW, r.n2, true, nullptr, nullptr, dH2);
-        bf16_t* dH1 = b16(HW * r.cin);
-        conv3(dH2, A_CONV3, r.c1.b, H, W, r.cout, dH1, EPI_BF16, nullptr, false);
+        BT dOb = castb(dOut, HW * r.cout);
+        BT dH3 = conv_b(dOb, A_CONV3, r.c2.b, H, W, r.cout, false);
+        BT dH2 = bt(HW * r.cout);
+        gn_bwd(sv.h2, sv.h2_bf16, dH3, sv.part2, r.cout, (int)HW, r.n2, true, nullptr, nullptr, dH2);
+        BT dH1 = conv_b(dH2, A_CONV3, r.c1.b, H, W, r.cout, false);
         const float* skip = dOut;
-        if (r.has_sc) { float* s = f32(HW * r.cin); gemm(dOb, r.cout, r.sc.b, (int)HW, s, r.cin, EPI_F32, nullptr, 0, false); skip = s; }
+        if (r.has_sc) { float* s = f32(HW * r.cin); gemm_f32(dOb, r.cout, r.sc.b, (int)HW, s, r.cin, nullptr, 0, false); skip = s; }
         float* dX = f32(HW * r.cin);
-        gn_bwd(sv.x, false, dH1, sv.part1, r.cin, (int)HW, r.n1, true, skip, dX, nullptr);
+        gn_bwd(sv.x, false, dH1, sv.part1, r.cin, (int)HW, r.n1, true, skip, dX, BT{});
         return dX;
     }
     float* attn_fwd(const float* x, int N, AttnSaved* sv) {
         const int C = attn.C;
-        bf16_t* g = b16((size_t)N * C);
-        float* part = gn_fwd(x, false, C, N, attn.gn, false, g, nullptr);
-        bf16_t* q = b16((size_t)N * C); bf16_t* k = b16((size_t)N * C); bf16_t* v = b16((size_t)N * C);
-        gemm(g, C, attn.q.f, N, q, C, EPI_BF16); gemm(g, C, attn.k.f, N, k, C, EPI_BF16); gemm(g, C, attn.v.f, N, v, C, EPI_BF16);
-        bf16_t* vT = b16((size_t)N * C);
-        if (!dry) launch_transpose_bf16(v, vT, N, C, stream);
+        BT g = bt((size_t)N * C);
+        float* part = gn_fwd(x, false, C, N, attn.gn, false, g, BT{});
+        BT q = gemm_b(g, C, attn.q.f, N), k = gemm_b(g, C, attn.k.f, N), v = gemm_b(g, C, attn.v.f, N);
+        BT vT = transp(v, N, C);
         float* S = f32((size_t)N * N);
-        gemm_raw(q, C, k, C, N, N, C, S, N, EPI_F32);
-        bf16_t* P = b16((size_t)N * N);
-        if (!dry) launch_softmax_rows(S, P, N, N, 1.f / std::sqrt((float)C), stream);
-        bf16_t* O = b16((size_t)N * C);
-        gemm_raw(P, N, vT, N, N, C, N, O, C, EPI_BF16);
+        raw_f32(q, C, k, C, N, N, C, S, N);
+        BT P = bt((size_t)N * N);
+        if (!dry) launch_softmax_rows(S, P.hi, N, N, 1.f / std::sqrt((float)C), stream, P.lo);
+        BT O = raw_b(P, N, vT, N, N, C, N);
         float* out = f32((size_t)N * C);
-        gemm(O, C, attn.o.f, N, out, C, EPI_F32, x, C);
+        gemm_f32(O, C, attn.o.f, N, out, C, x, C);
         if (sv) { sv->x = x; sv->part = part; sv->q = q; sv->k = k; sv->v = v; sv->P = P; sv->N = N; }
         return out;
     }
     float* attn_bwd(const AttnSaved& sv, const float* dOut) {
         const int C = attn.C, N = sv.N;
-        bf16_t* dOb = cast(dOut, (size_t)N * C);
-        bf16_t* dO = b16((size_t)N * C);
-        gemm(dOb, C, attn.o.b, N, dO, C, EPI_BF16, nullptr, 0, false);
+        BT dOb = castb(dOut, (size_t)N * C);
+        BT dO = gemm_b(dOb, C, attn.o.b, N, false);
         // dV = P^T dO
-        bf16_t* PT = b16((size_t)N * N); bf16_t* dOT = b16((size_t)N * C);
-        if (!dry) { launch_transpose_bf16(sv.P, PT, N, N, stream); launch_transpose_bf16(dO, dOT, N, C, stream); }
-        bf16_t* dV = b16((size_t)N * C);
-        gemm_raw(PT, N, dOT, N, N, C, N, dV, C, EPI_BF16);
+        BT PT = transp(sv.P, N, N), dOT = transp(dO, N, C);
+        BT dV = raw_b(PT, N, dOT, N, N, C, N);
         // dP = dO V^T ; dS = scale * P o (dP - rowsum(dP o P))
         float* dP = f32((size_t)N * N);
-        gemm_raw(dO, C, sv.v, C, N, N, C, dP, N, EPI_F32);
-        bf16_t* dS = PT;                                          // P^T is dead: reuse
-        if (!dry) launch_softmax_bwd(sv.P, dP, dS, N, N, 1.f / std::sqrt((float)C), stream);
+        raw_f32(dO, C, sv.v, C, N, N, C, dP, N);
+        BT dS = PT;                                               // P^T is dead: reuse
+        if (!dry) launch_softmax_bwd(sv.P.hi, dP, dS.hi, N, N, 1.f / std::sqrt((float)C), stream, sv.P.lo, dS.lo);
         // dQ = dS K ; dK = dS^T Q
-        bf16_t* kT = b16((size_t)N * C); bf16_t* qT = b16((size_t)N * C); bf16_t* dST = b16((size_t)N * N);
-        if (!dry) { launch_transpose_bf16(sv.k, kT, N, C, stream); launch_transpose_bf16(sv.q, qT, N, C, stream); launch_transpose_bf16(dS, dST, N, N, stream); }
-        bf16_t* dQ = b16((size_t)N * C); bf16_t* dK = b16((size_t)N * C);
-        gemm_raw(dS, N, kT, N, N, C, N, dQ, C, EPI_BF16);
-        gemm_raw(dST, N, qT, N, N, C, N, dK, C, EPI_BF16);
+        BT kT = transp(sv.k, N, C), qT = transp(sv.q, N, C), dST = transp(dS, N, N);
+        BT dQ = raw_b(dS, N, kT, N, N, C, N), dK = raw_b(dST, N, qT, N, N, C, N);
         float* dg = f32((size_t)N * C);
-        gemm(dQ, C, attn.q.b, N, dg, C, EPI_F32, nullptr, 0, false);
-        gemm(dK, C, attn.k.b, N, dg, C, EPI_F32, dg, C, false);
-        gemm(dV, C, attn.v.b, N, dg, C, EPI_F32, dg, C, false);
-        bf16_t* dgb = cast(dg, (size_t)N * C);
+        gemm_f32(dQ, C, attn.q.b, N, dg, C, nullptr, 0, false);
+        gemm_f32(dK, C, attn.k.b, N, dg, C, dg, C, false);
+        gemm_f32(dV, C, attn.v.b, N, dg, C, dg, C, false);
+        BT dgb = castb(dg, (size_t)N * C);
         float* dX = f32((size_t)N * C);
-        gn_bwd(sv.x, false, dgb, sv.part, C, N, attn.gn, false, dOut, dX, nullptr);
+        gn_bwd(sv.x, false, dgb, sv.part, C, N, attn.gn, false, dOut, dX, BT{});
         return dX;
     }
 
@@ -288,10 +360,10 @@ struct rt_vae {
     float* forward(const float* lat, const float* eps, float c_lat, float c_eps, int h, int w, Tape* tp) {
         RT_REQUIRE(h <= cfg.latent_h && w <= cfg.latent_w, "vae: latent larger than configured");
         const size_t hw = (size_t)h * w;
-        bf16_t* z8 = b16(hw * 8);
-        if (!dry) launch_pq_conv_fwd(lat, eps, c_lat, c_eps, pq_w, pq_b, z8, (int)hw, stream);
+        BT z8 = bt(hw * 8);
+        if (!dry) launch_pq_conv_fwd(lat, eps, c_lat, c_eps, pq_w, pq_b, z8.hi, (int)hw, stream, z8.lo);
         float* x = f32(hw * conv_in.f.N);
-        conv3(z8, A_CONV3, conv_in.f, h, w, 8, x, EPI_F32);
+        conv_f32(z8, A_CONV3, conv_in.f, h, w, 8, x);
         ResSaved rs; AttnSaved as;
         x = res_fwd(mid0, x, h, w, &rs); if (tp) tp->res.push_back(rs);
         x = attn_fwd(x, (int)hw, &as); if (tp) tp->attn = as;
@@ -301,36 +373,35 @@ struct rt_vae {
             for (auto& r : up_res[i]) { x = res_fwd(r, x, H, W, &rs); if (tp) tp->res.push_back(rs); }
             if (i + 1 < up_res.size()) {
                 const int C = up_conv[i].cin;
-                bf16_t* xb = cast(x, (size_t)H * W * C);
+                BT xb = castb(x, (size_t)H * W * C);
                 float* y = f32((size_t)4 * H * W * C);
-                conv3(xb, A_CONV3_UP2, up_conv[i].f, H, W, C, y, EPI_F32);
+                conv_f32(xb, A_CONV3_UP2, up_conv[i].f, H, W, C, y);
                 if (tp) tp->up_hw.push_back({H, W});
                 H *= 2; W *= 2; x = y;
             }
         }
         const int C0 = cfg.block_out_channels[0];
-        bf16_t* hn = b16((size_t)H * W * C0);
-        float* part = gn_fwd(x, false, C0, H * W, norm_out, true, hn, nullptr);
+        BT hn = bt((size_t)H * W * C0);
+        float* part = gn_fwd(x, false, C0, H * W, norm_out, true, hn, BT{});
         float* img = f32((size_t)H * W * conv_out.f.N);          // [HWi, 4], channel 3 is padding
-        conv3(hn, A_CONV3, conv_out.f, H, W, C0, img, EPI_F32);
+        conv_f32(hn, A_CONV3, conv_out.f, H, W, C0, img);
         if (tp) { tp->last_x = x; tp->part_out = part; tp->Hi = H; tp->Wi = W; }
         return img;
     }
     // d(loss)/d(z1) where z1 = post_quant_conv output, given dimg (bf16 [HWi, 8])
-    float* backward(const Tape& tp, const bf16_t* dimg, int h, int w) {
+    float* backward(const Tape& tp, BT dimg, int h, int w) {
         int H = tp.Hi, W = tp.Wi;
         const int C0 = cfg.block_out_channels[0];
-        bf16_t* dHn = b16((size_t)H * W * C0);
-        conv3(dimg, A_CONV3, conv_out.b, H, W, 8, dHn, EPI_BF16, nullptr, false);
+        BT dHn = conv_b(dimg, A_CONV3, conv_out.b, H, W, 8, false);
         float* dX = f32((size_t)H * W * C0);
-        gn_bwd(tp.last_x, false, dHn, tp.part_out, C0, H * W, norm_out, true, nullptr, dX, nullptr);
+        gn_bwd(tp.last_x, false, dHn, tp.part_out, C0, H * W, norm_out, true, nullptr, dX, BT{});
         int ri = (int)tp.res.size() - 1;
         for (int i = (int)up_res.size() - 1; i >= 0; --i) {
             if (i + 1 < (int)up_res.size()) {
                 const int C = up_conv[i].cin;
-                bf16_t* dYb = cast(dX, (size_t)H * W * C);
+                BT dYb = castb(dX, (size_t)H * W * C);
                 float* dUp = f32((size_t)H * W * C);
-                conv3(dYb, A_CONV3, up_conv[i].b, H, W, C, dUp, EPI_F32, nullptr, false);
+                conv_f32(dYb, A_CONV3, up_conv[i].b, H, W, C, dUp, nullptr, false);
                 H /= 2; W /= 2;
                 float* d = f32((size_t)H * W * C);
                 if (!dry) launch_sumpool2x2(dUp, d, 1, H, W, C, stream);
@@ -341,9 +412,9 @@ struct rt_vae {
         dX = res_bwd(mid1, tp.res[ri--], dX);
         dX = attn_bwd(tp.attn, dX);
         dX = res_bwd(mid0, tp.res[ri--], dX);
-        bf16_t* dXb = cast(dX, (size_t)h * w * conv_in.cout);
+        BT dXb = castb(dX, (size_t)h * w * conv_in.cout);
         float* dz = f32((size_t)h * w * 4);
-        conv3(dXb, A_CONV3, conv_in.b, h, w, conv_in.coutP, dz, EPI_F32, nullptr, false);
+        conv_f32(dXb, A_CONV3, conv_in.b, h, w, conv_in.coutP, dz, nullptr, false);
         return dz;
     }
 };
@@ -363,8 +434,8 @@ static size_t vae_measure(rt_vae* v) {
     rt_vae::Tape tp;
     float* img = v->forward(nullptr, nullptr, 1.f, 0.f, v->cfg.latent_h, v->cfg.latent_w, &tp);
     (void)img;
-    v->b16((size_t)tp.Hi * tp.Wi * 8); v->f32(4096 * 16 * 4 + 64);
-    v->backward(tp, nullptr, v->cfg.latent_h, v->cfg.latent_w);
+    BT dimg = v->bt((size_t)tp.Hi * tp.Wi * 8); v->f32(4096 * 16 * 4 + 64);
+    v->backward(tp, dimg, v->cfg.latent_h, v->cfg.latent_w);
     v->dry = false;
     const size_t peak = v->ws_peak; v->ws_off = 0;
     return peak + (1 << 20);
@@ -455,9 +526,10 @@ int rt_vae_color_guidance(rt_vae* v, float* latents, const float* noise_pred, fl
         float* tgt = v->f32((size_t)n_regions * 3 + 4);
         HIP_CHECK(hipMemcpyAsync(tgt, target_rgb_host, (size_t)n_regions * 12, hipMemcpyHostToDevice, v->stream));
         ColorLossArgs c{}; c.img = img; c.ldi = v->conv_out.f.N; c.masks = masks_img; c.target = tgt; c.n = n_regions; c.HWi = HWi;
-        c.nblk = 1024; c.partial = v->f32((size_t)c.nblk * n_regions * 4); c.dimg = v->b16((size_t)HWi * 8); c.loss_out = v->f32(4);
+        BT dimg = v->bt((size_t)HWi * 8);
+        c.nblk = 1024; c.partial = v->f32((size_t)c.nblk * n_regions * 4); c.dimg = dimg.hi; c.dimg_lo = dimg.lo; c.loss_out = v->f32(4);
         launch_color_loss_grad(c, v->stream);
-        float* dz = v->backward(tp, c.dimg, h, w);
+        float* dz = v->backward(tp, dimg, h, w);
         launch_pq_conv_bwd_update(dz, 4, v->pq_w, 1.f / (sa * sc), weight, mask_all, latents, grad_out, h * w, v->stream);
         if (loss_out_host) HIP_CHECK(hipMemcpyAsync(loss_out_host, c.loss_out, 4, hipMemcpyDeviceToHost, v->stream));
         HIP_CHECK(hipStreamSynchronize(v->stream));

@@ -30,6 +30,7 @@ __device__ __forceinline__ void dxhat4(const GroupNormBwdArgs& p, size_t off, co
     float x[4], da[4];
     ld4(p.x, p.x_bf16, off, x);
     ld4(p.dA, 1, off, da);
+    if (p.dA_lo) { float dl[4]; ld4(p.dA_lo, 1, off, dl); da[0] += dl[0]; da[1] += dl[1]; da[2] += dl[2]; da[3] += dl[3]; }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         xh[e] = (x[e] - mu[e]) * rs[e];
@@ -108,6 +109,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GroupNormBwdArgs p) {
             if (p.add) { const float4 t = *(const float4*)(p.add + off); o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w; }
             if (p.out) *(float4*)(p.out + off) = make_float4(o[0], o[1], o[2], o[3]);
             if (p.out_bf16) { uint2 w; w.x = pack_bf16x2(o[0], o[1]); w.y = pack_bf16x2(o[2], o[3]); *(uint2*)(p.out_bf16 + off) = w; }
+            if (p.out_bf16_lo) { uint2 w; w.x = pack_bf16x2_lo(o[0], o[1]); w.y = pack_bf16x2_lo(o[2], o[3]); *(uint2*)(p.out_bf16_lo + off) = w; }
         }
     }
 }
@@ -151,7 +153,7 @@ __device__ __forceinline__ float block_reduce(float v, bool is_max, float* sh) {
     for (int i = 1; i < 4; ++i) r = is_max ? fmaxf(r, sh[i]) : r + sh[i];
     return r;
 }
-__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, bf16_t* __restrict__ p, int cols, float scale) {
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, bf16_t* __restrict__ p, bf16_t* __restrict__ p_lo, int cols, float scale) {
     __shared__ float sh[4];
     const float* row = s + (size_t)blockIdx.x * cols;
     float mx = -INFINITY;
@@ -161,23 +163,32 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     for (int c = threadIdx.x; c < cols; c += 256) sum += __expf(row[c] * scale - mx);
     sum = block_reduce(sum, false, sh);
     const float inv = 1.f / sum;
-    for (int c = threadIdx.x; c < cols; c += 256) p[(size_t)blockIdx.x * cols + c] = f32_to_bf16(__expf(row[c] * scale - mx) * inv);
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        const float v = __expf(row[c] * scale - mx) * inv;
+        p[(size_t)blockIdx.x * cols + c] = f32_to_bf16(v);
+        if (p_lo) p_lo[(size_t)blockIdx.x * cols + c] = f32_to_bf16(bf16_residual(v));
+    }
 }
-void launch_softmax_rows(const float* s, bf16_t* p, int rows, int cols, float scale, hipStream_t st) {
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, st, s, p, cols, scale);
+void launch_softmax_rows(const float* s, bf16_t* p, int rows, int cols, float scale, hipStream_t st, bf16_t* p_lo) {
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, st, s, p, p_lo, cols, scale);
     HIP_CHECK(hipGetLastError());
 }
-__global__ __launch_bounds__(256) void softmax_bwd_kernel(const bf16_t* __restrict__ p, const float* __restrict__ dp, bf16_t* __restrict__ ds,
-                                                          int cols, float scale) {
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const bf16_t* __restrict__ p, const bf16_t* __restrict__ p_lo, const float* __restrict__ dp,
+                                                          bf16_t* __restrict__ ds, bf16_t* __restrict__ ds_lo, int cols, float scale) {
     __shared__ float sh[4];
     const size_t base = (size_t)blockIdx.x * cols;
+    auto prob = [&](int c) { return bf16_to_f32(p[base + c]) + (p_lo ? bf16_to_f32(p_lo[base + c]) : 0.f); };
     float dot = 0.f;
-    for (int c = threadIdx.x; c < cols; c += 256) dot += bf16_to_f32(p[base + c]) * dp[base + c];
+    for (int c = threadIdx.x; c < cols; c += 256) dot += prob(c) * dp[base + c];
     dot = block_reduce(dot, false, sh);
-    for (int c = threadIdx.x; c < cols; c += 256) ds[base + c] = f32_to_bf16(scale * bf16_to_f32(p[base + c]) * (dp[base + c] - dot));
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        const float v = scale * prob(c) * (dp[base + c] - dot);
+        ds[base + c] = f32_to_bf16(v);
+        if (ds_lo) ds_lo[base + c] = f32_to_bf16(bf16_residual(v));
+    }
 }
-void launch_softmax_bwd(const bf16_t* p, const float* dp, bf16_t* ds, int rows, int cols, float scale, hipStream_t st) {
-    hipLaunchKernelGGL(softmax_bwd_kernel, dim3(rows), dim3(256), 0, st, p, dp, ds, cols, scale);
+void launch_softmax_bwd(const bf16_t* p, const float* dp, bf16_t* ds, int rows, int cols, float scale, hipStream_t st, const bf16_t* p_lo, bf16_t* ds_lo) {
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3(rows), dim3(256), 0, st, p, p_lo, dp, ds, ds_lo, cols, scale);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -216,7 +227,7 @@ void launch_add_f32(const float* a, const float* b, float* out, size_t n, hipStr
 // ---------------------------------------------------------------- post_quant_conv (1x1, 4 -> 4) fused with predict_x0 / scaling
 // z0 = (c_lat * lat + c_eps * eps)  [= predict_x0(lat, eps) / scaling_factor];  out = W z0 + b
 __global__ void pq_conv_fwd_kernel(const float* lat, const float* eps, float c_lat, float c_eps, const float* W, const float* b,
-                                   bf16_t* out, int HW) {
+                                   bf16_t* out, bf16_t* out_lo, int HW) {
     const int pix = blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= HW) return;
     float z[4], o[4];
@@ -226,10 +237,11 @@ __global__ void pq_conv_fwd_kernel(const float* lat, const float* eps, float c_l
     for (int k = 0; k < 4; ++k) o[k] = b[k] + W[k * 4 + 0] * z[0] + W[k * 4 + 1] * z[1] + W[k * 4 + 2] * z[2] + W[k * 4 + 3] * z[3];
     uint4 q; q.x = pack_bf16x2(o[0], o[1]); q.y = pack_bf16x2(o[2], o[3]); q.z = 0; q.w = 0;
     *(uint4*)(out + (size_t)pix * 8) = q;
+    if (out_lo) { uint4 l; l.x = pack_bf16x2_lo(o[0], o[1]); l.y = pack_bf16x2_lo(o[2], o[3]); l.z = 0; l.w = 0; *(uint4*)(out_lo + (size_t)pix * 8) = l; }
 }
 void launch_pq_conv_fwd(const float* lat, const float* eps, float c_lat, float c_eps, const float* W, const float* b, bf16_t* out, int HW,
-                        hipStream_t st) {
-    hipLaunchKernelGGL(pq_conv_fwd_kernel, dim3(cdiv(HW, 256)), dim3(256), 0, st, lat, eps, c_lat, c_eps, W, b, out, HW);
+                        hipStream_t st, bf16_t* out_lo) {
+    hipLaunchKernelGGL(pq_conv_fwd_kernel, dim3(cdiv(HW, 256)), dim3(256), 0, st, lat, eps, c_lat, c_eps, W, b, out, out_lo, HW);
     HIP_CHECK(hipGetLastError());
 }
 __global__ void pq_conv_bwd_update_kernel(const float* dz, int ldz, const float* W, float gscale, float weight, const float* mask_all,
@@ -308,6 +320,7 @@ __global__ __launch_bounds__(256) void color_grad_kernel(ColorLossArgs p) {
         }
         uint4 q; q.x = pack_bf16x2(g[0], g[1]); q.y = pack_bf16x2(g[2], 0.f); q.z = 0; q.w = 0;
         *(uint4*)(p.dimg + (size_t)pix * 8) = q;
+        if (p.dimg_lo) { uint4 l; l.x = pack_bf16x2_lo(g[0], g[1]); l.y = pack_bf16x2_lo(g[2], 0.f); l.z = 0; l.w = 0; *(uint4*)(p.dimg_lo + (size_t)pix * 8) = l; }
     }
 }
 void launch_color_loss_grad(const ColorLossArgs& a, hipStream_t st) {

@@ -364,14 +364,19 @@ SDXL_VAE_CONFIG = dict(block_out_channels=(128, 256, 512, 512), layers_per_block
 
 class RtVaeConfig(C.Structure):
     _fields_ = [("n_blocks", C.c_int), ("block_out_channels", C.c_int * RT_MAX_LEVELS), ("layers_per_block", C.c_int),
-                ("norm_groups", C.c_int), ("scaling_factor", C.c_float), ("latent_h", C.c_int), ("latent_w", C.c_int)]
+                ("norm_groups", C.c_int), ("scaling_factor", C.c_float), ("latent_h", C.c_int), ("latent_w", C.c_int),
+                ("precise", C.c_int)]
 
 
 class VaeDecoder:
     """AutoencoderKL decoder on the engine: `.decode(z)` (same call surface as diffusers' `vae.decode(z).sample`) and
-    the colour-guidance update of the rich-text loop (rd.py:151-168 / xl.py:849-867)."""
+    the colour-guidance update of the rich-text loop (rd.py:151-168 / xl.py:849-867).
 
-    def __init__(self, cfg, latent_h, latent_w, device=0, state_dict=None):
+    `precise=True` runs every contraction as three bf16 MFMA passes over (hi, lo) operand pairs - fp32-class products - which is
+    what the SDXL pipeline of the reference asks of its VAE (xl.py:856 `.to(dtype=torch.float32)`); the SD pipeline decodes in the
+    checkpoint's dtype (rd.py:160) and keeps the single-pass default."""
+
+    def __init__(self, cfg, latent_h, latent_w, device=0, state_dict=None, precise=False):
         self.lib = load_library()
         c = RtVaeConfig()
         boc = tuple(cfg["block_out_channels"])
@@ -382,6 +387,8 @@ class VaeDecoder:
         c.norm_groups = cfg["norm_num_groups"]
         c.scaling_factor = cfg["scaling_factor"]
         c.latent_h, c.latent_w = latent_h, latent_w
+        c.precise = int(bool(precise))
+        self.precise = bool(precise)
         self.cfg, self.cfg_dict, self.device = c, dict(cfg), device
         self.scaling_factor = cfg["scaling_factor"]
         self.h = C.c_void_p()

@@ -20,6 +20,7 @@ final latents, VAE decode <= 2e-2, guidance gradient <= 5e-2.  Wall time on the 
 """
 import math
 import os
+import time
 
 import pytest
 import torch
@@ -232,18 +233,20 @@ def test_full_width_vae_decode_and_guidance_gradient_match_oracle():
 
 
 def test_sdxl_vae_config5_size_decode_and_guidance_match_oracle():
-    """BASELINE config 5 at its own size: the SDXL VAE (scaling 0.13025, 128-256-512-512) on a 128x128 latent = 1024x1024 image:
-    decode, colour-guidance gradient and latent update (region_diffusion_sdxl.py:849-867; the reference decodes in fp32, :856)
-    against torch autograd through the fp32 oracle decoder on the host (~2 min of CPU work, ~25 GB of autograd state)."""
+    """BASELINE config 5 at its own size AND its own arithmetic: the SDXL VAE (scaling 0.13025, 128-256-512-512) on a 128x128 latent
+    = 1024x1024 image: decode, colour-guidance gradient and latent update (region_diffusion_sdxl.py:849-867) against torch autograd
+    through the fp32 oracle decoder on the host (~2 min of CPU work, ~25 GB of autograd state).  The reference runs this VAE in fp32
+    (:856), so the engine under test is the PRECISE one (three bf16 MFMA passes over hi/lo operand pairs), held to fp32-class
+    tolerances: decode 3e-4, loss 1e-4, gradient and update 1e-3 relative L2.  The single-pass engine (what the SD pipeline uses) is
+    run beside it on the same inputs at the round-2 tolerances, so the two error levels are printed side by side."""
     from oracle.vae import SDXL_VAE_CONFIG, OracleVAEDecoder, color_guidance_update, random_vae_state_dict
     from rich_text_to_image_amd.engine import VaeDecoder
     hw = 128
     sd = random_vae_state_dict(SDXL_VAE_CONFIG, seed=7)
-    v = VaeDecoder(SDXL_VAE_CONFIG, hw, hw, device=0, state_dict=sd)
     o = OracleVAEDecoder(SDXL_VAE_CONFIG, sd)
     g = torch.Generator().manual_seed(3)
     lat, eps = torch.randn(1, 4, hw, hw, generator=g), torch.randn(1, 4, hw, hw, generator=g)
-    # 10 colour spans + the remainder mask, as sample.py hands them over for a 10-segment prompt (n_color + 1 masks, n_color targets)
+    # n_color + 1 masks for n_color targets, as sample.py hands them over (the reference's zip drops the last mask)
     masks = [(torch.rand(1, 1, 8 * hw, 8 * hw, generator=g) ** 2).repeat(1, 4, 1, 1) for _ in range(3)]
     rgb = [torch.rand(1, 3, 1, 1, generator=g) for _ in range(2)]
     mall = torch.rand(1, 4, hw, hw, generator=g)
@@ -254,13 +257,21 @@ def test_sdxl_vae_config5_size_decode_and_guidance_match_oracle():
     with torch.no_grad():
         x0 = (lat - eps * (1 - alpha) ** 0.5) / alpha ** 0.5
         ref = o.decode(x0 / sc)
-    out = v.decode((x0 / sc).to(DEV))
-    r = rel_l2(out, ref)
-    lat_g = lat.clone().to(DEV)
-    loss, grad = v.color_guidance(lat_g, eps.to(DEV), alpha, hw, hw, masks, rgb, wgt, mall, want_grad=True)
-    rg, ru = rel_l2(grad, grad_ref), rel_l2(lat_g.cpu() - lat, new_ref - lat)
-    print(f"SDXL VAE 128x128 -> 1024x1024: decode rel-L2 {r:.3e}; loss {loss:.4f} vs {loss_ref:.4f}; grad rel-L2 {rg:.3e}; update rel-L2 {ru:.3e}")
-    assert r < 2e-2
-    assert abs(loss - loss_ref) < 2e-2 * abs(loss_ref)
-    assert rg < 5e-2 and ru < 5e-2
-    v.close()
+    for precise, (t_dec, t_loss, t_grad) in ((True, (3e-4, 1e-4, 1e-3)), (False, (2e-2, 2e-2, 5e-2))):
+        v = VaeDecoder(SDXL_VAE_CONFIG, hw, hw, device=0, state_dict=sd, precise=precise)
+        out = v.decode((x0 / sc).to(DEV))
+        r = rel_l2(out, ref)
+        lat_g = lat.clone().to(DEV)
+        loss, grad = v.color_guidance(lat_g, eps.to(DEV), alpha, hw, hw, masks, rgb, wgt, mall, want_grad=True)
+        rg, ru = rel_l2(grad, grad_ref), rel_l2(lat_g.cpu() - lat, new_ref - lat)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        v.color_guidance(lat_g, eps.to(DEV), alpha, hw, hw, masks, rgb, wgt, mall)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3
+        print(f"SDXL VAE 128x128 -> 1024x1024 ({'precise, 3 passes' if precise else 'single pass'}): decode rel-L2 {r:.3e}; loss {loss:.6f} "
+              f"vs {loss_ref:.6f}; grad rel-L2 {rg:.3e}; update rel-L2 {ru:.3e}; guidance call {ms:.1f} ms")
+        assert r < t_dec
+        assert abs(loss - loss_ref) < t_loss * abs(loss_ref)
+        assert rg < t_grad and ru < t_grad
+        v.close()
