@@ -37,16 +37,15 @@ struct rt_error : std::runtime_error {
     } while (0)
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-// round-to-nearest-even, NaN preserved
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
+// fp32 -> bf16, round-to-nearest-even, NaN stays NaN: gfx950's v_cvt_pk_bf16_f32 (one instruction per PAIR; rounds 1-2 carried a
+// 12-instruction integer sequence with an exec-mask branch for the NaN case per VALUE, which made the bf16 epilogues VALU bound)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 hw_bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, hw_bf16x2));
 }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, f) & 0xffffu); }
 // "low part" of a value whose high part is its bf16 rounding: v ~= bf16(v) + bf16(v - bf16(v)) to 2^-17 relative.  The precise mode
 // of the VAE engine (vae.hip) multiplies such pairs with three bf16 MFMA passes (hi*hi + lo*hi + hi*lo, fp32 accumulation).
 __device__ __forceinline__ float bf16_residual(float v) { return v - bf16_to_f32(f32_to_bf16(v)); }
@@ -54,14 +53,40 @@ __device__ __forceinline__ uint32_t pack_bf16x2_lo(float a, float b) { return pa
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-// gelu(x) = 0.5 x (1 + erf(x / sqrt 2)) with erf from Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 output
-// grid): one v_rcp + one v_exp + 7 FMAs instead of libm's branchy erff (the GEGLU epilogues run it on 32 values per lane and tile).
+// gelu(x) = 0.5 x (1 + erf(x / sqrt 2)), erf(x / sqrt 2) as an odd degree-17 polynomial P of clamp(x, +-4.25) with P(4.25) == 1
+// (weighted least-squares minimax fit, tools/fit_gelu.py): |gelu error| <= 6.4e-5 absolute everywhere (below half an ulp of the bf16
+// output for |gelu| > 0.03, exact saturation 0 / x outside the clamp), no transcendental instruction.  The GEGLU epilogues evaluate
+// it on 56 gate values per lane and tile; round 3 measured them VALU bound on the previous rcp + exp2 form (2 quarter-rate
+// instructions + 13 scalar FMAs per value).  The x2 form maps to v_pk_mul_f32 / v_pk_fma_f32, two gates per issue slot; both forms
+// run the same IEEE fma sequence and are bit-identical.
+#define RT_GELU_CLAMP 4.25f
+#define RT_GELU_C8 1.203002836e-10f
+#define RT_GELU_COEFS(K)                                                                                                                  \
+    K(-1.137335648e-08f) K(4.748426363e-07f) K(-1.167462415e-05f) K(1.911683503e-04f) K(-2.242938848e-03f)           \
+    K(1.971663348e-02f) K(-1.328222901e-01f) K(7.978754640e-01f)
+__device__ __forceinline__ f32x2 gelu_erf_x2(f32x2 x) {
+    f32x2 xc;
+    xc.x = __builtin_amdgcn_fmed3f(x.x, -RT_GELU_CLAMP, RT_GELU_CLAMP);
+    xc.y = __builtin_amdgcn_fmed3f(x.y, -RT_GELU_CLAMP, RT_GELU_CLAMP);
+    const f32x2 s = xc * xc;
+    f32x2 q = {RT_GELU_C8, RT_GELU_C8};
+#define RT_K(c) q = __builtin_elementwise_fma(q, s, (f32x2){c, c});
+    RT_GELU_COEFS(RT_K)
+#undef RT_K
+    const f32x2 pe = xc * q;                                        // erf(x / sqrt 2)
+    const f32x2 h = x * 0.5f;
+    return __builtin_elementwise_fma(h, pe, h);
+}
 __device__ __forceinline__ float gelu_erf(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * z);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float er = 1.f - poly * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);      // erf(|x| / sqrt 2)
-    return 0.5f * x + 0.5f * fabsf(x) * er;                                                   // x * 0.5 * (1 + sign(x) * er)
+    const float xc = __builtin_amdgcn_fmed3f(x, -RT_GELU_CLAMP, RT_GELU_CLAMP);
+    const float s = xc * xc;
+    float q = RT_GELU_C8;
+#define RT_K(c) q = __builtin_fmaf(q, s, c);
+    RT_GELU_COEFS(RT_K)
+#undef RT_K
+    const float pe = xc * q;
+    const float h = x * 0.5f;
+    return __builtin_fmaf(h, pe, h);
 }
 
 // async global -> LDS copy of 16 B per lane (LDS destination = wave-uniform base + lane*16)

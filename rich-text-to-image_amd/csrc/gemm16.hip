@@ -379,13 +379,18 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void gemm16_kernel(GemmArgs p, i
 #pragma unroll
         for (int t = 0; t < TNO; ++t) {
             float v[4];
+            if constexpr (EPI == EPI_GEGLU) {
+                const int tv = (t >> 1) * 4 + (t & 1);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if constexpr (EPI == EPI_GEGLU) {
-                    constexpr int dummy = 0; (void)dummy;
-                    const int tv = (t >> 1) * 4 + (t & 1);
-                    v[e] = (acc[i][tv][e] + bias_v[t][e]) * gelu_erf(acc[i][tv + 2][e] + bias_g[t][e]);
-                } else v[e] = acc[i][t][e] + bias_v[t][e];
+                for (int e = 0; e < 4; e += 2) {                     // two gates per packed-fp32 issue slot
+                    const f32x2 gt = {acc[i][tv + 2][e] + bias_g[t][e], acc[i][tv + 2][e + 1] + bias_g[t][e + 1]};
+                    const f32x2 vl = {acc[i][tv][e] + bias_v[t][e], acc[i][tv][e + 1] + bias_v[t][e + 1]};
+                    const f32x2 o = vl * gelu_erf_x2(gt);
+                    v[e] = o.x; v[e + 1] = o.y;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][t][e] + bias_v[t][e];
             }
             if constexpr (TEMB) {
                 int row = m0 + (wm * TMW + i) * 16 + l15; if (row >= p.M) row = p.M - 1;
