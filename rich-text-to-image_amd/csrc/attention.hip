@@ -25,6 +25,7 @@
 
 #ifdef RT_ATTN_TIMING
 __device__ long long g_attn_times[4 * 8];
+__device__ long long g_attn_wg[8192 * 2];            // [start, end] s_memtime of every workgroup (occupancy profile, probe only)
 #define AT_T(i) { const long long now_ = __builtin_readcyclecounter(); tacc[i] += now_ - tlast; tlast = now_; }
 #else
 #define AT_T(i)
@@ -34,7 +35,12 @@ __device__ long long g_attn_times[4 * 8];
 // that the 16-B V^T chunks of every batch entry stay aligned.
 // NW = waves per workgroup (4 or 8): every wave owns 32 queries and all of them share the staged K / V^T tiles, so an 8-wave
 // workgroup issues half the LDS-DMA pieces per query (2 instead of 4 per wave and 64-key tile) and halves the L2 -> LDS bytes.
-template <int DP, int KT, bool CROSS, bool RAGGED = false, int NW = 4>
+// FOLD (self-attention): the running reference m of the online softmax is subtracted BY THE MATRIX PIPE: one more MFMA k step per
+// 32-key sub-tile with A = (1, 0, ...) for every key and B = (-m, 0, ...) for the lane's query, so the accumulators come out as
+// s - m and the 32 v_sub per tile and wave disappear from the VALU stream that bounds this kernel.  m is kept
+// bf16-representable (softmax is invariant to the reference; it only has to stay within 2^8 of the true running maximum), so the
+// product 1 * (-m) is exact.
+template <int DP, int KT, bool CROSS, bool RAGGED = false, int NW = 4, bool FOLD = !CROSS>
 __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
     constexpr int NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -111,7 +117,11 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
     for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-    float m = -1e30f, l = 0.f;
+    float m = FOLD ? 0.f : -1e30f, l = 0.f;
+    bf16x8 ka, qm;                                                  // FOLD: the constant key-side fragment and the query-side (-m) fragment
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ka[e] = (__bf16)0.f; qm[e] = (__bf16)0.f; }
+    if (FOLD && hi == 0) ka[0] = (__bf16)1.f;
 
     const int ntile = (p.NK + KT - 1) / KT;
     stage(0, 0);
@@ -119,6 +129,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
     __syncthreads();
 #ifdef RT_ATTN_TIMING
     long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+    const long long t_wg0 = tlast;
 #endif
     for (int kt = 0; kt < ntile; ++kt) {
         const int cur = kt & 1;
@@ -143,10 +154,11 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
                 const bf16x8 kf = *(const bf16x8*)(ks_ + ((ks >> 1) * KT + row) * 64 + ls * 16);
                 s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[j], 0, 0, 0);
             }
+            if constexpr (FOLD) s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qm, s[j], 0, 0, 0);      // s - m
         }
         AT_T(1)
         // ---- online softmax (lane holds 16 of the 32 keys of each sub-tile for its query: 8*hi + [0,8) and 16 + 8*hi + [0,8); partner = lane^32)
-        float mx = m;
+        float mx = FOLD ? (kt == 0 ? -INFINITY : 0.f) : m;          // FOLD: s is already relative to m
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -162,7 +174,26 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
         // by 2^8 instead of 1, which bf16 P / fp32 accumulation absorb, and the O / l rescale (32 accumulator
         // read-modify-writes per tile) is skipped for almost every tile.  The decision is taken before this tile's P
         // is exponentiated and after the previous tile's P.V completed, so everything at the old scale is scaled once.
-        if (!__all(mx - m <= 8.f)) {
+        if constexpr (FOLD) {
+            if (kt == 0 || !__all(mx <= 8.f)) {
+                const float mn = bf16_to_f32(f32_to_bf16(m + mx));   // new reference, exact as an MFMA operand
+                const float delta = mn - m;
+                m = mn;
+                if (hi == 0) qm[0] = (__bf16)(-mn);
+                if (kt > 0) {                                        // (first tile: O = l = 0, and delta may be negative: 2^-delta overflows)
+                    const float alpha = __builtin_amdgcn_exp2f(-delta);
+                    l *= alpha;
+#pragma unroll
+                    for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[j][r] -= delta;   // this tile was produced against the old reference
+            }
+        } else if (!__all(mx - m <= 8.f)) {
             const float alpha = __builtin_amdgcn_exp2f(m - mx);
             m = mx;
             l *= alpha;
@@ -176,7 +207,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float pv = __builtin_amdgcn_exp2f(s[j][r] - m);      // v_exp_f32: argument <= 8, underflow flushes to 0
+                float pv = __builtin_amdgcn_exp2f(FOLD ? s[j][r] : s[j][r] - m);      // v_exp_f32: argument <= 8, underflow flushes to 0
                 if (CROSS) {
                     const int kl = j * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
                     pv *= wl[kl];
@@ -213,6 +244,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
     }
 #ifdef RT_ATTN_TIMING
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0) for (int i = 0; i < 6; ++i) g_attn_times[wave * 8 + i] = tacc[i];
+    if (tid == 0 && blockIdx.x < 8192) { g_attn_wg[2 * blockIdx.x] = t_wg0; g_attn_wg[2 * blockIdx.x + 1] = __builtin_readcyclecounter(); }
 #endif
 
     l += __shfl_xor(l, 32);
@@ -245,7 +277,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
     }
 }
 
-template <int DP, int KT, bool CROSS, bool RAGGED = false, int NW = 4>
+template <int DP, int KT, bool CROSS, bool RAGGED = false, int NW = 4, bool FOLD = !CROSS>
 static void launch_t(const AttnArgs& a, hipStream_t st) {
     // K / V^T double buffer (+ the cross-attention multipliers); the epilogue reuses it as NW slabs of 32 x (DP*2 + 16) bytes
     size_t lds = 4 * (size_t)KT * DP * 2 + (CROSS ? 2 * KT * sizeof(float) : 0);
@@ -253,19 +285,20 @@ static void launch_t(const AttnArgs& a, hipStream_t st) {
     if (slabs > lds) lds = slabs;
     static bool attr = false;
     if (!attr) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)attn_kernel<DP, KT, CROSS, RAGGED, NW>,
+        HIP_CHECK(hipFuncSetAttribute((const void*)attn_kernel<DP, KT, CROSS, RAGGED, NW, FOLD>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
     AttnArgs aa = a;
     aa.nqb = cdiv(a.N, 32 * NW);
     dim3 grid(aa.nqb * a.H * a.B), block(NW * 64);
-    hipLaunchKernelGGL((attn_kernel<DP, KT, CROSS, RAGGED, NW>), grid, block, lds, st, aa);
+    hipLaunchKernelGGL((attn_kernel<DP, KT, CROSS, RAGGED, NW, FOLD>), grid, block, lds, st, aa);
     HIP_CHECK(hipGetLastError());
 }
 
 #ifdef RT_PROBE
 int g_attn_nw = 0;          // probe override: 4 or 8 waves per workgroup for the d = 64 self-attention kernel
+int g_attn_nofold = 0;      // probe override: the round-2 form (v_sub in the softmax) for A/B timing
 #endif
 
 void launch_attention(const AttnArgs& a, hipStream_t st) {
@@ -298,6 +331,7 @@ void launch_attention(const AttnArgs& a, hipStream_t st) {
                 if (ragged) launch_t<64, 64, false, true>(a, st);
 #ifdef RT_PROBE
                 else if (wide) launch_t<64, 64, false, false, 8>(a, st);
+                else if (g_attn_nofold) launch_t<64, 64, false, false, 4, false>(a, st);
 #endif
                 else launch_t<64, 64, false>(a, st);
                 break;

@@ -411,6 +411,27 @@ def test_online_softmax_rescale_branch_with_spiked_keys():
     report("self_attn spiked", out.float()[None], ref, atol=2e-2, rtol=2e-2)
 
 
+@pytest.mark.parametrize("offset", [-40.0, 40.0])
+def test_online_softmax_folded_reference_far_from_zero(offset):
+    """The self-attention kernel subtracts its running reference m through an extra MFMA k step (attention.hip FOLD) and keeps m
+    bf16-representable.  All scores sit ~290 (log2 domain) below / above zero here - the first tile must re-base from the initial
+    reference 0 (exp2 would underflow / overflow otherwise) and m is rounded on a coarse bf16 grid (spacing 2 at 290); later spikes
+    force more re-bases.  Softmax is shift invariant, so the fp32 reference is unaffected."""
+    B, H, N, d, DP = 2, 2, 512, 64, 64
+    q, k, v = rnd(B, N, H * d, seed=46), rnd(B, N, H * d, seed=47), rnd(B, N, H * d, seed=48)
+    q, k = q.reshape(B, N, H, d), k.reshape(B, N, H, d)
+    q[..., d - 1] = 40.0
+    k[..., d - 1] = offset
+    k[0, 300, 0, : d - 1] = q[0, 9, 0, : d - 1] * 10.0         # a spike in tile 4 for query 9 of head 0
+    q, k = q.reshape(B, N, H * d), k.reshape(B, N, H * d)
+    qs = d ** -0.5 * math.log2(math.e)
+    Q, K, V = (_pack_heads(t.reshape(B * N, -1), H, d, DP, s) for t, s in ((q, qs), (k, 1.0), (v, 1.0)))
+    out = attention(Q, K, V.t().contiguous(), B, H, N, N, DP)
+    ref, _ = _ref_attention(Q.float().reshape(B, N, -1) / qs, K.float().reshape(B, N, -1), V.float().reshape(B, N, -1), H)
+    assert torch.isfinite(out.float()).all()
+    report(f"self_attn scores offset {offset:+.0f}", out.float().reshape(B, N, -1), ref, atol=2e-2, rtol=2e-2)
+
+
 @pytest.mark.parametrize("use_fs", [False, True])
 def test_cross_attention_fontsize(use_fs):
     B, H, N, d, DP, P = 3, 2, 256, 32, 32, 2

@@ -11,9 +11,10 @@ int main() {
       for (bf16_t* dst : {Q, K, VT}) { for (auto& v : h) { x = x * 1664525u + 1013904223u; v = (uint16_t)(0x3c00 | ((x >> 9) & 0x83ff) | ((x >> 3) & 0x8000)); }
         hipMemcpy(dst, h.data(), h.size() * 2, hipMemcpyHostToDevice); } }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int nw : {4, 8, 4, 8})
+    for (int mode : {0, 1, 0, 1, 2})                                // 0: round-2 softmax (v_sub), 1: -m folded into the MFMAs (FOLD), 2: FOLD, 8 waves
     for (auto sh : shs) {
-        g_attn_nw = nw;
+        const int nw = mode == 2 ? 8 : 4;
+        g_attn_nw = nw; g_attn_nofold = mode == 0;
         AttnArgs a{}; a.Q = Q; a.ldq = sh.H * DP; a.K = K; a.ldk = sh.H * DP; a.VT = VT; a.ldvt = sh.B * sh.N; a.O = O; a.ldo = sh.H * DP;
         for (int b = 0; b < sh.B; ++b) { a.q_src[b] = a.k_src[b] = a.v_src[b] = b; a.wset[b] = 0; }
         a.B = sh.B; a.H = sh.H; a.N = sh.N; a.NK = sh.N; a.nk_valid = sh.N; a.DP = DP; a.cross = 0;
@@ -22,7 +23,7 @@ int main() {
         for (int r = 0; r < 20; ++r) launch_attention(a, 0);
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
-        printf("self-attn %d waves/WG B%d H%d N%d d64: %7.1f us %6.0f TF\n", nw, sh.B, sh.H, sh.N, ms / 20 * 1e3, 4.0 * sh.B * sh.H * (double)sh.N * sh.N * 64 / (ms / 20 * 1e-3) / 1e12);
+        printf("self-attn mode %d %d waves/WG B%d H%d N%d d64: %7.1f us %6.0f TF\n", mode, nw, sh.B, sh.H, sh.N, ms / 20 * 1e3, 4.0 * sh.B * sh.H * (double)sh.N * sh.N * 64 / (ms / 20 * 1e-3) / 1e12);
 #ifdef RT_ATTN_TIMING
         long long t[32]; hipMemcpyFromSymbol(t, HIP_SYMBOL(g_attn_times), sizeof(t));
         const double nt = sh.N / 64.0;
