@@ -310,6 +310,35 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void gemm16_kernel(GemmArgs p, i
             for (int s_own = 0; s_own < RW; ++s_own) load_res(s_own, s_own);
         }
     }
+    // bias of this wave's columns: requested here as well (the fragment registers of the main loop are dead), so that its round trip
+    // (1.0-1.3 k cycles when it opened the epilogue, profiles/r3_gemm16_probe_v5_epilogue_breakdown.txt) hides behind the barrier / exchange
+    float bias_v[TNO][4], bias_g[EPI == EPI_GEGLU ? TNO : 1][4];
+    auto load_bias = [&]() {
+#pragma unroll
+    for (int t = 0; t < TNO; ++t) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bias_v[t][e] = 0.f; if (EPI == EPI_GEGLU) bias_g[t][e] = 0.f; }
+        if (p.bias) {
+            if constexpr (EPI == EPI_GEGLU) {
+                // packed columns: per 64-block [32 value | 32 gate]; output tile t (16 columns) = value tile 4*(t/2) + t%2, gate + 2
+                const int col = wcol0 + ((t >> 1) * 4 + (t & 1)) * 16 + 4 * q4;
+                if (col + 32 + 4 <= p.N) {
+                    const float4 b0 = *(const float4*)(p.bias + col), b1 = *(const float4*)(p.bias + col + 32);
+                    bias_v[t][0] = b0.x; bias_v[t][1] = b0.y; bias_v[t][2] = b0.z; bias_v[t][3] = b0.w;
+                    bias_g[t][0] = b1.x; bias_g[t][1] = b1.y; bias_g[t][2] = b1.z; bias_g[t][3] = b1.w;
+                }
+            } else {
+                const int col = wcol0 + t * 16 + 4 * q4;
+                if (col < p.N) {
+                    const float4 b0 = *(const float4*)(p.bias + col);
+                    bias_v[t][0] = b0.x; bias_v[t][1] = b0.y; bias_v[t][2] = b0.z; bias_v[t][3] = b0.w;
+                }
+            }
+        }
+    }
+    };
+    constexpr bool BIAS_EARLY = !F16 && MODE == A_DENSE;                                // (the fp16-trunk forms hold the residual window here: hoisting the bias too spills)
+    if constexpr (BIAS_EARLY) load_bias();
     // raw barriers from here on: a __syncthreads() carries s_waitcnt vmcnt(0) and would wait for the residual round trip
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                    // every wave left the ring: exchange buffers + transpose slabs
@@ -346,29 +375,7 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void gemm16_kernel(GemmArgs p, i
     constexpr int RS = TNO * 16 * ES + 16;                           // slab row stride (16-B pad: conflict-free 16-B column writes)
     static_assert(NW * 16 * RS <= S * STAGE, "slabs");
     char* slab = smem + (size_t)wave * 16 * RS;
-    float bias_v[TNO][4], bias_g[EPI == EPI_GEGLU ? TNO : 1][4];
-#pragma unroll
-    for (int t = 0; t < TNO; ++t) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { bias_v[t][e] = 0.f; if (EPI == EPI_GEGLU) bias_g[t][e] = 0.f; }
-        if (p.bias) {
-            if constexpr (EPI == EPI_GEGLU) {
-                // packed columns: per 64-block [32 value | 32 gate]; output tile t (16 columns) = value tile 4*(t/2) + t%2, gate + 2
-                const int col = wcol0 + ((t >> 1) * 4 + (t & 1)) * 16 + 4 * q4;
-                if (col + 32 + 4 <= p.N) {
-                    const float4 b0 = *(const float4*)(p.bias + col), b1 = *(const float4*)(p.bias + col + 32);
-                    bias_v[t][0] = b0.x; bias_v[t][1] = b0.y; bias_v[t][2] = b0.z; bias_v[t][3] = b0.w;
-                    bias_g[t][0] = b1.x; bias_g[t][1] = b1.y; bias_g[t][2] = b1.z; bias_g[t][3] = b1.w;
-                }
-            } else {
-                const int col = wcol0 + t * 16 + 4 * q4;
-                if (col < p.N) {
-                    const float4 b0 = *(const float4*)(p.bias + col);
-                    bias_v[t][0] = b0.x; bias_v[t][1] = b0.y; bias_v[t][2] = b0.z; bias_v[t][3] = b0.w;
-                }
-            }
-        }
-    }
+    if constexpr (!BIAS_EARLY) load_bias();
 #ifdef RT_G16_TIMING
     { float bsum = 0.f; for (int t = 0; t < TNO; ++t) bsum += bias_v[t][0]; asm volatile("" ::"v"(bsum)); G16_T(5) }
 #endif
