@@ -191,8 +191,8 @@ void launch_cast_f32_bf16(const float* x, bf16_t* out, size_t n, hipStream_t st,
 // out[b][n] (+)= sum_k act(a[b][k]) * W[n][k] + bias[n];  B <= 8
 void launch_small_linear(const float* a, int lda, const bf16_t* W, int ldw, const float* bias, float* out, int ldo,
                          int B, int N, int K, int silu_in, int accumulate, hipStream_t st);
-// one entry per ResnetBlock2D: out[out_off + b*N + n] = bias[n] + sum_k silu(emb[b][k]) * W[n][k]; `first` = prefix sum of N
-struct TembEntry { const bf16_t* W; const float* bias; int N; int first; long out_off; };
+// one entry per ResnetBlock2D: out[B*first + b*N + n] = bias[n] + sum_k silu(emb[b][k]) * W[n][k]; `first` = prefix sum of N
+struct TembEntry { const bf16_t* W; const float* bias; int N; int first; };       // output block of an entry: [B, N] at B * first (batch-independent table)
 void launch_temb_all(const float* emb, int lde, float* silu_scratch, const TembEntry* tab, int ntab, int total, int B, int K, float* out,
                      hipStream_t st);
 void launch_timestep_embed(const float* t, int n, int dim, float* out, int ldo, hipStream_t st);

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void temb_all_kernel(const float* __restrict__
             float s = acc[b];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-            if (lane == 0) out[(size_t)e.out_off + (size_t)b * e.N + n] = s + e.bias[n];
+            if (lane == 0) out[(size_t)B * e.first + (size_t)b * e.N + n] = s + e.bias[n];       // [B, N] block of projection t at B * first
         }
     }
 }

@@ -165,7 +165,6 @@ struct rt_engine {
     std::vector<TembEntry> temb_tab;
     int temb_total = 0;
     TembEntry* temb_tab_dev = nullptr;
-    int temb_tab_B = -1;             // batch size the device table's out offsets were built for
     float* temb_all = nullptr;       // [resnet][B][cout] of the running forward
 
     // per-image state
@@ -256,7 +255,7 @@ struct rt_engine {
         r.has_sc = cin != cout;
         if (r.has_sc) r.sc = mk_linear(name + ".conv_shortcut", cin, cout, true, true);
         r.temb_first = temb_total; temb_total += cout;
-        temb_tab.push_back(TembEntry{r.temb.w, r.temb.b, cout, r.temb_first, 0});
+        temb_tab.push_back(TembEntry{r.temb.w, r.temb.b, cout, r.temb_first});
         return r;
     }
     // q/k/v projection with head padding d -> DP on the output rows
@@ -322,7 +321,7 @@ struct rt_engine {
     }
 
     void build_plan() {
-        slots.clear(); slot_index.clear(); down.clear(); up.clear(); temb_tab.clear(); temb_total = 0; temb_tab_B = -1;
+        slots.clear(); slot_index.clear(); down.clear(); up.clear(); temb_tab.clear(); temb_total = 0;
         const int L = cfg.n_levels;
         const int* boc = cfg.block_out_channels;
         temb_dim = boc[0] * 4;
@@ -604,14 +603,6 @@ struct rt_engine {
             Scope sc(ws);
             float* semb = ws.f32((size_t)B * temb_dim);
             if (!dry()) {
-                if (temb_tab_B != B) {                                   // out offsets depend on the batch size: rebuild the small table
-                    std::vector<TembEntry> t = temb_tab;
-                    for (auto& e : t) e.out_off = (long)B * e.first;
-                    if (!temb_tab_dev) HIP_CHECK(hipMalloc((void**)&temb_tab_dev, t.size() * sizeof(TembEntry)));
-                    HIP_CHECK(hipMemcpyAsync(temb_tab_dev, t.data(), t.size() * sizeof(TembEntry), hipMemcpyHostToDevice, stream));
-                    HIP_CHECK(hipStreamSynchronize(stream));             // `t` is a stack vector
-                    temb_tab_B = B;
-                }
                 launch_temb_all(emb, temb_dim, semb, temb_tab_dev, (int)temb_tab.size(), temb_total, B, temb_dim, temb_all, stream);
             }
         }
@@ -855,6 +846,10 @@ int rt_create(const rt_config* cfg, int device, rt_engine** out) {
             if (e->splitk_need) {
                 HIP_CHECK(hipMalloc((void**)&e->splitk_buf, e->splitk_need * 4));
                 e->splitk_floats = e->splitk_need;
+            }
+            if (!e->temb_tab.empty()) {      // the time_emb_proj table of temb_all_kernel: batch-independent, uploaded once
+                HIP_CHECK(hipMalloc((void**)&e->temb_tab_dev, e->temb_tab.size() * sizeof(TembEntry)));
+                HIP_CHECK(hipMemcpy(e->temb_tab_dev, e->temb_tab.data(), e->temb_tab.size() * sizeof(TembEntry), hipMemcpyHostToDevice));
             }
         }
         e->set_fontsize(nullptr, nullptr, 0);      // multiplier set 0/1 = plain softmax until rt_set_fontsize is called
