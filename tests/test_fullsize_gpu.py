@@ -175,6 +175,40 @@ def test_sdxl_config3_rich_step_matches_oracle(sdxl):
     assert r < 3e-2 and rr < 3e-2
 
 
+def test_sdxl_full_architecture_two_step_loop_with_background_blend(sdxl):
+    """The iterations `test_sdxl_config3_rich_step_matches_oracle` leaves out, at the SDXL-base architecture on a 64x64 latent (the
+    oracle needs ~3 s per forward at this size instead of ~12 s at 128x128): a 2-step Euler loop with R = 2, inject_selfattn = 0.5
+    and inject_background = 0.5 - iteration 0 is injected (t = 501), iteration 1 is NOT (t = 1: region streams attend with their own
+    Q / K, no resnet feature) and ends with the background blend of xl.py:868-872 (i == int(0.5 * 2)), both latent streams stepped on
+    every iteration (xl.py:832).  Final latents against oracle.region_loop.rich_loop_xl, which is pinned to the reference loop."""
+    eng, o = sdxl
+    hw, R, steps, gs, isa, ibg = 64, 2, 2, 5.0, 0.5, 0.5
+    g = torch.Generator().manual_seed(17)
+    emb = torch.randn(R + 1, 77, 2048, generator=g)
+    pooled = torch.randn(R + 1, 1280, generator=g)
+    tid = torch.tensor([[512.0, 512.0, 0, 0, 512.0, 512.0]])
+    m = _masks(R, hw, g)
+    masks = [m[r:r + 1] for r in range(R)]
+    sched = OracleEuler(); sched.set_timesteps(steps)
+    lat0 = torch.randn(1, 4, hw, hw, generator=g) * sched.init_noise_sigma
+    tfd = {"word_pos": torch.tensor([4]), "font_size": torch.tensor([8.0])}
+    eng.set_prompts(emb.to(DEV), pooled.to(DEV), tid)
+    eng.set_masks(m.to(DEV))
+    eng.set_fontsize(tfd["word_pos"], tfd["font_size"])
+    eng.set_schedule(0, sched.timesteps.tolist(), sched.sigmas.tolist(), steps)
+    eng.set_latents(lat0.to(DEV))
+    for i in range(steps):
+        eng.region_step(i, gs, isa, ibg, xl=True, elide=False)
+    got = eng.read_latents(hw, hw).cpu()
+    trace = []
+    ref = rich_loop_xl(o, OracleEuler(), emb, pooled, tid, masks, lat0, steps, gs, tfd, isa, ibg, trace=trace)
+    r = rel_l2(got - lat0, ref - lat0)
+    bgm = (m[R - 1:R] > 0.5).expand_as(ref)            # mostly-background pixels: after the blend they hold the reference stream's latents
+    rb = rel_l2((got - lat0)[bgm], (ref - lat0)[bgm])
+    print(f"SDXL full arch, 2-step loop (injected + non-injected + background blend): latent change rel-L2 {r:.3e} (background region {rb:.3e})")
+    assert r < 3e-2 and rb < 3e-2
+
+
 def test_sd15_config1_rich_loop_matches_oracle(sd15):
     """BASELINE config 1 shape (SD-v1.5 512x512, 2 regions, PLMS) for a 2-step schedule = 3 PLMS iterations."""
     eng, o = sd15
