@@ -121,7 +121,7 @@ def cross_attention_block(dev, F=7):
         trunk = torch.randn(M, Cc, generator=g, device=dev).to(torch.float16)
         q = torch.empty(M, H * DP, device=dev, dtype=torch.bfloat16); o = torch.empty_like(q); y = torch.empty_like(trunk)
         ia = lambda v: (C.c_int * F)(*v)
-        prm, ws = ia([0, 4, 0, 4, 1, 2, 3][:F]), ia([0, 1, 0, 0, 0, 0, 0][:F])
+        prm, ws = ia([0, 4, 0, 4, 1, 2, 3][:F]), ia([-1, 1, -1, -1, -1, -1, -1][:F])      # as the engine: one font-size stream, the others plain (-1)
 
         def block():
             rc = lib.rt_op_cross_attn_block(_ptr(x), _ptr(wq), _ptr(wo), _ptr(bo), _ptr(K), _ptr(VT), 5 * 96, prm, ws, _ptr(wabs), _ptr(wsgn),

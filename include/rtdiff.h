@@ -135,6 +135,8 @@ int rt_unet_forward(rt_engine* e, const float* x, int B, int h, int w, float tim
 int rt_op_gemm(const void* A, const void* W, const float* bias, void* out, const void* res, const float* temb,
                int mode, int epi, int M, int N, int K, int lda, int ldw, int ldo, int ldres, int temb_ld,
                int rows_per_batch, int Hin, int Win, int Cin, int Hout, int Wout, void* stream);
+/* wset_host (cross only): per batch entry the row of wabs / wsgn [nsets, NK] to multiply the exponentials / probabilities with
+ * (attention_processor.py:386-401), or -1 for plain softmax over the keys < nk_valid (no table reads; NULL = set 0 everywhere). */
 int rt_op_attention(const void* Q, int ldq, const void* K, int ldk, const void* VT, int ldvt, void* O, int ldo,
                     const int* q_src_host, const int* k_src_host, const int* v_src_host, const int* wset_host,
                     const float* wabs, const float* wsgn, int B, int H, int N, int NK, int nk_valid, int DP, int cross,
@@ -151,7 +153,9 @@ int rt_op_gemm16_variant(const void* A, const void* W, const float* bias, void* 
  *   trunk_out[B*N, C] (fp16) = trunk_in + to_out(softmax_fs(to_q(x) K[prompt]^T) V[prompt]) + bo
  * x bf16 [B*N, C] (LayerNorm output); wq bf16 [H*DP, C] head-padded and pre-scaled by d^-1/2 log2 e; wo bf16 [C, H*DP]; bo fp32 [C] or NULL;
  * kcache bf16 [P*96, H*DP], vtcache bf16 [H*DP, ldvt] (77 keys padded to 96 per prompt); prompt_host / wset_host: per batch entry the
- * prompt index and the multiplier set (0 plain softmax, 1 font-size) in wabs / wsgn [2, 96]; q_scratch, o_scratch bf16 [B*N, H*DP]. */
+ * prompt index and the multiplier set in wabs / wsgn [nsets, 96] (the engine's tables: 0 plain softmax, 1 font-size), or -1 = plain softmax
+ * over the 77 valid keys without reading the tables (what the engine passes for every stream without a font-size entry: identical bits,
+ * fewer instructions); q_scratch, o_scratch bf16 [B*N, H*DP]. */
 int rt_op_cross_attn_block(const void* x, const void* wq, const void* wo, const float* bo, const void* kcache, const void* vtcache, int ldvt,
                            const int* prompt_host, const int* wset_host, const float* wabs, const float* wsgn, const void* trunk_in_f16,
                            void* trunk_out_f16, void* q_scratch, void* o_scratch, int B, int N, int C, int H, int DP, void* stream);

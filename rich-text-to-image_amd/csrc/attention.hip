@@ -41,7 +41,7 @@ __device__ long long g_attn_wg[8192 * 2];            // [start, end] s_memtime o
 // bf16-representable (softmax is invariant to the reference; it only has to stay within 2^8 of the true running maximum), so the
 // product 1 * (-m) is exact.
 template <int DP, int KT, bool CROSS, bool RAGGED = false, int NW = 4, bool FOLD = !CROSS>
-__global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
+__global__ __launch_bounds__(NW * 64, (CROSS && DP <= 64) ? 3 : 1) void attn_kernel(AttnArgs p) {
     constexpr int NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE = KT * DP * 2;          // bytes of one K (or V^T) tile
@@ -69,7 +69,10 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
     const int qb = p.q_src[b], kb = p.k_src[b], vb = p.v_src[b];
 
     float* wl = (float*)(smem + 2 * STAGE);    // cross: [2][KT] multipliers
-    if (CROSS) {
+    // wset[b] < 0: plain softmax over the nk_valid keys - no multiplier tables (6 of the 7 streams of a rich-text step); the 48
+    // table reads + 2 x 48 multiplies per lane are a quarter of this single-tile kernel's instructions
+    const bool plain = CROSS && p.wset[b] < 0;                      // workgroup-uniform
+    if (CROSS && !plain) {
         const int ws = p.wset[b];
         for (int i = tid; i < KT; i += NT) {
             wl[i] = p.wabs[ws * p.NK + i];
@@ -164,8 +167,11 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 if (CROSS || RAGGED) {
-                    const int key = kt * KT + j * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
-                    if (key >= (CROSS ? p.nk_valid : p.NK)) s[j][r] = -INFINITY;
+                    // (uniform test first: only the sub-tiles that reach past the last valid key pay the per-element compare)
+                    if (kt * KT + (j + 1) * 32 > (CROSS ? p.nk_valid : p.NK)) {
+                        const int key = kt * KT + j * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
+                        if (key >= (CROSS ? p.nk_valid : p.NK)) s[j][r] = -INFINITY;
+                    }
                 }
                 mx = fmaxf(mx, s[j][r]);
             }
@@ -203,21 +209,26 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
                 for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
         }
         float rs = 0.f;
+        if (CROSS && !plain) {                                       // font-size stream: e_k = exp(s_k - max) |fs_k|, p_k = sign(fs_k) e_k / sum e
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float pv = __builtin_amdgcn_exp2f(FOLD ? s[j][r] : s[j][r] - m);      // v_exp_f32: argument <= 8, underflow flushes to 0
-                if (CROSS) {
+                for (int r = 0; r < 16; ++r) {
                     const int kl = j * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
-                    pv *= wl[kl];
+                    float pv = __builtin_amdgcn_exp2f(s[j][r] - m) * wl[kl];
                     rs += pv;
-                    pv *= wl[KT + kl];
-                } else {
-                    rs += pv;                                      // (v_pk_add_f32 pairs measured slower: 131 extra v_mov)
+                    s[j][r] = pv * wl[KT + kl];
                 }
-                s[j][r] = pv;
-            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(FOLD ? s[j][r] : s[j][r] - m);      // v_exp_f32: argument <= 8, underflow flushes to 0
+                    rs += pv;                                      // (v_pk_add_f32 pairs measured slower: 131 extra v_mov)
+                    s[j][r] = pv;
+                }
+        }
         l += rs;
         AT_T(2)
 

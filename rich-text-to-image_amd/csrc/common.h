@@ -95,6 +95,14 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// LDS-DMA through a buffer descriptor: buffer_load_dwordx4 v(voff), s[rsrc], s(soff) offen lds.  `base` must be wave-uniform; the
+// descriptor is rebuilt from it at every call site (4 SALU moves, hoisted by the compiler).  Kept in a non-template __device__
+// function: the descriptor type exists in device compilation only and a kernel TEMPLATE that names it loses its host-side stub.
+static __device__ __forceinline__ void glds16_buf(const void* base, int voff_bytes, int soff_bytes, void* lds_wave_base, unsigned range_bytes = 0x7fffffffu) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, range_bytes, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff_bytes, soff_bytes, 0, 0);
+}
+
 // ---------------------------------------------------------------- GEMM / implicit-GEMM conv
 enum { A_DENSE = 0, A_CONV3 = 1, A_CONV3_S2 = 2, A_CONV3_UP2 = 3 };
 enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_BF16_TEMB = 2, EPI_GEGLU = 3, EPI_F16 = 4 };   // EPI_F16: fp16 output (+ fp16 residual): the UNet trunk

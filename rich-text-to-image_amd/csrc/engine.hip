@@ -547,7 +547,7 @@ struct rt_engine {
                 if (!dry()) {
                     AttnArgs a{}; a.Q = qk; a.ldq = HD; a.K = k.kcache; a.ldk = HD; a.VT = k.vtcache; a.ldvt = cfg.max_prompts * 96;
                     a.O = o; a.ldo = HD;
-                    for (int b = 0; b < B; ++b) { a.q_src[b] = b; a.k_src[b] = in.prompt[b]; a.v_src[b] = in.prompt[b]; a.wset[b] = in.fontsize[b] ? 1 : 0; }
+                    for (int b = 0; b < B; ++b) { a.q_src[b] = b; a.k_src[b] = in.prompt[b]; a.v_src[b] = in.prompt[b]; a.wset[b] = in.fontsize[b] ? 1 : -1; }      // -1: plain softmax, no multiplier tables
                     a.wabs = wabs; a.wsgn = wsgn;
                     a.B = B; a.H = t.heads; a.N = HW; a.NK = 96; a.nk_valid = 77; a.DP = t.DP; a.cross = 1;
                     prof_begin(RT_PROF_ATTN_CROSS, 4.0 * B * t.heads * (double)HW * 77 * t.d);

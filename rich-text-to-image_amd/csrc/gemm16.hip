@@ -42,13 +42,6 @@ __device__ long long g_g16_times[8192 * 8];
 #define RT_G16_ABLATE 0
 #endif
 
-// LDS-DMA through a buffer descriptor: buffer_load_dwordx4 v(voff), s[rsrc], s(soff) offen lds.  `base` must be wave-uniform; the
-// descriptor is rebuilt from it at every call site (4 SALU moves, hoisted by the compiler).  Kept in a non-template __device__
-// function: the descriptor type exists in device compilation only and a kernel TEMPLATE that names it loses its host-side stub.
-__device__ __forceinline__ void glds16_buf(const void* base, int voff_bytes, int soff_bytes, void* lds_wave_base, unsigned range_bytes = 0x7fffffffu) {
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, range_bytes, 0x00020000);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff_bytes, soff_bytes, 0, 0);
-}
 #define RT_G16_OOB 0x7fff0000       // a voffset beyond every descriptor range used here: the lane's 16 bytes arrive as zeros
 
 // MODE = A_CONV3: 3x3 stride-1 pad-1 convolution as an implicit GEMM on the SAME main loop (M = pixels of the NHWC activation,

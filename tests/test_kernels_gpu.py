@@ -459,6 +459,34 @@ def test_cross_attention_fontsize(use_fs):
         report(f"cross_attn stream {b} fs={wset[b]}", out.float().reshape(B, N, -1)[b], ref[0], atol=1.5e-2, rtol=1.5e-2)
 
 
+def test_cross_attention_plain_path_equals_the_tables_of_ones():
+    """wset[b] < 0 selects plain softmax over the nk_valid keys without multiplier tables (attention.hip: what the engine passes for
+    every stream without a font-size entry).  It must agree BIT FOR BIT with wset = 0 on tables of ones / zeros for the padded keys:
+    multiplying by 1.0 and by the 0 of a key whose score was masked to -inf changes nothing - in a batch that mixes both kinds."""
+    B, H, N, d, DP, P = 4, 3, 384, 64, 64, 2
+    q = rnd(B, N, H * d, seed=53)
+    kc, vc = rnd(P, 77, H * d, seed=54), rnd(P, 77, H * d, seed=55)
+    qs = d ** -0.5 * math.log2(math.e)
+    Q = _pack_heads(q.reshape(B * N, -1), H, d, DP, qs)
+    Kp = torch.zeros(P, 96, H * d); Kp[:, :77] = kc
+    Vp = torch.zeros(P, 96, H * d); Vp[:, :77] = vc
+    K, V = _pack_heads(Kp.reshape(P * 96, -1), H, d, DP), _pack_heads(Vp.reshape(P * 96, -1), H, d, DP)
+    wp, fs = torch.tensor([4, 11]), torch.tensor([2.5, -0.75])
+    wabs = torch.zeros(2, 96); wabs[:, :77] = 1.0
+    wsgn = torch.ones(2, 96)
+    wabs[1, wp] = fs.abs(); wsgn[1, wp] = fs.sign()
+    prompt = [0, 1, 1, 0]
+    kw = dict(q_src=[0, 1, 2, 3], k_src=prompt, v_src=prompt, cross=True, wabs=wabs.to(DEV), wsgn=wsgn.to(DEV), nk_valid=77)
+    tables = attention(Q, K, V.t().contiguous(), B, H, N, 96, DP, wset=[0, 1, 0, 0], **kw)
+    plain = attention(Q, K, V.t().contiguous(), B, H, N, 96, DP, wset=[-1, 1, -1, -1], **kw)
+    assert torch.equal(tables, plain)
+    qr = Q.float().reshape(B, N, -1) / qs
+    kr, vr = K.float().reshape(P, 96, -1)[:, :77], V.float().reshape(P, 96, -1)[:, :77]
+    for b in (0, 1):
+        ref, _ = _ref_attention(qr[b:b + 1], kr[prompt[b]][None], vr[prompt[b]][None], H, (wp, fs) if b == 1 else None)
+        report(f"cross_attn plain-path batch, stream {b}", plain.float().reshape(B, N, -1)[b], ref[0], atol=1.5e-2, rtol=1.5e-2)
+
+
 def test_attention_against_reference_module_golden():
     """tests/golden/attention_ops.pt was produced by the UNMODIFIED reference Attention module."""
     import os
