@@ -589,7 +589,7 @@ def test_groupnorm(B, HW, C1, C2, G, silu, bf16in):
 
 
 @pytest.mark.parametrize("f16", [False, True])
-@pytest.mark.parametrize("rows,C", [(100, 64), (512, 640), (1024, 1280), (77, 320)])
+@pytest.mark.parametrize("rows,C", [(100, 64), (512, 640), (1024, 1280), (77, 320), (1021, 640), (515, 1280), (96, 768)])
 def test_layernorm(rows, C, f16):
     x = (rnd(rows, C, seed=70) * 3 + 1).to(DEV)
     if f16:
