@@ -297,7 +297,11 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void gemm16_kernel(GemmArgs p, i
             if (F16) rres[F16 ? slot : 0][F16 ? it : 0] = (r < 16 && i < TMW) ? *(const uint4*)((const f16_t*)p.res + (size_t)row * p.ldres + col) : uint4{0, 0, 0, 0};
         }
     };
-    if constexpr (F16) {
+    // K-split forms: ahead of the exchange (its round trip, 7 - 8 k cycles for the chip-wide 18 MB burst, hides behind the LDS pass:
+    // 29.4 vs 31.6 us per 7168 x 1280 x 1280 launch); class A has no exchange to hide behind and measured better with the request
+    // after the post-loop barrier (ff.net.2 28672 x 640 x 2560: 74.1 -> 69.7 us, to_out 640: 30.2 -> 28.6 us)
+    constexpr bool RES_EARLY = WK == 2;
+    if constexpr (F16 && RES_EARLY) {
         if (p.res) {
 #pragma unroll
             for (int s_own = 0; s_own < RW; ++s_own) load_res(s_own, s_own);
@@ -362,6 +366,12 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void gemm16_kernel(GemmArgs p, i
         __builtin_amdgcn_s_barrier();                                // the exchange region becomes the transpose slabs
     }
     G16_T(3)
+    if constexpr (F16 && !RES_EARLY) {
+        if (p.res) {
+#pragma unroll
+            for (int s_own = 0; s_own < RW; ++s_own) load_res(s_own, s_own);
+        }
+    }
 
     // ---- epilogue: lane (l15, q4) holds row l15 and columns 4*q4 .. +3 of every 16x16 tile.  Each wave transposes one 16-row tile
     // at a time through its private slab and moves row-contiguous 16-B chunks to / from HBM (guide T21).

@@ -52,6 +52,7 @@ int main(int argc, char** argv) {
     // name, M, N, K, epi, residual, weights_on_rows, {old configs}, {new variants}, try wstat 0 and 1
     const Case cases[] = {
         {"attn.to_out / to_q 1280 (f16 trunk + res)", 7168, 1280, 1280, EPI_F16, 1, 0, {2, -1, -1}, {0, -1, 1, -1, -1, -1}, 0},
+        {"to_out 1280 (f16 trunk, NO residual)", 7168, 1280, 1280, EPI_F16, 0, 0, {2, -1, -1}, {0, -1, -1, -1, -1, -1}, 0},
         {"attn2.to_q 1280 (bf16)", 7168, 1280, 1280, EPI_BF16, 0, 0, {2, -1, -1}, {0, -1, -1, -1, -1, -1}, 0},
         {"ff.net.2 1280 (K = 5120, f16 + res)", 7168, 1280, 5120, EPI_F16, 1, 0, {2, -1, -1}, {0, -1, -1, -1, -1, -1}, 0},
         {"attn1 Q|K 1280 (N = 2560)", 7168, 2560, 1280, EPI_BF16, 0, 0, {2, -1, -1}, {0, -1, 4, -1, 2, -1}, 0},
