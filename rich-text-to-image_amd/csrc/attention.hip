@@ -25,7 +25,6 @@
 
 #ifdef RT_ATTN_TIMING
 __device__ long long g_attn_times[4 * 8];
-__device__ long long g_attn_wg[8192 * 2];            // [start, end] s_memtime of every workgroup (occupancy profile, probe only)
 #define AT_T(i) { const long long now_ = __builtin_readcyclecounter(); tacc[i] += now_ - tlast; tlast = now_; }
 #else
 #define AT_T(i)
@@ -132,7 +131,6 @@ __global__ __launch_bounds__(NW * 64, (CROSS && DP <= 64) ? 3 : 1) void attn_ker
     __syncthreads();
 #ifdef RT_ATTN_TIMING
     long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
-    const long long t_wg0 = tlast;
 #endif
     for (int kt = 0; kt < ntile; ++kt) {
         const int cur = kt & 1;
@@ -255,7 +253,6 @@ __global__ __launch_bounds__(NW * 64, (CROSS && DP <= 64) ? 3 : 1) void attn_ker
     }
 #ifdef RT_ATTN_TIMING
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0) for (int i = 0; i < 6; ++i) g_attn_times[wave * 8 + i] = tacc[i];
-    if (tid == 0 && blockIdx.x < 8192) { g_attn_wg[2 * blockIdx.x] = t_wg0; g_attn_wg[2 * blockIdx.x + 1] = __builtin_readcyclecounter(); }
 #endif
 
     l += __shfl_xor(l, 32);
