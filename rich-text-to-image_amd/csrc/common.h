@@ -126,6 +126,8 @@ struct GemmArgs {
                                      // gemm16.hip so that a stream's result does not depend on the other streams of the launch
     float* splitk_ws;                // optional split-K partial-sum scratch owned by the caller (engine workspace); null: per-(device, stream) fallback
     size_t splitk_ws_floats;
+    int prefer_patch_conv;           // 1: stride-1 3x3 convolution that should stay on the patch kernel (single-image VAE layers whose 224-row GEMM
+                                     // tiles would leave most of the chip idle: the caller decides on its own, batch-free, shape)
     int weights_on_rows;             // 1: the V^T product (A = weight rows, W = token rows): tile-class choices key on M instead of N
     int split_tiles;                 // 128x128 output tiles of ONE batch entry's share of the problem (0: unknown).  The split-K rule
                                      // uses it instead of the actual tile count, so a stream's result does not depend on how many

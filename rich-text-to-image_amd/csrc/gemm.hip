@@ -1441,7 +1441,7 @@ void launch_gemm(const GemmArgs& a, hipStream_t st) {
     const int ksl = g_splitk ? splitk_slices(a) : 1;
     // patch convolutions that cannot fill the chip (< 128 workgroups) go through the split-K implicit GEMM as well
     const bool patch_underfilled = ksl > 1 && a.mode != A_DENSE;
-    if (a.mode == A_CONV3 && ksl == 1 && g_force_cfg < 0 && g_use16 && g_conv16 && g_conv_patch) {
+    if (a.mode == A_CONV3 && ksl == 1 && g_force_cfg < 0 && g_use16 && g_conv16 && g_conv_patch && !a.prefer_patch_conv) {
         // stride-1 3x3 convolutions with Cin % 64 == 0: implicit GEMM on the 16x16x32 family's main loop (gemm16.hip, MODE = A_CONV3)
         int wstat = 0;
         const int v = gemm16_pick(a, 0, &wstat);

@@ -584,10 +584,14 @@ int gemm16_pick(const GemmArgs& a, int weights_on_rows, int* wstat) {
     };
     if (a.mode == A_CONV3) {
         // same classes as the dense problems of the same width; the K-split class needs an even K-tile count (Cin / 64 even)
+        // ... and only where ONE image contributes enough tiles that the batches of a step fill the chip (the rule may not look at
+        // the batch: a stream must take the same path alone and inside a batch).  SDXL: 38 - 74 tiles per image at every level;
+        // SD-v1.5's 32^2 / 16^2 levels: 20 / 16, three to seven of which leave most CUs idle - they stay on the patch kernel
+        // (config 1, same box: 126 steps/s with them here, 134 on the patch kernel).
         const bool wide = a.N % 320 == 0 && (long)cdiv(rps, 224) * (a.N / 320) >= 32;
         if (wide) return 4;
-        if (a.N % 160 == 0 && (a.K / BK16) % 2 == 0) return 0;
-        if (a.N % 256 == 0) return 2;
+        if (a.N % 160 == 0 && (a.K / BK16) % 2 == 0) return (long)cdiv(rps, 224) * (a.N / 160) >= 30 ? 0 : -1;
+        if (a.N % 256 == 0) return (long)cdiv(rps, 224) * (a.N / 256) >= 30 ? 2 : -1;
         return -1;
     }
     if (weights_on_rows) {

@@ -194,6 +194,9 @@ struct rt_vae {
         g.M = Ho * Wo; g.N = N; g.K = K; g.ldw = K; g.ldo = N; g.ldres = N; g.rows_per_batch = Ho * Wo; g.Hin = H; g.Win = Wd; g.Cin = CinP;
         g.Hout = Ho; g.Wout = Wo;
         RT_REQUIRE(K == 9 * CinP, "vae conv: weight/input channel mismatch");
+        // one image: the 224 x 256 tiles of the GEMM-loop convolution fill the chip only from 256^2 x 256 channels upwards (SD 64^2
+        // latent: 13.1 ms per guidance call with every layer on it, 11.3 ms on the patch kernel; SDXL 128^2: 39.7 vs 41.0 the other way)
+        g.prefer_patch_conv = (long)g.M * N < 192L * 224 * 256;
         launch_gemm(g, stream);
     }
     void split(const float* x, BT o, size_t n) { if (!dry) launch_cast_f32_bf16(x, o.hi, n, stream, o.lo); }
