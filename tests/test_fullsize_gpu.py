@@ -136,8 +136,8 @@ def _masks(R, hw, g):
 def test_sdxl_config3_rich_step_matches_oracle(sdxl):
     """BASELINE config 3 (the benched workload): the FIRST iteration of a 2-step Euler schedule (t = 501 > 500: injected - 7 streams,
     the three region streams with qk_src / res_src -> text_ref), both latent streams after the scheduler step.  The non-injected
-    iteration of the loop is covered at full size by the SD-v1.5 loop below and, for SDXL, by the stream-mode forward above; the
-    oracle costs ~0.5 min per SDXL forward on the GPU box's host, which is what bounds this file."""
+    iteration and the background blend are covered at the SDXL architecture by the 2-step loop test below (on a 64x64 latent: the
+    oracle costs ~12 s per SDXL forward at 128x128 on the GPU box's host, which is what bounds this file)."""
     from oracle.region_loop import rich_step_forwards
     eng, o = sdxl
     hw, R, steps, gs, isa = 128, 4, 2, 5.0, 0.5
