@@ -141,6 +141,12 @@ int rt_op_attention(const void* Q, int ldq, const void* K, int ldk, const void* 
                     const int* q_src_host, const int* k_src_host, const int* v_src_host, const int* wset_host,
                     const float* wabs, const float* wsgn, int B, int H, int N, int NK, int nk_valid, int DP, int cross,
                     void* stream);
+/* Host-only query of the shape rule of csrc/gemm16.hip (no device needed; tests/test_gemm16_pick.py): the tile variant a problem of `streams`
+ * streams x rows_per_stream rows takes (ids below; -1: not in the family / stays on gemm.hip or the patch convolution; -2: conv3x3 query
+ * with a non-square map).  conv3x3 = 1: stride-1 3x3 convolution with Cin = K_or_Cin input channels on a square map of rows_per_stream
+ * pixels.  *w_stationary = 1 when the launch uses the W-stationary tile -> XCD order.  The summation CLASS of the answer ({2,3,4,5,8} /
+ * {0,1} / {6,7} / -1) never depends on `streams`; inside a class the tile shape follows the batch. */
+int rt_op_gemm16_pick(int conv3x3, int epi, int streams, int rows_per_stream, int N, int K_or_Cin, int weights_on_rows, int* w_stationary);
 /* One tile variant of the 16x16x32-MFMA GEMM family (csrc/gemm16.hip; tests / micro-benchmarks - rt_op_gemm picks by shape):
  * 0: 224x160 K-split  1: 128x160 K-split  2: 224x256  3: 256x256  4: 224x320  5: 256x320  6: 160x224 K-split (V^T)  7: 160x128 K-split
  * 8: 128x256;  -1: the variant the shape rule picks.  Variants {2,3,4,5,8} (class A) give the same bits as each other and as every

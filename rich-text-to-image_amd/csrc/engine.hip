@@ -1090,6 +1090,27 @@ int rt_op_attention(const void* Q, int ldq, const void* K, int ldk, const void* 
         launch_attention(a, (hipStream_t)stream);
     })
 }
+// The shape rule of csrc/gemm16.hip as a host-only query (no device needed): which tile variant a problem takes (-1: stays on gemm.hip /
+// the patch convolution) and whether it uses the W-stationary tile -> XCD order.  `streams` images / streams of rows_per_stream rows each.
+int rt_op_gemm16_pick(int conv3x3, int epi, int streams, int rows_per_stream, int N, int K_or_Cin, int weights_on_rows, int* w_stationary) {
+    try {
+        GemmArgs g{};
+        g.epi = epi; g.N = N; g.weights_on_rows = weights_on_rows;
+        if (conv3x3) {
+            int side = 1; while (side * side < rows_per_stream) ++side;
+            if (side * side != rows_per_stream) return -2;                      // square maps only in this query
+            g.mode = A_CONV3; g.Cin = K_or_Cin; g.K = 9 * K_or_Cin; g.ldw = g.K; g.ldo = N;
+            g.Hin = g.Hout = g.Win = g.Wout = side; g.rows_per_batch = rows_per_stream; g.M = streams * rows_per_stream;
+        } else {
+            g.mode = A_DENSE; g.K = K_or_Cin; g.lda = g.K; g.ldw = g.K; g.rows_per_stream = rows_per_stream;
+            if (weights_on_rows) { g.M = N; g.N = streams * rows_per_stream; } else g.M = streams * rows_per_stream;
+        }
+        int ws = 0;
+        const int v = gemm16_pick(g, weights_on_rows, &ws);
+        if (w_stationary) *w_stationary = ws;
+        return v;
+    } catch (...) { return -3; }
+}
 // One tile variant of the 16x16x32 family (csrc/gemm16.hip) on a dense problem - tests and micro-benchmarks; rt_op_gemm picks by shape.
 int rt_op_gemm16_variant(const void* A, const void* W, const float* bias, void* out, const void* res, int epi, int M, int N, int K, int lda,
                          int ldw, int ldo, int ldres, int weights_on_rows, int variant, int wstat, void* stream) {

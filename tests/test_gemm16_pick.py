@@ -1,0 +1,55 @@
+"""Host logic of the GEMM tile rule (csrc/gemm16.hip::gemm16_pick through rt_op_gemm16_pick; no GPU): the summation class is a pure function
+of ONE stream's shape - never of the batch - which is what makes a stream computed alone and inside a batch give the same bits
+(DESIGN 4.7), and the routing decisions DESIGN quotes for the SDXL / SD-v1.5 shapes."""
+import ctypes as C
+
+import pytest
+
+from rich_text_to_image_amd.engine import load_library
+
+EPI_BF16, EPI_F32, EPI_TEMB, EPI_GEGLU, EPI_F16 = 0, 1, 2, 3, 4
+
+
+@pytest.fixture(scope="module")
+def pick():
+    lib = load_library()
+
+    def f(conv, epi, streams, rps, N, K, vt=0):
+        ws = C.c_int(0)
+        v = lib.rt_op_gemm16_pick(conv, epi, streams, rps, N, K, vt, C.byref(ws))
+        return v, ws.value
+    return f
+
+
+def test_variant_never_depends_on_the_number_of_streams(pick):
+    shapes = [(0, EPI_F16, 1024, 1280, 1280), (0, EPI_F16, 1024, 1280, 5120), (0, EPI_BF16, 1024, 2560, 1280), (0, EPI_GEGLU, 1024, 10240, 1280),
+              (0, EPI_GEGLU, 4096, 5120, 640), (0, EPI_F16, 4096, 640, 640), (0, EPI_BF16, 4096, 1280, 640), (0, EPI_BF16, 256, 1280, 1280),
+              (1, EPI_TEMB, 1024, 1280, 1280), (1, EPI_F16, 4096, 640, 640), (1, EPI_F16, 16384, 320, 320), (1, EPI_TEMB, 1024, 640, 320)]
+    # what must not move is the CLASS (summation order): A = one ascending sum over k (variants 2, 3, 4, 5, 8: bit-identical with each
+    # other and with gemm.hip), B = K-split (0, 1), B^T (6, 7), or "not in the family"; inside a class the tile follows the actual M
+    cls = {-1: "none", 0: "B", 1: "B", 2: "A", 3: "A", 4: "A", 5: "A", 8: "A", 6: "BT", 7: "BT"}
+    for conv, epi, rps, N, K in shapes:
+        got = {cls[pick(conv, epi, s, rps, N, K)[0]] for s in (1, 2, 3, 5, 7, 8)}
+        assert len(got) == 1, (conv, epi, rps, N, K, got)
+
+
+def test_sdxl_step_shapes_take_the_documented_classes(pick):
+    assert pick(0, EPI_F16, 7, 1024, 1280, 1280)[0] == 0            # to_out / to_q at 1280 channels: K-split class B, 224x160
+    assert pick(0, EPI_F16, 7, 1024, 1280, 5120)[0] == 0            # ff.net.2
+    assert pick(0, EPI_BF16, 7, 1024, 2560, 1280)[0] == 4           # stacked Q|K: class A, 224x320
+    assert pick(0, EPI_GEGLU, 7, 1024, 10240, 1280) == (2, 1)       # GEGLU: 224x256, W-stationary tile order (40 column tiles)
+    assert pick(0, EPI_GEGLU, 7, 4096, 5120, 640)[1] == 0           # 20 column tiles do not divide over 8 XCDs: grouped order
+    assert pick(0, EPI_F16, 7, 4096, 640, 640)[0] == 4              # the 640-channel level fills the chip per stream on 320-wide tiles
+    assert pick(0, EPI_BF16, 7, 1024, 1280, 1280, vt=1)[0] in (6, 7)   # V^T = W_v X^T: transposed K-split class
+    assert pick(0, EPI_BF16, 7, 64, 1280, 1280)[0] == -1            # 8x8 maps stay on gemm.hip (128x128 tiles / split-K)
+    assert pick(0, EPI_BF16, 7, 1024, 1280, 320)[0] == -1           # K % 128 != 0
+
+
+def test_convolutions_only_where_one_image_contributes_enough_tiles(pick):
+    assert pick(1, EPI_TEMB, 7, 1024, 1280, 1280)[0] == 0           # SDXL 32^2 x 1280 -> 1280: 5 x 8 = 40 tiles per image
+    assert pick(1, EPI_F16, 7, 4096, 640, 640)[0] == 4              # SDXL 64^2: 19 x 2 = 38
+    assert pick(1, EPI_F16, 7, 16384, 320, 320)[0] == 4             # SDXL 128^2: 74
+    assert pick(1, EPI_TEMB, 3, 1024, 640, 640)[0] == -1            # SD-v1.5 32^2 x 640: 5 x 4 = 20 tiles per image -> patch kernel
+    assert pick(1, EPI_TEMB, 3, 256, 1280, 1280)[0] == -1           # SD-v1.5 16^2
+    assert pick(1, EPI_F32, 1, 4096, 512, 512)[0] == 2              # a 64^2 x 512 VAE layer passes the rule (38 tiles); the single-image VAE
+    #                                                                 opts out on its own through GemmArgs.prefer_patch_conv (vae.hip)
