@@ -118,9 +118,13 @@ int rt_attn_module_info(rt_engine* e, int idx, char* name, int name_cap, int* ma
 /* per-launch HIP-event timing of the MFMA kernels on the engine's stream (bench.py roofline leg).
  * Algorithmic FLOPs are counted per launch (2*M*N*K for GEMM/conv, 4*B*H*N*NK*d for attention; padded
  * head dims / keys are not counted). */
-enum { RT_PROF_GEMM_DENSE = 0, RT_PROF_GEMM_CONV = 1, RT_PROF_ATTN_SELF = 2, RT_PROF_ATTN_CROSS = 3 };
+enum { RT_PROF_GEMM_DENSE = 0, RT_PROF_GEMM_CONV = 1, RT_PROF_ATTN_SELF = 2, RT_PROF_ATTN_CROSS = 3,
+       RT_PROF_ATTN_STORE = 4 /* head-averaged map accumulation of the plain pass (attn_store_kernel, HBM-side accumulators) */ };
 int rt_profile_enable(rt_engine* e, int on);     /* on: start recording (clears old records); off: stop */
 int rt_profile_read(rt_engine* e, int kernel_class, int* count, double* total_ms, double* total_flops);
+/* as rt_profile_read, plus the ALGORITHMIC HBM bytes of the launches (attention store: the fp32 accumulator read + written once and the
+ * Q / K rows of the recorded stream read once; 0 for the classes that are priced in FLOPs) */
+int rt_profile_read2(rt_engine* e, int kernel_class, int* count, double* total_ms, double* total_flops, double* total_bytes);
 
 /* operator level (parity tests, AttnProcessor / unet(...) seams; unet_2d_condition.py:703-717) ------------ */
 /* x [B,4,h,w] f32 NCHW; per-stream: input scale, prompt index, font-size flag, self-attention Q/K source
@@ -161,7 +165,10 @@ int rt_op_gemm16_variant(const void* A, const void* W, const float* bias, void* 
  * kcache bf16 [P*96, H*DP], vtcache bf16 [H*DP, ldvt] (77 keys padded to 96 per prompt); prompt_host / wset_host: per batch entry the
  * prompt index and the multiplier set in wabs / wsgn [nsets, 96] (the engine's tables: 0 plain softmax, 1 font-size), or -1 = plain softmax
  * over the 77 valid keys without reading the tables (what the engine passes for every stream without a font-size entry: identical bits,
- * fewer instructions); q_scratch, o_scratch bf16 [B*N, H*DP]. */
+ * fewer instructions); q_scratch, o_scratch bf16 [B*N, H*DP].
+ * Launches: where the tiling allows it (DP = 64, H*64 % 320 == 0, N % 128 == 0, C % 64 == 0: the 1280-channel level of SDXL, 60 of its 70
+ * blocks) to_q and the attention are ONE kernel (csrc/gemm16.hip, EPI_XATTN: a 128 x 320 tile = 128 queries x 5 heads stays in LDS,
+ * q_scratch is not written) followed by the to_out GEMM; otherwise to_q GEMM -> attention -> to_out GEMM. */
 int rt_op_cross_attn_block(const void* x, const void* wq, const void* wo, const float* bo, const void* kcache, const void* vtcache, int ldvt,
                            const int* prompt_host, const int* wset_host, const float* wabs, const float* wsgn, const void* trunk_in_f16,
                            void* trunk_out_f16, void* q_scratch, void* o_scratch, int B, int N, int C, int H, int DP, void* stream);
@@ -197,7 +204,7 @@ const char* rt_op_last_error(void);
 int rt_op_gemm_force_config(int cfg);
 /* A/B switches (benchmarks; the engine wrapper reads RTDIFF_DEBUG_FLAGS once at load): bit 0 patch-eligible 3x3 convs through the
  * implicit-GEMM kernels; bit 1 keep gemm16.hip out; bit 2 no split-K; bit 3 stride-1 3x3 convs stay on the patch kernel (not on the
- * gemm16 main loop) */
+ * gemm16 main loop); bit 4 cross-attention as to_q GEMM + attention launch instead of the fused kernel */
 int rt_op_gemm_debug(int flags);
 
 /* ---- VAE decoder: colour guidance (rd.py:151-168, xl.py:849-867) and plain decode (rd.py:227-236) ----

@@ -123,11 +123,14 @@ def vae_config(path, default):
     return cfg
 
 
-def load_text_encoder(path, device=0, with_projection=False):
+def load_text_encoder(path, device=0, with_projection=False, weights=True):
     """CLIP text encoder directory (config.json + safetensors) -> HipCLIPTextEncoder (GEMMs / LayerNorm / causal attention on the
-    engine's operators; no transformers model is instantiated)."""
-    from .clip_text_encoder import HipCLIPTextEncoder
-    return HipCLIPTextEncoder(load_state_dict_dir(path), _component_config(path), device=device, with_projection=with_projection)
+    engine's operators; no transformers model is instantiated).  weights=False: the same object from config.json alone with
+    zero-filled parameters of the right shapes - a rank that receives them through launcher.broadcast_pipeline."""
+    from .clip_text_encoder import HipCLIPTextEncoder, empty_state_dict
+    cfg = _component_config(path)
+    sd = load_state_dict_dir(path) if weights else empty_state_dict(cfg, with_projection)
+    return HipCLIPTextEncoder(sd, cfg, device=device, with_projection=with_projection)
 
 
 DEFAULT_REPO = {"SD": "runwayml/stable-diffusion-v1-5", "SDXL": "stabilityai/stable-diffusion-xl-base-1.0"}
@@ -163,15 +166,17 @@ def resolve_checkpoint(name_or_path, kind="SD"):
                             f". Pass a local directory (unet/, vae/, tokenizer*/, text_encoder*/) or set ${ENV_OVERRIDE[kind]}.")
 
 
-def load_components(load_path, kind="SD", device=0, latent_hw=None, lora_path=None, lora_scale=1.0):
+def load_components(load_path, kind="SD", device=0, latent_hw=None, lora_path=None, lora_scale=1.0, weights=True):
     """Everything the facade constructors need from a diffusers-layout directory (unet/, vae/, tokenizer[_2]/, text_encoder[_2]/) as
     keyword arguments of RegionDiffusion / RegionDiffusionXL.  `latent_hw` sizes the VAE plan (default: the model's native size).
-    `lora_path`: a LoRA .safetensors file merged into the UNet weights before they are bound (lora.merge_lora)."""
+    `lora_path`: a LoRA .safetensors file merged into the UNet weights before they are bound (lora.merge_lora).
+    weights=False (seed-parallel ranks != 0, sample.py --gpus N): only the config / tokenizer files are read; the UNet arena, the VAE
+    arena and the text-encoder parameters stay zero until launcher.broadcast_pipeline delivers rank 0's."""
     from .engine import SD15_CONFIG, SD_VAE_CONFIG, SDXL_CONFIG, SDXL_VAE_CONFIG, VaeDecoder
     dev = torch.device(f"cuda:{device}")
-    unet_sd = load_state_dict_dir(os.path.join(load_path, "unet"))
-    vae_sd = load_state_dict_dir(os.path.join(load_path, "vae"))
-    if lora_path:
+    unet_sd = load_state_dict_dir(os.path.join(load_path, "unet")) if weights else "empty"
+    vae_sd = load_state_dict_dir(os.path.join(load_path, "vae")) if weights else None
+    if lora_path and weights:
         from safetensors.torch import load_file
         from .lora import merge_lora
         unet_sd, _ = merge_lora(unet_sd, load_file(lora_path), lora_scale)
@@ -181,11 +186,11 @@ def load_components(load_path, kind="SD", device=0, latent_hw=None, lora_path=No
     vae = VaeDecoder(vae_cfg, hw[0], hw[1], device=device, state_dict=vae_sd, precise=(kind == "SDXL"))   # xl.py:856 / :918-938: fp32 VAE
     tok = ClipBPETokenizer.from_pretrained(load_path, "tokenizer")
     if kind == "SD":
-        enc = load_text_encoder(os.path.join(load_path, "text_encoder"), device)
+        enc = load_text_encoder(os.path.join(load_path, "text_encoder"), device, weights=weights)
         return dict(unet_state_dict=unet_sd, config=unet_cfg, vae=vae, tokenizer=tok, text_encoder=ClipEncoderSD(enc, dev))
     tok2 = ClipBPETokenizer.from_pretrained(load_path, "tokenizer_2")
-    enc1 = load_text_encoder(os.path.join(load_path, "text_encoder"), device)
-    enc2 = load_text_encoder(os.path.join(load_path, "text_encoder_2"), device, with_projection=True)
+    enc1 = load_text_encoder(os.path.join(load_path, "text_encoder"), device, weights=weights)
+    enc2 = load_text_encoder(os.path.join(load_path, "text_encoder_2"), device, with_projection=True, weights=weights)
     fz = True
     mi = os.path.join(load_path, "model_index.json")
     if os.path.exists(mi):

@@ -19,6 +19,29 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+def empty_state_dict(config, with_projection=False, vocab_size=None):
+    """Zero tensors under the transformers CLIPTextModel[WithProjection] key names with the shapes `config` implies: what a rank that
+    receives the weights by broadcast constructs its encoder from (launcher.broadcast_pipeline needs equal shapes on every rank)."""
+    g = (lambda k, d=None: config.get(k, d)) if isinstance(config, dict) else (lambda k, d=None: getattr(config, k, d))
+    Cc, L, I, N = g("hidden_size"), g("num_hidden_layers"), g("intermediate_size"), g("max_position_embeddings", 77)
+    V = vocab_size or g("vocab_size", 49408)
+    z = lambda *s: torch.zeros(*s)
+    sd = {"text_model.embeddings.token_embedding.weight": z(V, Cc), "text_model.embeddings.position_embedding.weight": z(N, Cc),
+          "text_model.final_layer_norm.weight": z(Cc), "text_model.final_layer_norm.bias": z(Cc)}
+    for i in range(L):
+        q = f"text_model.encoder.layers.{i}."
+        for n in "qkv":
+            sd[q + f"self_attn.{n}_proj.weight"], sd[q + f"self_attn.{n}_proj.bias"] = z(Cc, Cc), z(Cc)
+        sd[q + "self_attn.out_proj.weight"], sd[q + "self_attn.out_proj.bias"] = z(Cc, Cc), z(Cc)
+        for n in ("layer_norm1", "layer_norm2"):
+            sd[q + n + ".weight"], sd[q + n + ".bias"] = z(Cc), z(Cc)
+        sd[q + "mlp.fc1.weight"], sd[q + "mlp.fc1.bias"] = z(I, Cc), z(I)
+        sd[q + "mlp.fc2.weight"], sd[q + "mlp.fc2.bias"] = z(Cc, I), z(Cc)
+    if with_projection:
+        sd["text_projection.weight"] = z(g("projection_dim", Cc), Cc)
+    return sd
+
+
 class HipCLIPTextEncoder:
     def __init__(self, state_dict, config, device=0, with_projection=False):
         """config: transformers CLIPTextConfig or a dict with hidden_size, num_attention_heads, num_hidden_layers, intermediate_size,

@@ -105,8 +105,10 @@ static __device__ __forceinline__ void glds16_buf(const void* base, int voff_byt
 
 // ---------------------------------------------------------------- GEMM / implicit-GEMM conv
 enum { A_DENSE = 0, A_CONV3 = 1, A_CONV3_S2 = 2, A_CONV3_UP2 = 3 };
-enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_BF16_TEMB = 2, EPI_GEGLU = 3, EPI_F16 = 4 };   // EPI_F16: fp16 output (+ fp16 residual): the UNet trunk
+enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_BF16_TEMB = 2, EPI_GEGLU = 3, EPI_F16 = 4,   // EPI_F16: fp16 output (+ fp16 residual): the UNet trunk
+       EPI_XATTN = 5 };   // gemm16.hip only: the to_q projection whose tile never leaves the CU - 77-key cross-attention on it, O written (launch_xattn_fused)
 typedef _Float16 f16_t;
+#define RT_MAXB 16
 
 struct GemmArgs {
     const bf16_t* A;   // dense: [M, lda]; conv: NHWC input [B, Hin, Win, Cin]
@@ -132,11 +134,24 @@ struct GemmArgs {
     int split_tiles;                 // 128x128 output tiles of ONE batch entry's share of the problem (0: unknown).  The split-K rule
                                      // uses it instead of the actual tile count, so a stream's result does not depend on how many
                                      // other streams share the launch (batch invariance); see splitk_slices in gemm.hip
+    // EPI_XATTN (launch_xattn_fused): A = LayerNorm'd tokens [B * xa_tokens, K], W = packed to_q [H * 64, K] (pre-scaled by
+    // d^-1/2 log2 e), out = attention output O [M, ldo] bf16.  K / V^T: the per-prompt cross-attention cache (AttnArgs layout).
+    const bf16_t* xa_k; const bf16_t* xa_vt;
+    int xa_ldk, xa_ldvt;
+    int xa_tokens;                   // query tokens per stream (multiple of 128: a 128-row tile never straddles two streams)
+    int xa_nk_valid;                 // keys >= xa_nk_valid of the 96 cached rows are masked (77)
+    const float* xa_wabs; const float* xa_wsgn;      // [nsets, 96] font-size multipliers (attention_processor.py:386-401)
+    int xa_prompt[RT_MAXB], xa_wset[RT_MAXB];        // per stream: prompt index into the cache, multiplier set (-1: plain softmax)
 };
+// Fused to_q -> 77-key cross-attention (one launch instead of two; Q never reaches HBM).  Eligible: head dim 64, H * 64 % 320 == 0,
+// tokens % 128 == 0, C % 64 == 0, C >= 192.
+bool xattn_fused_supported(int C, int H, int DP, int tokens);
+void launch_xattn_fused(const GemmArgs& a, hipStream_t st);
 void launch_gemm(const GemmArgs& a, hipStream_t st);
 size_t gemm_splitk_scratch_floats(const GemmArgs& a);   // fp32 partial sums launch_gemm needs for this problem (0: not split)
 void gemm_force_config(int cfg);   // -1: shape-based choice; 0..8: force a gemm.hip tile configuration (also keeps gemm16.hip out)
-void gemm_set_debug(int d);        // bit 0: eligible 3x3 convolutions through the implicit-GEMM kernels; bit 1: keep gemm16.hip out
+void gemm_set_debug(int d);        // bit 0: eligible 3x3 convolutions through the implicit-GEMM kernels; bit 1: keep gemm16.hip out; bit 4: no fused cross-attention
+bool gemm_xattn_enabled();         // the fused to_q + cross-attention kernel is allowed (debug bit 4 clear, gemm16 on, no forced configuration)
 // gemm16.hip: 16x16x32-MFMA family (224-row tiles, intra-tile K split); dense problems with K % 64 == 0 only
 #define RT_G16_NVAR 9
 bool gemm16_supported(const GemmArgs& a);
@@ -144,7 +159,6 @@ int gemm16_pick(const GemmArgs& a, int weights_on_rows, int* wstat);      // var
 void launch_gemm16_variant(const GemmArgs& a, int variant, int wstat, hipStream_t st);
 
 // ---------------------------------------------------------------- attention
-#define RT_MAXB 16
 struct AttnArgs {
     const bf16_t* Q;  int ldq;   // [*, ldq]  row (q_src[b]*N + n), head h at column h*DP; pre-scaled by d^-1/2 * log2(e)
     const bf16_t* K;  int ldk;   // [*, ldk]  row (k_src[b]*NK + key), head h at column h*DP

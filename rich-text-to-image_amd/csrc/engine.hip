@@ -13,6 +13,7 @@
 #include "common.h"
 #include "../../include/rtdiff.h"
 #include <map>
+#include <mutex>
 #include <vector>
 #include <string>
 #include <cmath>
@@ -188,12 +189,12 @@ struct rt_engine {
     int steps_done = 0;
 
     // optional per-launch HIP-event profiling of the MFMA kernels (bench.py roofline leg)
-    struct ProfRec { int cls; double flops; hipEvent_t a, b; };
+    struct ProfRec { int cls; double flops, bytes; hipEvent_t a, b; };
     bool profiling = false;
     std::vector<ProfRec> prof;
-    void prof_begin(int cls, double flops) {
+    void prof_begin(int cls, double flops, double bytes = 0.0) {
         if (!profiling) return;
-        ProfRec r; r.cls = cls; r.flops = flops;
+        ProfRec r; r.cls = cls; r.flops = flops; r.bytes = bytes;
         HIP_CHECK(hipEventCreate(&r.a)); HIP_CHECK(hipEventCreate(&r.b));
         HIP_CHECK(hipEventRecord(r.a, stream));
         prof.push_back(r);
@@ -536,13 +537,32 @@ struct rt_engine {
                         sa.K = qk + HD; sa.ldk = 2 * HD; sa.k_row0 = (long)in.store_stream * HW;
                         sa.out = k.store[0]; sa.H = t.heads; sa.N = HW; sa.NK = HW; sa.NKpad = HW; sa.NKrows = HW; sa.DP = t.DP;
                         sa.overwrite = k.store_mode[0] == 2;
+                        prof_begin(RT_PROF_ATTN_STORE, 2.0 * 2.0 * t.heads * (double)HW * HW * t.d, 8.0 * HW * HW + 2.0 * 2.0 * HW * HD);
                         launch_attn_store(sa, stream);
+                        prof_end();
                         k.store_rows[0] = HW; k.store_cols[0] = HW;
                     }
                 }
                 gemm(o, HD, k.out1, M, hcur, C, EPI_F16, hcur, C);
                 // --- attn2 (cross, K/V from the per-prompt cache; font-size softmax on flagged streams)
                 layernorm(hcur, k.ln2, n, M);
+                // to_q and the 77-key attention as ONE launch (gemm16.hip, EPI_XATTN: the Q tile stays in LDS) wherever the tiling
+                // allows it - a pure function of the layer's shape; the token-map capture of the plain pass reads Q from HBM and
+                // keeps the two-launch form for the layers it records
+                const bool capture2 = in.store_stream >= 0 && k.store_mode[1];
+                const bool fused2 = gemm_xattn_enabled() && xattn_fused_supported(C, t.heads, t.DP, HW) && !capture2;
+                if (fused2) {
+                    if (!dry()) {
+                        GemmArgs g{}; g.A = n; g.W = k.q2.w; g.out = o; g.zero = zero; g.mode = A_DENSE; g.epi = EPI_XATTN;
+                        g.M = M; g.N = HD; g.K = C; g.lda = C; g.ldw = k.q2.K; g.ldo = HD; g.rows_per_stream = HW;
+                        g.xa_k = k.kcache; g.xa_vt = k.vtcache; g.xa_ldk = HD; g.xa_ldvt = cfg.max_prompts * 96; g.xa_tokens = HW; g.xa_nk_valid = 77;
+                        g.xa_wabs = wabs; g.xa_wsgn = wsgn;
+                        for (int b = 0; b < B; ++b) { g.xa_prompt[b] = in.prompt[b]; g.xa_wset[b] = in.fontsize[b] ? 1 : -1; }
+                        prof_begin(RT_PROF_GEMM_DENSE, 2.0 * M * HD * C + 4.0 * B * t.heads * (double)HW * 77 * t.d);
+                        launch_xattn_fused(g, stream);
+                        prof_end();
+                    }
+                } else {
                 gemm(n, C, k.q2, M, qk, HD, EPI_BF16);
                 if (!dry()) {
                     AttnArgs a{}; a.Q = qk; a.ldq = HD; a.K = k.kcache; a.ldk = HD; a.VT = k.vtcache; a.ldvt = cfg.max_prompts * 96;
@@ -559,9 +579,12 @@ struct rt_engine {
                         sa.K = k.kcache; sa.ldk = HD; sa.k_row0 = (long)in.prompt[in.store_stream] * 96;
                         sa.out = k.store[1]; sa.H = t.heads; sa.N = HW; sa.NK = 77; sa.NKpad = 96; sa.NKrows = 96; sa.DP = t.DP;
                         sa.overwrite = k.store_mode[1] == 2;
+                        prof_begin(RT_PROF_ATTN_STORE, 2.0 * 2.0 * t.heads * (double)HW * 77 * t.d, 8.0 * HW * 77 + 2.0 * (HW + 96.0) * HD);
                         launch_attn_store(sa, stream);
+                        prof_end();
                         k.store_rows[1] = HW; k.store_cols[1] = 77;
                     }
+                }
                 }
                 gemm(o, HD, k.out2, M, hcur, C, EPI_F16, hcur, C);
                 // --- GEGLU feed-forward (attention.py:209-304)
@@ -1047,10 +1070,22 @@ int rt_profile_read(rt_engine* e, int cls, int* count, double* total_ms, double*
         *count = n; *total_ms = ms; *total_flops = fl;
     })
 }
+int rt_profile_read2(rt_engine* e, int cls, int* count, double* total_ms, double* total_flops, double* total_bytes) {
+    const int rc = rt_profile_read(e, cls, count, total_ms, total_flops);
+    if (rc != RT_OK) return rc;
+    double by = 0;
+    for (auto& r : e->prof) if (r.cls == cls) by += r.bytes;
+    *total_bytes = by;
+    return RT_OK;
+}
 
 // ---- operator-level entry points (stateless; share one lazily allocated zero page per device) ----
-static bf16_t* op_zero_page() {
-    static thread_local bf16_t* z = nullptr;
+static bf16_t* op_zero_page() {       // one page per DEVICE (a thread that drives two GPUs must not hand device-0 memory to device-1 kernels)
+    static std::mutex mu;
+    static std::map<int, bf16_t*> pages;
+    int dev = 0; HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    bf16_t*& z = pages[dev];
     if (!z) { HIP_CHECK(hipMalloc((void**)&z, 256)); HIP_CHECK(hipMemset(z, 0, 256)); }
     return z;
 }
@@ -1133,6 +1168,15 @@ int rt_op_cross_attn_block(const void* x, const void* wq, const void* wo, const 
         RT_REQUIRE(B >= 1 && B <= RT_MAXB && N > 0 && C % 8 == 0 && H > 0 && DP % 32 == 0, "rt_op_cross_attn_block: shape");
         hipStream_t st = (hipStream_t)stream;
         const int M = B * N, HD = H * DP;
+        if (gemm_xattn_enabled() && xattn_fused_supported(C, H, DP, N)) {
+            // the engine's path for these shapes: to_q + attention in one launch (Q stays in LDS; q_scratch is not written)
+            GemmArgs g{}; g.A = (const bf16_t*)x; g.W = (const bf16_t*)wq; g.out = o_scratch; g.zero = op_zero_page(); g.mode = A_DENSE; g.epi = EPI_XATTN;
+            g.M = M; g.N = HD; g.K = C; g.lda = C; g.ldw = C; g.ldo = HD; g.rows_per_stream = N;
+            g.xa_k = (const bf16_t*)kcache; g.xa_vt = (const bf16_t*)vtcache; g.xa_ldk = HD; g.xa_ldvt = ldvt; g.xa_tokens = N; g.xa_nk_valid = 77;
+            g.xa_wabs = wabs; g.xa_wsgn = wsgn;
+            for (int b = 0; b < B; ++b) { g.xa_prompt[b] = prompt_host ? prompt_host[b] : 0; g.xa_wset[b] = wset_host ? wset_host[b] : 0; }
+            launch_xattn_fused(g, st);
+        } else {
         GemmArgs g{}; g.A = (const bf16_t*)x; g.W = (const bf16_t*)wq; g.out = q_scratch; g.zero = op_zero_page(); g.mode = A_DENSE; g.epi = EPI_BF16;
         g.M = M; g.N = HD; g.K = C; g.lda = C; g.ldw = C; g.ldo = HD; g.rows_per_stream = N; g.split_tiles = cdiv(N, 128) * cdiv(HD, 128);
         launch_gemm(g, st);
@@ -1141,6 +1185,7 @@ int rt_op_cross_attn_block(const void* x, const void* wq, const void* wo, const 
         for (int b = 0; b < B; ++b) { a.q_src[b] = b; a.k_src[b] = prompt_host ? prompt_host[b] : 0; a.v_src[b] = a.k_src[b]; a.wset[b] = wset_host ? wset_host[b] : 0; }
         a.B = B; a.H = H; a.N = N; a.NK = 96; a.nk_valid = 77; a.DP = DP; a.cross = 1;
         launch_attention(a, st);
+        }
         GemmArgs o{}; o.A = (const bf16_t*)o_scratch; o.W = (const bf16_t*)wo; o.bias = bo; o.out = trunk_out; o.res = trunk_in; o.zero = op_zero_page();
         o.mode = A_DENSE; o.epi = EPI_F16; o.M = M; o.N = C; o.K = HD; o.lda = HD; o.ldw = HD; o.ldo = C; o.ldres = C; o.rows_per_stream = N;
         o.split_tiles = cdiv(N, 128) * cdiv(C, 128);

@@ -1213,14 +1213,18 @@ static int g_conv_patch = 1;
 static int g_use16 = 1;
 static int g_splitk = 1;
 static int g_conv16 = 1;
+static int g_xattn = 1;
 #ifdef RT_PROBE
 int g_conv3p_tn = 0;          // probe override of the patch kernel's column-tile count
 #endif
 // bit 0: route eligible convs through the implicit-GEMM kernels; bit 1: keep the 16x16x32 family (gemm16.hip) out (A/B tests)
 // bit 2: no split-K; bit 3: stride-1 3x3 convolutions stay on the patch kernel (conv3p_kernel) instead of gemm16.hip's implicit GEMM
+// bit 4: cross-attention as to_q GEMM + attention launch instead of the fused kernel (gemm16.hip, EPI_XATTN)
 void gemm_set_debug(int flags) {
     g_conv_patch = (flags & 1) ? 0 : 1; g_use16 = (flags & 2) ? 0 : 1; g_splitk = (flags & 4) ? 0 : 1; g_conv16 = (flags & 8) ? 0 : 1;
+    g_xattn = (flags & 16) ? 0 : 1;
 }
+bool gemm_xattn_enabled() { return g_xattn != 0 && g_use16 != 0 && g_force_cfg < 0; }
 
 template <int EPI, bool UP2, int TN>
 static void launch_conv3p_tn(const GemmArgs& a, int ntm, hipStream_t st) {

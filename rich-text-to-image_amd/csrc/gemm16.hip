@@ -44,6 +44,164 @@ __device__ long long g_g16_times[8192 * 8];
 
 #define RT_G16_OOB 0x7fff0000       // a voffset beyond every descriptor range used here: the lane's 16 bytes arrive as zeros
 
+// ---------------------------------------------------------------------------------------------- EPI_XATTN: fused to_q + cross-attention
+// The SDXL cross-attention block (models/attention.py:169-189, models/attention_processor.py:476-545, font-size softmax :386-401)
+// ran as to_q GEMM -> 96-key attention -> to_out GEMM; the attention launch does 2.8 GFLOP and is bound by reading Q and writing O
+// (18 + 18 MB per launch at 1024 tokens x 1280 channels x 7 streams, 18.6 us + a kernel boundary).  Here the to_q tile never leaves
+// the CU: a 128 x 320 output tile = 128 queries of ONE stream x 5 whole heads (d = 64), computed by the class-A main loop
+// (2(M) x 4(N) waves, 64 x 80 per wave), is written to LDS as bf16, and every wave then runs the 77-key attention of one 16-query
+// row tile, head after head, against K / V^T of the stream's prompt staged per head by LDS-DMA (requested before the last K tile of
+// the main loop, so the first two heads land behind it).  Swapped products as in attention.hip: S^T = K Q^T (a lane owns ONE query
+// and 24 of its 96 keys: the row statistics need two cross-lane steps), O^T = V^T P^T with P^T fed straight from the S^T
+// accumulators - the K rows of key tile j are staged in the order pi_j(i) = 32 (j/2) + 8 (i/4) + 4 (j%2) + i%4, which makes the
+// 8 accumulator values of a lane for key tiles (2s, 2s+1) the keys 32 s + 8 q4 + [0, 8): exactly the k slots of the 16x16x32 B
+// operand.  O replaces Q in LDS (same rows / columns, wave-private) and leaves in 16-B row-contiguous chunks.
+//
+// LDS map (163,840 B = all of it; ring = 2 x 57,344): Q / O tile [0, 83,968) (128 rows x 656 B: 16-B pad, conflict-free fragment
+// reads), K/V buffer C [83,968, 108,544), multiplier tables [108,544, 109,312), K/V buffers A, B [114,688, 163,840) (beyond the ring:
+// may be filled while the main loop still runs).  One K/V buffer = K [96 staged rows][128 B, XOR-swizzled slots] + V^T [12 key
+// chunks][64 d][16 B].
+#define XA_QS 656
+#define XA_KVA 114688
+#define XA_KVB 139264
+#define XA_KVC 83968
+#define XA_WTAB 108544
+#define XA_LDS 163840
+// (buffer-descriptor LDS-DMA: behind the flat global_load_lds form hipcc's waitcnt pass puts s_waitcnt vmcnt(0) in front of every
+// later LDS access, which would serialise the per-head prefetch)
+static __device__ __forceinline__ void xattn_stage_head(const GemmArgs& p, char* smem, int kvoff, int head, int prompt, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int pc = i * 8 + wave;                                 // wave-uniform piece id: 0..11 K rows, 12..23 V^T key chunks
+        if (pc < 12) {
+            const int rho = pc * 8 + (lane >> 3), pslot = lane & 7;  // staged row: key tile j = rho / 16, position i = rho % 16
+            const int j = rho >> 4, i16 = rho & 15;
+            const int key = 32 * (j >> 1) + 8 * (i16 >> 2) + 4 * (j & 1) + (i16 & 3);
+            const int swz = (rho >> 1) & 7;
+            glds16_buf(p.xa_k, ((prompt * 96 + key) * p.xa_ldk + head * 64 + ((pslot ^ swz) << 3)) * 2, 0, smem + kvoff + pc * 1024);
+        } else {
+            const int c = pc - 12;
+            glds16_buf(p.xa_vt, ((head * 64 + lane) * p.xa_ldvt + prompt * 96 + c * 8) * 2, 0, smem + kvoff + 12288 + c * 1024);
+        }
+    }
+}
+
+// One (16-query row tile, head) unit of a wave.  qrow = first LDS row of the tile, hcol = byte column of the head inside the Q tile.
+template <bool FS>
+static __device__ __forceinline__ void xattn_unit(char* smem, int kvoff, int qrow, int hcol, int nk_valid, int lane) {
+    const int l15 = lane & 15, q4 = lane >> 4;
+    char* qp = smem + (qrow + l15) * XA_QS + hcol;
+    const bf16x8 qf0 = *(const bf16x8*)(qp + q4 * 16), qf1 = *(const bf16x8*)(qp + 64 + q4 * 16);
+    const char* kp = smem + kvoff + l15 * 128;
+    const int swz = (l15 >> 1) & 7;
+    const int o0 = ((q4 ^ swz) << 4), o1 = (((4 + q4) ^ swz) << 4);
+    f32x4_t s[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        s[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(kp + j * 2048 + o0), qf0, s[j], 0, 0, 0);
+        s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(kp + j * 2048 + o1), qf1, s[j], 0, 0, 0);
+    }
+    // softmax over the 96 (77 valid) keys of the lane's query: 24 values here, the rest in lanes l15 + 16 {1, 2, 3}
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = 32 * (j >> 1) + 8 * q4 + 4 * (j & 1) + r;
+            if (32 * (j >> 1) + 32 > nk_valid) { if (key >= nk_valid) s[j][r] = -INFINITY; }      // uniform test first
+            mx = fmaxf(mx, s[j][r]);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+    const float* wt = (const float*)(smem + XA_WTAB);
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float e = __builtin_amdgcn_exp2f(s[j][r] - mx);           // Q carries d^-1/2 log2 e
+            if constexpr (FS) {                                       // e_k = exp(s_k - max) |fs_k|, p_k = sign(fs_k) e_k / sum e
+                const int key = 32 * (j >> 1) + 8 * q4 + 4 * (j & 1) + r;
+                e *= wt[key];
+                sum += e;
+                e *= wt[96 + key];
+            } else sum += e;
+            s[j][r] = e;
+        }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.f / sum;
+    // O^T = V^T P^T: three 32-key steps, four 16-row d tiles
+    f32x4_t o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const char* vp = smem + kvoff + 12288 + (q4 * 64 + l15) * 16;
+#pragma unroll
+    for (int st = 0; st < 3; ++st) {
+        union { uint32_t u[4]; bf16x8 v; } pf;
+        pf.u[0] = pack_bf16x2(s[2 * st][0], s[2 * st][1]); pf.u[1] = pack_bf16x2(s[2 * st][2], s[2 * st][3]);
+        pf.u[2] = pack_bf16x2(s[2 * st + 1][0], s[2 * st + 1][1]); pf.u[3] = pack_bf16x2(s[2 * st + 1][2], s[2 * st + 1][3]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(vp + st * 4096 + dt * 256), pf.v, o[dt], 0, 0, 0);
+    }
+    // O over Q (the unit's own rows / columns; its Q fragments are in registers)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        uint2 w; w.x = pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv); w.y = pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv);
+        *(uint2*)(qp + (dt * 16 + 4 * q4) * 2) = w;
+    }
+}
+
+template <int TMW, int TNW, int WN>
+static __device__ __forceinline__ void xattn_tail(const GemmArgs& p, char* smem, f32x4_t (&acc)[TMW][TNW], int m0, int n0, int wm, int wn,
+                                                  int wave, int lane, int tid, int prompt, int head0, int wset) {
+    static_assert(TMW == 4 && TNW == 5 && WN == 4, "128 x 320 tile, 2 x 4 waves");
+    const int l15 = lane & 15, q4 = lane >> 4;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                    // every wave left the ring
+    // Q tile -> LDS (bf16): lane (l15, q4) holds row l15 and columns 4 q4 .. +3 of every 16 x 16 tile
+#pragma unroll
+    for (int i = 0; i < TMW; ++i)
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) {
+            uint2 w; w.x = pack_bf16x2(acc[i][j][0], acc[i][j][1]); w.y = pack_bf16x2(acc[i][j][2], acc[i][j][3]);
+            *(uint2*)(smem + (wm * 64 + i * 16 + l15) * XA_QS + (wn * 80 + j * 16 + 4 * q4) * 2) = w;
+        }
+    xattn_stage_head(p, smem, XA_KVC, head0 + 2, prompt, wave, lane);
+    const bool fs = wset >= 0;                                       // workgroup-uniform
+    if (fs && tid < 96) {
+        float* wt = (float*)(smem + XA_WTAB);
+        wt[tid] = p.xa_wabs[wset * 96 + tid];
+        wt[96 + tid] = p.xa_wsgn[wset * 96 + tid];
+    }
+    const int qrow = wave * 16;
+    // phase h: every wave does (its row tile, head h).  K/V pieces retire in issue order: heads 0, 1 (main loop), 2 (above), 3, 4.
+#define XA_PHASE(H_, KV_, BEHIND_, REFILL_HEAD_, REFILL_KV_)                                                          \
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(BEHIND_) : "memory");                           \
+    __builtin_amdgcn_s_barrier();                                                                                     \
+    if (REFILL_HEAD_ >= 0) xattn_stage_head(p, smem, REFILL_KV_, head0 + (REFILL_HEAD_ < 0 ? 0 : REFILL_HEAD_), prompt, wave, lane); \
+    if (fs) xattn_unit<true>(smem, KV_, qrow, (H_) * 128, p.xa_nk_valid, lane);                                       \
+    else xattn_unit<false>(smem, KV_, qrow, (H_) * 128, p.xa_nk_valid, lane);
+    XA_PHASE(0, XA_KVA, 6, -1, 0)
+    XA_PHASE(1, XA_KVB, 3, 3, XA_KVA)
+    XA_PHASE(2, XA_KVC, 3, 4, XA_KVB)
+    XA_PHASE(3, XA_KVA, 3, -1, 0)
+    XA_PHASE(4, XA_KVB, 0, -1, 0)
+#undef XA_PHASE
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // O tile -> HBM: 128 rows x 40 chunks of 16 B
+#pragma unroll
+    for (int it = 0; it < 10; ++it) {
+        const int id = it * 512 + tid;
+        const int r = id / 40, ch = id - r * 40;
+        if (m0 + r < p.M)
+            *(uint4*)((bf16_t*)p.out + (size_t)(m0 + r) * p.ldo + n0 + ch * 8) = *(const uint4*)(smem + r * XA_QS + ch * 16);
+    }
+}
+
 // MODE = A_CONV3: 3x3 stride-1 pad-1 convolution as an implicit GEMM on the SAME main loop (M = pixels of the NHWC activation,
 // K tile t = (tap t / nch, 64-channel chunk t % nch), weights packed [Cout][tap][Cin] as everywhere else): only the A loader differs -
 // the lane's pixel address shifted by the tap, with the padding taps sent out of the descriptor's range so that they read as zeros.
@@ -88,6 +246,10 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void gemm16_kernel(GemmArgs p, i
         tm = first_m + (bid % gsz) % gm; tn = (bid % gsz) / gm;
     }
     const int m0 = tm * BM, n0 = tn * BN;
+    // EPI_XATTN: the tile's stream (a 128-row tile never straddles: xa_tokens % 128 == 0), its prompt / multiplier set, first head
+    const int xa_b = EPI == EPI_XATTN ? m0 / p.xa_tokens : 0;
+    const int xa_prompt = EPI == EPI_XATTN ? p.xa_prompt[xa_b] : 0, xa_wset = EPI == EPI_XATTN ? p.xa_wset[xa_b] : -1;
+    const int xa_head0 = n0 >> 6;
 
     // ---- loader: piece i of this wave copies 8-row group g = i*NW + wave of the (A rows | W rows) list.  Buffer-descriptor LDS-DMA
     // (buffer_load_dwordx4 ... offen lds, guide T8): per piece ONE 32-bit VGPR byte offset, the K-tile offset is a scalar (soffset)
@@ -261,10 +423,20 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void gemm16_kernel(GemmArgs p, i
         }
         kstep(t, cur_off, nxt_off, C0{}, C0{}, C1{}, C0{}, C0{});                        // t = nk-2
         kstep(t, cur_off, nxt_off, C1{}, C1{}, C2{}, C0{}, C0{}); advance(); ++t;
+        if constexpr (EPI == EPI_XATTN) {
+            // nothing of the ring is in flight any more: K / V^T of the tile's first two heads, into the LDS beyond the ring,
+            // land behind the last K tile's MFMAs
+            xattn_stage_head(p, smem, XA_KVA, xa_head0, xa_prompt, wave, lane);
+            xattn_stage_head(p, smem, XA_KVB, xa_head0 + 1, xa_prompt, wave, lane);
+        }
         kstep(t, cur_off, nxt_off, C0{}, C0{}, C1{}, C0{}, C0{});                        // t = nk-1
         kstep(t, cur_off, nxt_off, C1{}, C1{}, C0{}, C0{}, C0{});
     }
     G16_T(2)
+    if constexpr (EPI == EPI_XATTN) {
+        xattn_tail<TMW, TNW, WN>(p, smem, acc, m0, n0, wm, wn, wave, lane, tid, xa_prompt, xa_head0, xa_wset);
+        return;
+    }
 
     // ---- which 16-row tiles this wave finishes: K-split: kh = 0 owns row tiles [0, H0), kh = 1 owns [H0, TMW)
     constexpr int H0 = WK == 2 ? (TMW + 1) / 2 : TMW;
@@ -525,6 +697,24 @@ static void launch_e(const GemmArgs& a, int v, int wstat, hipStream_t st) {
         }
     }
     throw rt_error(RT_E_INVALID, "gemm16: variant cannot run this operand mode / epilogue");
+}
+
+bool xattn_fused_supported(int C, int H, int DP, int tokens) {
+    return DP == 64 && (H * 64) % 320 == 0 && tokens > 0 && tokens % 128 == 0 && C % BK16 == 0 && C >= 3 * BK16;
+}
+void launch_xattn_fused(const GemmArgs& a, hipStream_t st) {
+    RT_REQUIRE(a.mode == A_DENSE && a.epi == EPI_XATTN && a.N % 320 == 0 && a.K % BK16 == 0 && a.K >= 3 * BK16 && a.lda % 8 == 0 && a.ldw % 8 == 0 &&
+               a.ldo % 8 == 0, "xattn: shape");
+    RT_REQUIRE(a.xa_tokens > 0 && a.xa_tokens % 128 == 0 && a.M % a.xa_tokens == 0 && a.M / a.xa_tokens <= RT_MAXB, "xattn: tokens per stream must be a multiple of 128");
+    RT_REQUIRE(a.xa_k && a.xa_vt && a.xa_ldk % 8 == 0 && a.xa_ldvt % 8 == 0 && a.xa_nk_valid > 0 && a.xa_nk_valid <= 96, "xattn: K / V^T cache");
+    RT_REQUIRE((long)a.M * a.lda * 2 < 0x7fffffffL && (long)a.N * a.ldw * 2 < 0x7fffffffL, "xattn: operand beyond the 2 GiB descriptor range");
+    for (int b = 0; b < a.M / a.xa_tokens; ++b) RT_REQUIRE(a.xa_wset[b] < 0 || (a.xa_wabs && a.xa_wsgn), "xattn: multiplier tables");
+    using K = void (*)(GemmArgs, int);
+    K kern = gemm16_kernel<A_DENSE, EPI_XATTN, 4, 5, 2, 4, 1, 2>;
+    static bool attr = false;
+    if (!attr) { HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS)); attr = true; }
+    hipLaunchKernelGGL(kern, dim3(cdiv(a.M, 128) * (a.N / 320)), dim3(512), XA_LDS, st, a, 0);
+    HIP_CHECK(hipGetLastError());
 }
 
 static bool conv16_geometry(const GemmArgs& a) {

@@ -70,7 +70,7 @@ _SYMBOLS = [
     "rt_attn_store_read", "rt_attn_module_count", "rt_attn_module_info", "rt_get_state_ptrs", "rt_background_blend", "rt_vae_create", "rt_vae_destroy",
     "rt_vae_last_error", "rt_vae_weight_count", "rt_vae_weight_info", "rt_vae_bind_weight", "rt_vae_synchronize", "rt_vae_decode",
     "rt_vae_color_guidance", "rt_vae_arena_info", "rt_vae_arena_mark_bound", "rt_op_cast_bf16", "rt_op_attention_probs_avg", "rt_op_embed", "rt_op_activation", "rt_op_causal_attention",
-    "rt_op_cross_attn_block", "rt_op_gemm16_variant", "rt_op_gemm16_pick",
+    "rt_op_cross_attn_block", "rt_op_gemm16_variant", "rt_op_gemm16_pick", "rt_profile_read2",
 ]
 
 
@@ -311,6 +311,12 @@ class Engine:
 
     # ---- profiling (HIP events around every MFMA kernel launch on the engine stream)
     PROF_CLASSES = {0: "gemm_kernel<A_DENSE>", 1: "gemm_kernel<A_CONV3*>", 2: "attn_kernel<self>", 3: "attn_kernel<cross>"}
+    PROF_STORE = 4          # attn_store_kernel (plain pass, token-map capture): priced in algorithmic HBM bytes
+
+    def profile_read_store(self):
+        n, ms, fl, by = C.c_int(), C.c_double(), C.c_double(), C.c_double()
+        self._chk(self.lib.rt_profile_read2(self.h, self.PROF_STORE, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)))
+        return dict(launches=n.value, total_ms=ms.value, total_flops=fl.value, total_bytes=by.value)
 
     def profile_enable(self, on=True):
         self._chk(self.lib.rt_profile_enable(self.h, int(on)))

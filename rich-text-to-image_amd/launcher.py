@@ -34,12 +34,12 @@ def free_port():
         return s.getsockname()[1]
 
 
-def self_launch(script, argv, nproc, require_gpus=True):
+def self_launch(script, argv, nproc, require_gpus=True, module=None):
     """`python bench.py --gpus N` without a wrapper: when no torch.distributed.run environment is present (WORLD_SIZE unset) and
     N > 1, replace this process by `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
     --master-port P script argv...` - one rank per GPU, LOCAL_RANK selects the device.  Returns None when nothing has to be done
     (N == 1 or already inside a launch); returns an error string when the box has fewer than N GPUs (the caller reports it);
-    otherwise does not return."""
+    otherwise does not return.  `module`: launch `python -m <module>` instead of a script path."""
     import sys
     if nproc <= 1 or "WORLD_SIZE" in os.environ:
         return None
@@ -50,8 +50,10 @@ def self_launch(script, argv, nproc, require_gpus=True):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes fails without it on this driver
     env.setdefault("OMP_NUM_THREADS", "8")
+    # module: `python -m pkg.mod` programs (sample.py uses relative imports) are launched as torchrun's --module form
+    target = ["--module", module] if module else [script]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
-           "--master-port", str(env.get("MASTER_PORT") or free_port()), script] + list(argv)
+           "--master-port", str(env.get("MASTER_PORT") or free_port())] + target + list(argv)
     sys.stdout.flush(); sys.stderr.flush()
     os.execvpe(cmd[0], cmd, env)
 
@@ -69,9 +71,17 @@ class _DevicePointer:
 
 
 def arena_tensor(engine):
-    """Packed weight arena of an Engine or a VaeDecoder as a flat uint8 tensor (no copy)."""
+    """Packed weight arena of an Engine or a VaeDecoder as a flat uint8 tensor (no copy).  Objects that already hold their arena as a
+    tensor (`arena_as_tensor()`: the CPU stand-ins of tests/test_distributed_cpu.py) hand it over directly."""
+    if hasattr(engine, "arena_as_tensor"):
+        return engine.arena_as_tensor()
     ptr, nbytes = engine.arena()
     return torch.as_tensor(_DevicePointer(ptr, nbytes), device=f"cuda:{engine.device}")
+
+
+def _cuda_sync():
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
 
 
 LAST_BROADCAST_CALLS = 0      # dist.broadcast calls issued by the last broadcast_weights / broadcast_pipeline (bench line)
@@ -125,11 +135,11 @@ def broadcast_weights(engine, src=0):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return 0.0
     import time
-    torch.cuda.synchronize()
+    _cuda_sync()
     t0 = time.perf_counter()
     engine.synchronize()
     LAST_BROADCAST_CALLS = broadcast_tensor(arena_tensor(engine), src)
-    torch.cuda.synchronize()
+    _cuda_sync()
     if dist.get_rank() != src:
         engine.arena_mark_bound()
     return time.perf_counter() - t0
@@ -154,7 +164,7 @@ def broadcast_pipeline(unet_engine, vae=None, text_encoders=(), src=0):
             vae.arena_mark_bound()
     tens = [p for enc in text_encoders for p in enc.parameter_tensors()]
     n += broadcast_tensors(tens, src)
-    torch.cuda.synchronize()
+    _cuda_sync()
     LAST_BROADCAST_CALLS += n
     return t + time.perf_counter() - t0
 

@@ -86,15 +86,85 @@ def generate(model, param, model_type='SD', run_dir=None, color_guidance_weight=
     return plain_img, rich_img, timings
 
 
+def _load_json_arg(v):
+    """`--rich_text_json` value: the JSON text itself (as the reference passes it, sample.py:123) or a path to a file holding it."""
+    if os.path.isfile(v):
+        with open(v) as f:
+            return json.load(f)
+    return json.loads(v)
+
+
+def build_requests(a):
+    """The (rich-text JSON, seed) list of one invocation.  One JSON + one --seed = the reference's single image.  Several JSONs and / or
+    several --seeds = independent requests (BASELINE configs 4 / 5: "batch of 8 independent rich-text JSON/seeds"): JSONs and seeds
+    pair up one to one when both lists have the same length, otherwise every JSON is sampled with every seed.  `--requests FILE`:
+    one JSON object per line, {"rich_text_json": {...} | "<path>", "seed": 3, "negative_prompt": "..."} (missing keys: the flags)."""
+    reqs = []
+    if a.requests:
+        with open(a.requests) as f:
+            for line in f:
+                line = line.strip()
+                if not line:
+                    continue
+                r = json.loads(line)
+                js = r["rich_text_json"]
+                reqs.append(dict(text_input=_load_json_arg(js) if isinstance(js, str) else js, seed=int(r.get("seed", a.seed)),
+                                 negative_prompt=r.get("negative_prompt", a.negative_prompt)))
+    jsons = [_load_json_arg(v) for v in (a.rich_text_json or [])]
+    seeds = list(a.seeds) if a.seeds else [a.seed]
+    if jsons:
+        pairs = list(zip(jsons, seeds)) if len(jsons) == len(seeds) else [(j, sd) for j in jsons for sd in seeds]
+        reqs += [dict(text_input=j, seed=int(sd), negative_prompt=a.negative_prompt) for j, sd in pairs]
+    if not reqs:
+        raise SystemExit("sample: no request (pass --rich_text_json JSON [JSON ...] and / or --requests FILE)")
+    for i, r in enumerate(reqs):
+        r["index"] = i
+    return reqs
+
+
+def build_model(a, rank=0, local_rank=0, world=1):
+    """sample.py:24-32.  world > 1: rank 0 reads the checkpoint, the other ranks build the same objects from the config / tokenizer
+    files alone and receive the packed UNet arena, the VAE arena and the text-encoder weights in launcher.broadcast_pipeline's three
+    collectives (RCCL over xGMI; SURVEY 8e: one broadcast at start-up, no per-step collectives)."""
+    from .region_diffusion import RegionDiffusion
+    from .region_diffusion_sdxl import RegionDiffusionXL
+    res = 512 if a.model == 'SD' else 1024
+    # the VAE plan (decode + colour guidance workspace) is sized for the requested image, like the UNet engine
+    hw = ((a.height or res) // 8, (a.width or res) // 8)
+    if world == 1:
+        if a.model == 'SD':
+            return RegionDiffusion(torch.device('cuda'), load_path=a.load_path, latent_hw=hw), 0.0
+        return RegionDiffusionXL(load_path=a.load_path or ("stabilityai/stable-diffusion-xl-base-1.0" if a.model == 'SDXL' else "Linaqruf/animagine-xl"),
+                                 latent_hw=hw), 0.0
+    from . import launcher
+    from .checkpoint import load_components, resolve_checkpoint
+    kind = 'SD' if a.model == 'SD' else 'SDXL'
+    default = None if a.model != 'AnimeXL' else "Linaqruf/animagine-xl"
+    comp = load_components(resolve_checkpoint(a.load_path or default, kind), kind, local_rank, hw, weights=(rank == 0))
+    if kind == 'SD':
+        model = RegionDiffusion(local_rank, **comp)
+        encoders = [comp["text_encoder"].enc]
+    else:
+        model = RegionDiffusionXL(None, local_rank, **comp)
+        encoders = list(comp["text_encoders"].encoders)
+    eng = model.unet.engine(hw[0], hw[1])                            # the engine (and its arena) must exist on every rank before the broadcast
+    seconds = launcher.broadcast_pipeline(eng, model.vae, encoders, src=0)
+    return model, seconds
+
+
 def main(argv=None):
-    """Flags of sample.py:118-133 (+ --load_path).  The model is constructed exactly as sample.py:24-32 does."""
+    """Flags of sample.py:118-133 (+ --load_path), and the seed-parallel form the reference does not have (BASELINE
+    configs 4 / 5): `--gpus N` with several requests (`--rich_text_json A B ...`, `--seeds ...`, `--requests FILE`) re-executes itself
+    as N ranks under torch.distributed.run, rank 0 loads the checkpoint, ONE pipeline broadcast, requests dealt round-robin, every
+    rank writes its own images.  With one GPU and one request this is the reference's main()."""
+    import sys
     p = argparse.ArgumentParser()
     p.add_argument('--run_dir', type=str, default='results/')
     p.add_argument('--height', type=int, default=None)
     p.add_argument('--width', type=int, default=None)
     p.add_argument('--seed', type=int, default=6)
     p.add_argument('--sample_steps', type=int, default=41)
-    p.add_argument('--rich_text_json', type=str, required=True)
+    p.add_argument('--rich_text_json', type=str, nargs='+', default=None, help='JSON text or a file holding it; several = independent requests')
     p.add_argument('--negative_prompt', type=str, default='')
     p.add_argument('--model', type=str, default='SD', choices=['SD', 'SDXL', 'AnimeXL'])
     p.add_argument('--guidance_weight', type=float, default=8.5)
@@ -106,31 +176,100 @@ def main(argv=None):
     p.add_argument('--load_path', type=str, default=None,
                    help='diffusers-layout checkpoint directory; default: the hub ids of sample.py:26-30 resolved locally '
                         '(checkpoint.resolve_checkpoint: $RTDIFF_SD_PATH / $RTDIFF_SDXL_PATH / the Hugging Face hub cache)')
+    p.add_argument('--seeds', type=int, nargs='*', default=None, help='seeds of the independent requests (default: --seed)')
+    p.add_argument('--requests', type=str, default=None, help='JSON-lines request file (see build_requests)')
+    p.add_argument('--gpus', type=int, default=1, help='ranks = GPUs of this node; requests are dealt round-robin (one engine per GPU)')
+    p.add_argument('--dry_launch', action='store_true',
+                   help='exercise the launch / sharding / broadcast control path on the gloo backend with stand-in arenas and print '
+                        'one JSON line per rank - no GPU, no checkpoint (tests/test_distributed_cpu.py)')
+    argv = list(sys.argv[1:] if argv is None else argv)
     a = p.parse_args(argv)
-    from .region_diffusion import RegionDiffusion
-    from .region_diffusion_sdxl import RegionDiffusionXL
+    from . import launcher
+    err = launcher.self_launch(None, argv, a.gpus, require_gpus=not a.dry_launch, module=__spec__.name if __spec__ else "rich_text_to_image_amd.sample")
+    if err is not None:
+        raise SystemExit(f"sample: {err}")
+    rank, local_rank, world = launcher.init_distributed("gloo" if a.dry_launch else None)
+    if world != max(1, a.gpus) and "WORLD_SIZE" in os.environ:
+        raise SystemExit(f"sample: --gpus {a.gpus} but the launch environment says WORLD_SIZE={world}")
+    reqs = build_requests(a)
+    mine = launcher.shard_round_robin(reqs, rank, world)
+    if a.dry_launch:
+        return _dry_launch(a, rank, world, reqs, mine)
+    torch.cuda.set_device(local_rank)
+    model, bcast_s = build_model(a, rank, local_rank, world)
     res = 512 if a.model == 'SD' else 1024
-    # the VAE plan (decode + colour guidance workspace) is sized for the requested image, like the UNet engine
-    hw = ((a.height or res) // 8, (a.width or res) // 8)
-    # sample.py:24-32
-    if a.model == 'SD':
-        device = torch.device('cuda')
-        model = RegionDiffusion(device, load_path=a.load_path, latent_hw=hw)
-    elif a.model == 'SDXL':
-        model = RegionDiffusionXL(load_path=a.load_path or "stabilityai/stable-diffusion-xl-base-1.0", latent_hw=hw)
-    else:
-        model = RegionDiffusionXL(load_path=a.load_path or "Linaqruf/animagine-xl", latent_hw=hw)
-    param = {'text_input': json.loads(a.rich_text_json), 'height': a.height or res, 'width': a.width or res,
-             'guidance_weight': a.guidance_weight, 'steps': a.sample_steps, 'noise_index': a.seed, 'negative_prompt': a.negative_prompt}
-    plain, rich, t = generate(model, param, 'SD' if a.model == 'SD' else 'SDXL', a.run_dir, a.color_guidance_weight, a.inject_selfattn,
-                              a.segment_threshold, a.num_segments, a.inject_background)
-    print('time lapses: plain %.3f s, token maps %.3f s, rich %.3f s' % (t['plain'], t['token_maps'], t['rich']))
-    # seed%d_plain.jpg / seed%d_rich.jpg in run_dir, as sample.py:62-76,97-112 writes them (imageio there, PIL here)
+    os.makedirs(a.run_dir, exist_ok=True)
     from PIL import Image
-    for name, img in (('plain', plain), ('rich', rich)):
-        arr = img.images[0] if hasattr(img, 'images') else img[0]
-        (arr if isinstance(arr, Image.Image) else Image.fromarray(arr)).save(os.path.join(a.run_dir, 'seed%d_%s.jpg' % (a.seed, name)))
-    return plain, rich
+    out = []
+    for r in mine:
+        param = {'text_input': r['text_input'], 'height': a.height or res, 'width': a.width or res, 'guidance_weight': a.guidance_weight,
+                 'steps': a.sample_steps, 'noise_index': r['seed'], 'negative_prompt': r['negative_prompt']}
+        plain, rich, t = generate(model, param, 'SD' if a.model == 'SD' else 'SDXL', a.run_dir, a.color_guidance_weight, a.inject_selfattn,
+                                  a.segment_threshold, a.num_segments, a.inject_background)
+        print('[rank %d] request %d seed %d: time lapses: plain %.3f s, token maps %.3f s, rich %.3f s'
+              % (rank, r['index'], r['seed'], t['plain'], t['token_maps'], t['rich']), flush=True)
+        # seed%d_plain.jpg / seed%d_rich.jpg in run_dir, as sample.py:62-76,97-112 writes them (imageio there, PIL here); with several
+        # requests the request index keeps the names apart
+        tag = 'seed%d' % r['seed'] if len(reqs) == 1 else 'req%d_seed%d' % (r['index'], r['seed'])
+        for name, img in (('plain', plain), ('rich', rich)):
+            arr = img.images[0] if hasattr(img, 'images') else img[0]
+            (arr if isinstance(arr, Image.Image) else Image.fromarray(arr)).save(os.path.join(a.run_dir, '%s_%s.jpg' % (tag, name)))
+        out.append((plain, rich))
+    launcher.barrier()
+    if world > 1:
+        if rank == 0:
+            print('sample: %d requests on %d ranks, pipeline broadcast %.3f s (%d collectives)' % (len(reqs), world, bcast_s, launcher.LAST_BROADCAST_CALLS), flush=True)
+        torch.distributed.destroy_process_group()
+    return out[0] if len(out) == 1 else out
+
+
+class _StandInArena:
+    """CPU stand-in for an Engine / VaeDecoder in the dry launch: a byte arena, `arena_mark_bound`, `synchronize`."""
+
+    def __init__(self, nbytes, fill):
+        self.t = torch.full((nbytes,), fill, dtype=torch.uint8) if fill is not None else torch.zeros(nbytes, dtype=torch.uint8)
+        self.bound = fill is not None
+        self.device = "cpu"
+
+    def arena_as_tensor(self):
+        return self.t
+
+    def arena_mark_bound(self):
+        self.bound = True
+
+    def synchronize(self):
+        pass
+
+
+class _StandInEncoder:
+    def __init__(self, filled):
+        g = torch.Generator().manual_seed(7)
+        shapes = [((64, 32), torch.float32), ((32,), torch.float32), ((48, 32), torch.bfloat16), ((5,), torch.float32)]
+        self.p = [(torch.randn(*s, generator=g).to(dt) if filled else torch.zeros(*s, dtype=dt)) for s, dt in shapes]
+
+    def parameter_tensors(self):
+        return self.p
+
+
+def _dry_launch(a, rank, world, reqs, mine):
+    """The control path of a `--gpus N` run without GPUs or checkpoints: the SAME launcher.broadcast_pipeline call build_model makes,
+    on stand-in arenas (rank 0 filled, the others zero), then the per-rank request list as one JSON line."""
+    from . import launcher
+    unet, vae = _StandInArena(1 << 16, 0xA5 if rank == 0 else None), _StandInArena(1 << 12, 0x3C if rank == 0 else None)
+    encs = [_StandInEncoder(rank == 0), _StandInEncoder(rank == 0)]
+    seconds = launcher.broadcast_pipeline(unet, vae, encs, src=0)
+    ref = _StandInEncoder(True)
+    ok = bool((unet.t == 0xA5).all() and (vae.t == 0x3C).all() and unet.bound and vae.bound and
+              all(torch.equal(x, y) for e in encs for x, y in zip(e.p, ref.p)))
+    print(json.dumps({"rank": rank, "world": world, "requests_total": len(reqs), "requests_mine": [r["index"] for r in mine],
+                      "seeds_mine": [r["seed"] for r in mine], "pipeline_received": ok, "broadcast_collectives": launcher.LAST_BROADCAST_CALLS,
+                      "broadcast_s": seconds}), flush=True)
+    launcher.barrier()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    if not ok:
+        raise SystemExit("sample: dry launch: pipeline broadcast payload mismatch")
+    return None
 
 
 if __name__ == '__main__':

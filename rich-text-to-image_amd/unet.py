@@ -44,7 +44,9 @@ class HipUNet2DConditionModel:
                        max_prompts=self.max_prompts)
             if self._state_dict is None:
                 raise RuntimeError("HipUNet2DConditionModel: no weights loaded (call load_state_dict)")
-            if isinstance(self._state_dict, str) and self._state_dict.startswith("random"):
+            if isinstance(self._state_dict, str) and self._state_dict == "empty":
+                pass                                                            # the packed arena arrives by launcher.broadcast_weights
+            elif isinstance(self._state_dict, str) and self._state_dict.startswith("random"):
                 e.init_random_weights(seed=int(self._state_dict[6:] or 0))      # "random<seed>": benchmarks without checkpoints
             else:
                 e.load_state_dict(self._state_dict)

@@ -83,3 +83,61 @@ def test_bench_reports_missing_gpus_clearly():
     assert out.returncode == 0
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["value"] is None and "need 8 GPUs" in line["error"] and "need 8 GPUs" in out.stderr
+
+
+def test_sample_cli_gpus2_shards_requests_and_broadcasts_the_whole_pipeline(tmp_path):
+    """BASELINE configs 4 / 5 as ONE command: `python -m rich_text_to_image_amd.sample --gpus 2 --rich_text_json A B --seeds ...`
+    re-executes itself as 2 ranks under torch.distributed.run (launcher.self_launch, module form), deals the (JSON, seed) requests
+    round-robin and runs launcher.broadcast_pipeline - the UNet arena, the VAE arena AND the text-encoder weights, the call
+    build_model makes - here on stand-in arenas over gloo (--dry_launch: no GPU, no checkpoint).  Rank 1 starts from zeros and must
+    end with rank 0's bytes and arenas marked bound."""
+    import json
+    import subprocess
+    a = tmp_path / "a.json"
+    a.write_text(json.dumps({"ops": [{"insert": "a "}, {"attributes": {"font": "slabo"}, "insert": "night sky"}, {"insert": "\n"}]}))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    out = subprocess.run([sys.executable, "-m", "rich_text_to_image_amd.sample", "--model", "SDXL", "--gpus", "2", "--dry_launch",
+                          "--rich_text_json", str(a), "--seeds", "0", "1", "2", "3", "4"], env=env, capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = sorted((json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")), key=lambda d: d["rank"])
+    assert [l["rank"] for l in lines] == [0, 1] and all(l["world"] == 2 and l["requests_total"] == 5 for l in lines)
+    assert lines[0]["requests_mine"] == [0, 2, 4] and lines[1]["requests_mine"] == [1, 3] and lines[1]["seeds_mine"] == [1, 3]
+    assert all(l["pipeline_received"] and l["broadcast_collectives"] == 3 for l in lines)
+
+
+def test_sample_cli_request_list_forms(tmp_path):
+    """build_requests: one JSON x several seeds, JSONs paired with seeds, and a JSON-lines request file; a single request keeps the
+    reference's single-image behaviour (sample.py:17-114)."""
+    import json
+    import types
+    from rich_text_to_image_amd.sample import build_requests
+    j1, j2 = '{"ops":[{"insert":"a cat\\n"}]}', '{"ops":[{"insert":"a dog\\n"}]}'
+    ns = lambda **k: types.SimpleNamespace(**dict(dict(requests=None, rich_text_json=None, seeds=None, seed=6, negative_prompt=""), **k))
+    r = build_requests(ns(rich_text_json=[j1]))
+    assert len(r) == 1 and r[0]["seed"] == 6 and r[0]["index"] == 0
+    r = build_requests(ns(rich_text_json=[j1], seeds=[0, 1, 2]))
+    assert [x["seed"] for x in r] == [0, 1, 2] and all(x["text_input"] == json.loads(j1) for x in r)
+    r = build_requests(ns(rich_text_json=[j1, j2], seeds=[4, 5]))
+    assert [(x["text_input"]["ops"][0]["insert"], x["seed"]) for x in r] == [("a cat\n", 4), ("a dog\n", 5)]
+    f = tmp_path / "reqs.jsonl"
+    f.write_text(json.dumps({"rich_text_json": json.loads(j2), "seed": 9}) + "\n" + json.dumps({"rich_text_json": json.loads(j1)}) + "\n")
+    r = build_requests(ns(requests=str(f), rich_text_json=[j1], seeds=[1]))
+    assert [x["seed"] for x in r] == [9, 6, 1] and [x["index"] for x in r] == [0, 1, 2]
+    import pytest
+    with pytest.raises(SystemExit):
+        build_requests(ns())
+
+
+def test_text_encoder_empty_state_dict_has_the_shapes_of_a_real_one():
+    """Ranks != 0 construct their HipCLIPTextEncoder parameter list from config.json alone (clip_text_encoder.empty_state_dict) and
+    launcher.broadcast_tensors requires equal shapes on every rank: compare with transformers' own CLIPTextModelWithProjection."""
+    import transformers
+    from rich_text_to_image_amd.clip_text_encoder import empty_state_dict
+    cfg = transformers.CLIPTextConfig(hidden_size=64, num_attention_heads=4, num_hidden_layers=2, intermediate_size=128, vocab_size=300,
+                                      max_position_embeddings=77, projection_dim=48)
+    real = transformers.CLIPTextModelWithProjection(cfg).state_dict()
+    mine = empty_state_dict(cfg, with_projection=True)
+    norm = lambda k: k if k.startswith("text_model.") or k.startswith("text_projection") else "text_model." + k
+    real = {norm(k): tuple(v.shape) for k, v in real.items() if "position_ids" not in k}
+    assert {k: tuple(v.shape) for k, v in mine.items()} == real

@@ -560,6 +560,66 @@ def test_cross_attn_block_op_against_reference_module_golden():
         report(f"rt_op_cross_attn_block {name}", out.float().cpu(), g[name].reshape(B * N, Cc) + trunk.float().cpu(), atol=3e-2, rtol=3e-2)
 
 
+@pytest.mark.parametrize("B,N,Cc,H", [(3, 256, 320, 5), (7, 1024, 1280, 20), (2, 384, 640, 10)])
+def test_cross_attn_block_fused_kernel_against_reference_arithmetic(B, N, Cc, H):
+    """The fused to_q + 77-key attention kernel (csrc/gemm16.hip, EPI_XATTN; what the engine runs at the 1280-channel level of SDXL)
+    inside rt_op_cross_attn_block, on shapes that take it (d = 64, H % 5 == 0, N % 128 == 0): against the reference processor's
+    arithmetic in fp32 (attention_processor.py:476-545, font-size softmax :386-401 incl. a NEGATIVE size; attention.py:169-189 adds
+    the residual) on identical bf16-rounded operands, and against the three-launch form of the same operator (debug bit 4).
+    Streams mix prompts and plain / font-size softmax, so a tile's K / V^T and multiplier set follow ITS stream."""
+    import ctypes as C
+    from rich_text_to_image_amd.engine import load_library, _ptr
+    lib = load_library()
+    d = DP = 64
+    P = 3
+    qs = d ** -0.5 * math.log2(math.e)
+    x = bf(rnd(B * N, Cc, seed=80))
+    wq_f = rnd(H * d, Cc, seed=81) * Cc ** -0.5 * 3.0                       # scores of a few units: a peaked softmax
+    wq = bf(wq_f * qs)
+    wo = bf(rnd(Cc, H * d, seed=82) * (H * d) ** -0.5)
+    bo = (0.1 * rnd(Cc, seed=83)).to(DEV).contiguous()
+    kc, vc = rnd(P, 77, H * d, seed=84), rnd(P, 77, H * d, seed=85)
+    Kp = torch.zeros(P, 96, H * d); Kp[:, :77] = kc
+    Vp = torch.full((P, 96, H * d), 7.0); Vp[:, :77] = vc                    # padded keys carry junk values: they must be masked, not multiplied by ~0
+    K = bf(Kp.reshape(P * 96, -1)); VT = bf(Vp.reshape(P * 96, -1)).t().contiguous()
+    wp, fs = torch.tensor([2, 9, 30, 76]), torch.tensor([3.0, -1.5, 0.25, 20.0])
+    wabs = torch.zeros(2, 96); wabs[:, :77] = 1.0
+    wsgn = torch.ones(2, 96)
+    wabs[1, wp] = fs.abs(); wsgn[1, wp] = fs.sign()
+    wabs, wsgn = wabs.to(DEV), wsgn.to(DEV)
+    prompt = [(2 * b + 1) % P for b in range(B)]
+    wset = [1 if b % 3 == 1 else -1 for b in range(B)]
+    trunk = (rnd(B * N, Cc, seed=86) * 2).to(DEV).to(torch.float16).contiguous()
+    ia = lambda vals: (C.c_int * B)(*vals)
+
+    def run():
+        q = torch.zeros(B * N, H * DP, device=DEV, dtype=torch.bfloat16); o = torch.zeros_like(q); out = torch.empty_like(trunk)
+        rc = lib.rt_op_cross_attn_block(_ptr(x), _ptr(wq), _ptr(wo), _ptr(bo), _ptr(K), _ptr(VT), VT.stride(0), ia(prompt), ia(wset), _ptr(wabs),
+                                        _ptr(wsgn), _ptr(trunk), _ptr(out), _ptr(q), _ptr(o), B, N, Cc, H, DP, None)
+        assert rc == 0, lib.rt_op_last_error().decode()
+        torch.cuda.synchronize()
+        return out.float().cpu(), o.float().cpu(), q
+    fused, o_fused, q_fused = run()
+    assert float(q_fused.float().abs().max()) == 0.0, "the fused path must not write Q to HBM"
+    lib.rt_op_gemm_debug(16)
+    try:
+        three, o_three, q_three = run()
+    finally:
+        lib.rt_op_gemm_debug(0)
+    assert float(q_three.float().abs().max()) > 0.0
+    # fp32 reference on the same bf16-rounded operands; Q rounded to bf16 like both device paths do
+    xq = (x.float().cpu() @ wq.float().cpu().t()).to(torch.bfloat16).float() / qs
+    kr, vr = K.float().cpu().reshape(P, 96, -1)[:, :77], VT.float().cpu().t().reshape(P, 96, -1)[:, :77]
+    ref_o = torch.empty(B, N, H * d)
+    for b in range(B):
+        ref_o[b], _ = _ref_attention(xq.reshape(B, N, -1)[b:b + 1], kr[prompt[b]][None], vr[prompt[b]][None], H, (wp, fs) if wset[b] >= 0 else None)
+    report(f"fused attention output O B{B} N{N} C{Cc}", o_fused, ref_o.reshape(B * N, -1), atol=2e-2, rtol=2e-2)
+    ref = ref_o.reshape(B * N, -1).to(torch.bfloat16).float() @ wo.float().cpu().t() + bo.cpu() + trunk.float().cpu()
+    report(f"rt_op_cross_attn_block fused B{B} N{N} C{Cc}", fused, ref, atol=3e-2, rtol=2e-2)
+    report("fused vs three-launch form", fused, three, atol=3e-2, rtol=2e-2)
+    report("fused O vs three-launch O", o_fused, o_three, atol=2e-2, rtol=2e-2)
+
+
 # ----------------------------------------------------------------------------------------------- norms
 @pytest.mark.parametrize("B,HW,C1,C2,G,silu,bf16in", [(2, 256, 64, 0, 8, True, False), (3, 1024, 320, 0, 32, True, False),
                                                       (2, 64, 1280, 640, 32, True, False), (2, 4096, 640, 320, 32, True, False),
