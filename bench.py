@@ -68,7 +68,7 @@ def cpu_model_name():
     return "unknown"
 
 
-def cpu_baseline(sd_cpu, threads, x, ctx, pooled, tid, t):
+def cpu_baseline(sd_cpu, threads, x, ctx, pooled, tid, t, full_step=False, all_ctx=None, all_pooled=None):
     """Reference-equivalent CPU path: the fp32 oracle restatement of the reference UNet (oracle/unet.py, pinned
     against the unmodified reference) timed on the host cores of this box.  Bounded sample: ONE batch-1 SDXL
     UNet forward at 128x128 (the step is 7 such forwards + negligible elementwise work), on the SAME latents /
@@ -93,6 +93,19 @@ def cpu_baseline(sd_cpu, threads, x, ctx, pooled, tid, t):
         t0 = time.perf_counter()
         ref = o.forward(x, t, ctx, added)
         dt = time.perf_counter() - t0
+        if full_step:
+            # `--steps >= 50` (the default run): ONE FULL STEP = the 7 batch-1 forwards of a config-3 iteration (uncond, base, uncond_ref,
+            # text_ref, 3 regions: prompts 0, R, 0, R, 1, 2, 3), timed as a whole instead of one forward x 7
+            prompts = [0, all_ctx.shape[0] - 1, 0, all_ctx.shape[0] - 1, 1, 2, 3]
+            t1 = time.perf_counter()
+            for pi in prompts:
+                o.forward(x, t, all_ctx[pi:pi + 1], {"text_embeds": all_pooled[pi:pi + 1], "time_ids": tid})
+            step_s = time.perf_counter() - t1
+            return dict(value=1.0 / step_s, unit="steps/s", cores=threads, cores_physical=threads_max,
+                        cores_note=f"{threads} of {threads_max} physical cores (thread count picked by a matmul probe over {cand}: the fastest, so the baseline is not handicapped by oversubscription)",
+                        kind="port", cpu=cpu_model_name(),
+                        sample=f"1 full config-3 step = 7 batch-1 SDXL UNet forwards (fp32 oracle, {step_s:.1f} s; hooks / mask combine / Euler update are negligible beside them)",
+                        forward_seconds=dt, step_seconds=step_s), ref
     return dict(value=1.0 / (7 * dt), unit="steps/s", cores=threads, cores_physical=threads_max,
                 cores_note=f"{threads} of {threads_max} physical cores (thread count picked by a matmul probe over {cand}: the fastest, so the baseline is not handicapped by oversubscription)",
                 kind="port", cpu=cpu_model_name(),
@@ -405,7 +418,8 @@ def main():
         px = torch.randn(1, 4, hw, hw, generator=gp)
         eng.set_fontsize(None, None)
         got = eng.unet_forward(px.to(dev), 801.0, [0]).cpu()
-        cpu, ref = cpu_baseline(sd_cpu, threads, px, inp["emb"][:1].cpu(), inp["pooled"][:1].cpu(), inp["tid"], 801.0)
+        cpu, ref = cpu_baseline(sd_cpu, threads, px, inp["emb"][:1].cpu(), inp["pooled"][:1].cpu(), inp["tid"], 801.0,
+                                full_step=args.steps >= 50, all_ctx=inp["emb"].cpu(), all_pooled=inp["pooled"].cpu())
         rel = float(((got - ref).pow(2).sum() / ref.pow(2).sum()).sqrt())
         parity = dict(rel_l2=rel, tol=PARITY_TOL, ok=bool(rel <= PARITY_TOL),
                       config="SDXL-base full architecture, 1 UNet forward (latent 128x128, t=801, negative-prompt stream) vs the fp32 CPU oracle")
@@ -420,6 +434,7 @@ def main():
         def graph_replay():
             # the same `steps` steps captured into one HIP graph each and replayed: does the host side of ~1500 launches per step cost anything?
             side = torch.cuda.Stream()
+            eng.set_fontsize(torch.tensor([5, 6]), torch.tensor([20.0, 20.0]))      # (the parity leg cleared the multipliers)
             eng.synchronize(); eng.set_stream(side.cuda_stream)
             try:
                 reset(); torch.cuda.synchronize()

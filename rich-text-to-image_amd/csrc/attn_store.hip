@@ -103,8 +103,145 @@ __global__ __launch_bounds__(64) void attn_store_kernel(AttnStoreArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------- round 4: the one-pass form
+// The kernel above gives ONE wave 32 query rows and walks heads x key tiles twice with its operands fetched straight from
+// global memory behind every MFMA: 32 single-wave workgroups for a 1024 x 1024 map = 1.4 ms per launch, 74 launches per capturing
+// step of the SDXL plain pass = 105 ms on top of a 28 ms step (profiles/r4_plain_pass_before.json).  Here a workgroup of 8 waves
+// owns 16 query rows x ALL keys (<= 1024): wave w holds the key tiles w, w + 8, ... (16 keys each, at most 8) - its slice of S^T for
+// one head (<= 32 fp32 per lane) AND its slice of the head-average accumulator (<= 32 fp32 per lane) stay in registers, so the scores
+// are computed once: local row max -> LDS exchange over the 8 waves -> exp2 -> local row sum -> LDS exchange -> acc += e / (H sum).
+// Two barriers per head (statistics buffers alternate with the head's parity), the K fragments of head h + 1 are requested as soon as
+// the MFMAs of head h have consumed theirs.  Swapped product as in attention.hip (S^T = K Q^T: a lane owns one query), heads are
+// summed in ascending order in registers: deterministic, no atomics.  out (+)= is a read-modify-write of 64-B row segments.
+template <int DP>
+__global__ __launch_bounds__(512) void attn_store16_kernel(AttnStoreArgs p) {
+    constexpr int KSN = DP / 32;                     // 32-deep k steps of the 16x16x32 MFMA
+    constexpr int MT = 8;                            // key tiles per wave (8 waves x 8 tiles x 16 keys = 1024 keys)
+    typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+    __shared__ float smax[2][8][16], ssum[2][8][16];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, q4 = lane >> 4;
+    const int q0 = blockIdx.x * 16;
+    const int qrow = q0 + l15 < p.N ? q0 + l15 : p.N - 1;
+    const int ntile = p.NKpad >> 4;
+    const int nt = wave < ntile ? (ntile - wave + 7) >> 3 : 0;                  // tiles of this wave (wave-uniform), <= MT
+    const bf16_t* qbase = p.Q + ((size_t)p.q_row0 + qrow) * p.ldq + q4 * 8;
+    const bf16_t* kbase[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        int krow = (wave + 8 * i) * 16 + l15; if (krow > p.NKrows - 1) krow = p.NKrows - 1;
+        kbase[i] = p.K + ((size_t)p.k_row0 + krow) * p.ldk + q4 * 8;
+    }
+    f32x4_t acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    bf16x8 kf[MT][KSN], qf[KSN];
+    auto load_head = [&](int h) {
+#pragma unroll
+        for (int ks = 0; ks < KSN; ++ks) qf[ks] = *(const bf16x8*)(qbase + h * DP + ks * 32);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+            if (i < nt) {
+#pragma unroll
+                for (int ks = 0; ks < KSN; ++ks) kf[i][ks] = *(const bf16x8*)(kbase[i] + h * DP + ks * 32);
+            }
+    };
+    load_head(0);
+    const float invH = 1.f / (float)p.H;
+    for (int h = 0; h < p.H; ++h) {
+        const int par = h & 1;
+        f32x4_t s[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            s[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if (i < nt) {
+#pragma unroll
+                for (int ks = 0; ks < KSN; ++ks) s[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[i][ks], qf[ks], s[i], 0, 0, 0);
+            }
+        }
+        if (h + 1 < p.H) load_head(h + 1);           // the fragment registers are free: next head's operands fly behind the softmax
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+            if (i < nt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = (wave + 8 * i) * 16 + 4 * q4 + r;
+                    if (key >= p.NK) s[i][r] = -INFINITY;
+                    mx = fmaxf(mx, s[i][r]);
+                }
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        if (q4 == 0) smax[par][wave][l15] = mx;
+        // raw barriers: a __syncthreads() carries s_waitcnt vmcnt(0) and would wait for the next head's operands right here
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        float gm = smax[par][0][l15];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) gm = fmaxf(gm, smax[par][w][l15]);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+            if (i < nt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s[i][r] = __builtin_amdgcn_exp2f(s[i][r] - gm); sum += s[i][r]; }
+            }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        if (q4 == 0) ssum[par][wave][l15] = sum;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        float gs = ssum[par][0][l15];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) gs += ssum[par][w][l15];
+        const float sc = invH / gs;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+            if (i < nt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][r] += s[i][r] * sc;
+            }
+    }
+    if (q0 + l15 < p.N) {
+        float* orow = p.out + (size_t)(q0 + l15) * p.NK;
+        const bool vec = (p.NK & 3) == 0 && (((uintptr_t)p.out) & 15) == 0;      // rows stay 16-B aligned
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+            if (i < nt) {
+                const int key = (wave + 8 * i) * 16 + 4 * q4;
+                if (vec && key + 4 <= p.NK) {
+                    float4* d = (float4*)(orow + key);
+                    float4 v = p.overwrite ? make_float4(0.f, 0.f, 0.f, 0.f) : *d;
+                    v.x += acc[i][0]; v.y += acc[i][1]; v.z += acc[i][2]; v.w += acc[i][3];
+                    *d = v;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (key + r < p.NK) orow[key + r] = p.overwrite ? acc[i][r] : orow[key + r] + acc[i][r];
+                }
+            }
+    }
+}
+
+int g_store_legacy = 0;      // debug bit 5 (rt_op_gemm_debug(32)): the two-pass single-wave kernel for every shape (A/B timing)
 void launch_attn_store(const AttnStoreArgs& a, hipStream_t st) {
     RT_REQUIRE(a.NKpad % 32 == 0 && a.NK >= 1 && a.NK <= a.NKpad && a.NKrows >= 1 && a.H >= 1 && a.H <= 32, "attn_store: keys are padded to a multiple of 32; at most 32 heads");
+    if (a.NKpad <= 1024 && a.NKpad % 16 == 0 && !g_store_legacy) {
+        // every map the token-map producer consumes (32x32 self maps, N x 77 cross maps; attention_utils.py:243-248): one pass,
+        // 8 waves per 16 query rows
+        dim3 grid16(cdiv(a.N, 16)), block16(512);
+        switch (a.DP) {
+            case 32: hipLaunchKernelGGL(attn_store16_kernel<32>, grid16, block16, 0, st, a); break;
+            case 64: hipLaunchKernelGGL(attn_store16_kernel<64>, grid16, block16, 0, st, a); break;
+            case 96: hipLaunchKernelGGL(attn_store16_kernel<96>, grid16, block16, 0, st, a); break;
+            case 160: hipLaunchKernelGGL(attn_store16_kernel<160>, grid16, block16, 0, st, a); break;
+            default: throw rt_error(RT_E_UNSUPPORTED, "attn_store: unsupported padded head dim");
+        }
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     const int chunk = a.NKpad < RT_STORE_CHUNK ? a.NKpad : RT_STORE_CHUNK;
     const size_t lds = (size_t)32 * (chunk + 1) * 4 + (size_t)a.H * 64 * 2 * 4;
     dim3 grid(cdiv(a.N, 32)), block(64);

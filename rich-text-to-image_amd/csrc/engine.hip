@@ -714,9 +714,13 @@ struct rt_engine {
                 gemm_vt(k.v2, ctx, D, P * 96, k.vtcache, cfg.max_prompts * 96);
             }
         };
+        // one prompt = one "stream" of 96 rows: the tile class / split-K rule of these GEMMs is keyed on that, so a prompt's cached
+        // K / V bits do not depend on how many other prompts share the set
+        cur_hw = 96;
         for (auto& d : down) for (auto& t : d.attn) build(t);
         build(mid_t);
         for (auto& u : up) for (auto& t : u.attn) build(t);
+        cur_hw = 0;
         HIP_CHECK(hipMemsetAsync(aug_emb, 0, (size_t)cfg.max_prompts * temb_dim * 4, stream));
         if (cfg.addition_text_time) {
             RT_REQUIRE(pooled && time_ids, "set_prompts: SDXL needs pooled embeds and time_ids");
@@ -851,14 +855,28 @@ int rt_create(const rt_config* cfg, int device, rt_engine** out) {
             e->ws = Workspace(); e->ws.dry = true;
             e->splitk_need = 0;
             e->unet_forward(in);
-            {   // the K / V^T cache GEMMs of rt_set_prompts (outside a forward: cur_hw == 0) at the largest prompt count
+            {   // the K / V^T cache GEMMs of rt_set_prompts (one prompt = one 96-row stream) at the largest prompt count
                 const int D = cfg->cross_attention_dim, P96 = cfg->max_prompts * 96;
+                e->cur_hw = 96;
                 e->for_each_tblock([&](TransformerP& t, TBlockP& k) {
                     e->gemm(nullptr, D, k.k2, P96, nullptr, t.heads * t.DP, EPI_BF16);
                     e->gemm_vt(k.v2, nullptr, D, P96, nullptr, P96);
                 });
+                e->cur_hw = 0;
             }
             size_t peak = e->ws.peak;
+            {   // split-K slices GROW as the maps shrink (the rule keys on ONE stream's tile count): an engine built for 128 x 128
+                // latents and stepped at 64 x 64 needs more partial-sum scratch than the largest shape measures.  Dry passes at every
+                // halved latent size the architecture admits record it, so no forward ever allocates.
+                const int align = 1 << (cfg->n_levels - 1);
+                for (int s = 2; s <= 16; s *= 2) {
+                    FwdIn in2 = in; in2.h = cfg->latent_h / s; in2.w = cfg->latent_w / s;
+                    if (in2.h * s != cfg->latent_h || in2.w * s != cfg->latent_w || in2.h % align || in2.w % align || in2.h < 8 || in2.w < 8) break;
+                    const int deep = (in2.h / align) * (in2.w / align);
+                    if (deep % 8) break;                               // attention levels need h*w % 8 == 0
+                    e->unet_forward(in2);
+                }
+            }
             // set_prompts scratch
             size_t sp = (size_t)cfg->max_prompts * 96 * cfg->cross_attention_dim * 2 + (size_t)cfg->max_prompts * (cfg->projection_class_embeddings_input_dim + e->temb_dim) * 4 + (1 << 16);
             if (sp > peak) peak = sp;
@@ -1095,7 +1113,8 @@ static bf16_t* op_zero_page() {       // one page per DEVICE (a thread that driv
     catch (const std::exception& ex) { g_op_error = ex.what(); return RT_E_INVALID; }
 
 const char* rt_op_last_error(void) { return g_op_error.c_str(); }
-int rt_op_gemm_debug(int d) { gemm_set_debug(d); return RT_OK; }
+extern int g_store_legacy;
+int rt_op_gemm_debug(int d) { gemm_set_debug(d); g_store_legacy = (d & 32) ? 1 : 0; return RT_OK; }
 int rt_op_gemm_force_config(int cfg) {
     if (cfg < -1 || cfg > 8) return RT_E_INVALID;
     gemm_force_config(cfg);

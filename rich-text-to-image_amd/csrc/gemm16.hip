@@ -146,12 +146,19 @@ static __device__ __forceinline__ void xattn_unit(char* smem, int kvoff, int qro
         for (int dt = 0; dt < 4; ++dt)
             o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(vp + st * 4096 + dt * 256), pf.v, o[dt], 0, 0, 0);
     }
-    // O over Q (the unit's own rows / columns; its Q fragments are in registers)
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-        uint2 w; w.x = pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv); w.y = pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv);
-        *(uint2*)(qp + (dt * 16 + 4 * q4) * 2) = w;
+    // O over Q (the unit's own rows / columns; its Q fragments are in registers).  Written by inline ds_write_b64: in front of a
+    // compiler-visible LDS store hipcc's waitcnt pass puts s_waitcnt vmcnt(0) (LDS-DMA write-after-write), i.e. every phase would end
+    // by waiting for the K / V^T pieces of the heads that were just requested (measured: 3.7 k cycles per phase instead of ~1.5 k,
+    // profiles/r4_xattn_probe_v1.txt).  LDS operations of one wave execute in order; the closing barrier carries lgkmcnt(0).
+    const unsigned qaddr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(qp + 8 * q4);
+#define XA_OWRITE(DT_)                                                                                                         \
+    {                                                                                                                          \
+        const unsigned lo_ = pack_bf16x2(o[DT_][0] * inv, o[DT_][1] * inv), hi_ = pack_bf16x2(o[DT_][2] * inv, o[DT_][3] * inv); \
+        const unsigned long long w64_ = ((unsigned long long)hi_ << 32) | lo_;                                                 \
+        asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(qaddr), "v"(w64_), "n"((DT_) * 32) : "memory");                      \
     }
+    XA_OWRITE(0) XA_OWRITE(1) XA_OWRITE(2) XA_OWRITE(3)
+#undef XA_OWRITE
 }
 
 template <int TMW, int TNW, int WN>
@@ -177,6 +184,7 @@ static __device__ __forceinline__ void xattn_tail(const GemmArgs& p, char* smem,
         wt[96 + tid] = p.xa_wsgn[wset * 96 + tid];
     }
     const int qrow = wave * 16;
+    G16_T(3)
     // phase h: every wave does (its row tile, head h).  K/V pieces retire in issue order: heads 0, 1 (main loop), 2 (above), 3, 4.
 #define XA_PHASE(H_, KV_, BEHIND_, REFILL_HEAD_, REFILL_KV_)                                                          \
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(BEHIND_) : "memory");                           \
@@ -190,22 +198,40 @@ static __device__ __forceinline__ void xattn_tail(const GemmArgs& p, char* smem,
     XA_PHASE(3, XA_KVA, 3, -1, 0)
     XA_PHASE(4, XA_KVB, 0, -1, 0)
 #undef XA_PHASE
+    G16_T(5)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    // O tile -> HBM: 128 rows x 40 chunks of 16 B
+    G16_T(6)
+    // O tile -> HBM: 128 rows x 40 chunks of 16 B.  All LDS reads first: behind a global store hipcc's waitcnt pass puts
+    // s_waitcnt vmcnt(0) in front of the next LDS read (the LDS-DMA bookkeeping), which serialised the ten stores of a thread.
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t ov[10];
 #pragma unroll
     for (int it = 0; it < 10; ++it) {
         const int id = it * 512 + tid;
         const int r = id / 40, ch = id - r * 40;
-        if (m0 + r < p.M)
-            *(uint4*)((bf16_t*)p.out + (size_t)(m0 + r) * p.ldo + n0 + ch * 8) = *(const uint4*)(smem + r * XA_QS + ch * 16);
+        ov[it] = *(const u32x4_t*)(smem + r * XA_QS + ch * 16);
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < 10; ++it) asm volatile("" : "+v"(ov[it]));   // pins the reads above the stores (the scheduler sinks them back otherwise)
+#pragma unroll
+    for (int it = 0; it < 10; ++it) {
+        const int id = it * 512 + tid;
+        const int r = id / 40, ch = id - r * 40;
+        if (m0 + r < p.M) *(u32x4_t*)((bf16_t*)p.out + (size_t)(m0 + r) * p.ldo + n0 + ch * 8) = ov[it];
+    }
+#ifdef RT_G16_TIMING
+    G16_T(7)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    G16_T(4)
+#endif
 }
 
 // MODE = A_CONV3: 3x3 stride-1 pad-1 convolution as an implicit GEMM on the SAME main loop (M = pixels of the NHWC activation,
-// K tile t = (tap t / nch, 64-channel chunk t % nch), weights packed [Cout][tap][Cin] as everywhere else): only the A loader differs -
+// K tile t = (64-channel chunk t / 9, tap t % 9) - round 3: (tap t / nch, chunk t % nch) -, weights packed [Cout][tap][Cin] as everywhere else): only the A loader differs -
 // the lane's pixel address shifted by the tap, with the padding taps sent out of the descriptor's range so that they read as zeros.
-// It re-reads every input pixel nine times (from L2), which the patch kernel of gemm.hip avoids, but runs the 224-row / K-split
+// It re-reads every input pixel nine times (tap-inner K order: from the vL1D / L2), which the patch kernel of gemm.hip avoids, but runs the 224-row / K-split
 // main loop whose LDS array is not the bottleneck: 32^2 x 1280 -> 1280 for 7 streams is a 7168 x 1280 x 11520 GEMM.
 template <int MODE, int EPI, int TMW, int TNW, int WM, int WN, int WK, int S>
 __global__ __launch_bounds__(WM * WN * WK * 64) void gemm16_kernel(GemmArgs p, int wstat) {
@@ -291,17 +317,37 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void gemm16_kernel(GemmArgs p, i
     const int nch = MODE == A_CONV3 ? p.Cin / BK16 : 1;
     const unsigned a_range = MODE == A_CONV3 ? (unsigned)p.M * (unsigned)p.Cin * 2u : 0x7fffffffu;
     int is_tap = 0, is_chunk = 0, is_ky = 0, is_kx = 0;
+    int is_pix = -p.Win - 1;                                         // pixel shift of the tap, advanced incrementally (a (ky, kx) product in the
+                                                                     // loop made hipcc build a 9-entry table in scratch memory)
     auto stage_piece = [&](int t, int slot_off, int i) {             // piece i of K tile t -> ring slot at slot_off
         if (MODE == A_CONV3 && pisA[i]) {
-            const int shift = ((is_ky - 1) * p.Win + (is_kx - 1)) * p.Cin * 2;          // scalar
+            const int shift = is_pix * p.Cin * 2;                                       // scalar: (ky - 1) * Win + (kx - 1) pixels
             const int vo = ((tapmask[MODE == A_CONV3 ? i : 0] >> is_tap) & 1) ? voff[i] + shift : RT_G16_OOB;
             glds16_buf(p.A, vo, is_chunk * (BK16 * 2), smem + slot_off + ldst[i], a_range);
         } else {
-            glds16_buf(pisA[i] ? (const void*)p.A : (const void*)p.W, voff[i], t * (BK16 * 2), smem + slot_off + ldst[i]);
+            // conv weights are packed [Cout][tap][Cin]: the K offset of tile (tap, chunk) is tap * Cin + chunk * 64 (= t * 64 in the
+            // tap-major order)
+            const int wk = MODE == A_CONV3 ? (is_tap * p.Cin + is_chunk * BK16) * 2 : t * (BK16 * 2);
+            glds16_buf(pisA[i] ? (const void*)p.A : (const void*)p.W, voff[i], wk, smem + slot_off + ldst[i]);
         }
     };
+    // K-tile order of the convolution.  Round 3 ran (tap, chunk): for each tap the whole channel range of the tile's pixels streams
+    // by, so the nine re-reads of a pixel are a full A panel apart (224 rows x Cin x 2 B = 573 KB per workgroup, 18 MB per XCD against
+    // 4 MiB of L2): 615 - 936 MB per launch came over the fabric for 221 MB of operands (profiles/r3_pmc_traffic.json).  Round 4:
+    // (chunk, tap) - the nine taps of one 64-channel chunk follow each other, the shifted rows they re-read are 28 KB per workgroup
+    // and still in the vL1D / L2.  Same k order as the patch kernel of gemm.hip.  -DRT_G16_CONV_TAP_MAJOR builds the old order (A/B
+    // timing: `make tapmajor` + RTDIFF_LIB_PATH).
     auto tile_issued = [&]() {                                       // every piece of a K tile went out: advance (tap, chunk)
-        if (MODE == A_CONV3) { if (++is_chunk == nch) { is_chunk = 0; ++is_tap; if (++is_kx == 3) { is_kx = 0; ++is_ky; } } }
+        if (MODE == A_CONV3) {
+#ifdef RT_G16_CONV_TAP_MAJOR
+            if (++is_chunk == nch) { is_chunk = 0; ++is_tap; if (++is_kx == 3) { is_kx = 0; ++is_ky; is_pix += p.Win - 2; } else ++is_pix; }
+#else
+            if (++is_tap == 9) { is_tap = 0; is_kx = 0; is_pix = -p.Win - 1; ++is_chunk; }
+            else if (++is_kx == 3) { is_kx = 0; is_pix += p.Win - 2; }
+            else ++is_pix;
+#endif
+            (void)is_ky;
+        }
     };
 
     // ---- fragments: lane (l15, q): row l15 of a 16-row tile, 16-B chunk c = 4*khalf + q of the 128-B row
@@ -700,7 +746,12 @@ static void launch_e(const GemmArgs& a, int v, int wstat, hipStream_t st) {
 }
 
 bool xattn_fused_supported(int C, int H, int DP, int tokens) {
-    return DP == 64 && (H * 64) % 320 == 0 && tokens > 0 && tokens % 128 == 0 && C % BK16 == 0 && C >= 3 * BK16;
+    if (!(DP == 64 && (H * 64) % 320 == 0 && tokens > 0 && tokens % 128 == 0 && C % BK16 == 0 && C >= 3 * BK16)) return false;
+    // ... and only where the 128 x 320 tiles of a step's streams stay within one round of the chip: one stream may contribute at
+    // most 40 tiles (1024 tokens x 1280 channels: 32; the 4096-token / 640-channel level gives 64 per stream = 448 workgroups for 7
+    // streams, 1.75 rounds of a K = 640 loop: measured 51.4 us against 27.6 + 15 for the two launches, profiles/r4_xattn_probe_v1.txt).
+    // A function of ONE stream's shape, never of the batch.
+    return (tokens / 128) * (H * 64 / 320) <= 40;
 }
 void launch_xattn_fused(const GemmArgs& a, hipStream_t st) {
     RT_REQUIRE(a.mode == A_DENSE && a.epi == EPI_XATTN && a.N % 320 == 0 && a.K % BK16 == 0 && a.K >= 3 * BK16 && a.lda % 8 == 0 && a.ldw % 8 == 0 &&
@@ -730,6 +781,9 @@ bool gemm16_supported(const GemmArgs& a) {
     if (a.mode != A_DENSE || a.K % (2 * BK16) != 0 || a.K < 4 * BK16) return false;      // K % 128 (the K-split class runs pairs of K tiles), >= 4 tiles
     if (!(a.epi == EPI_BF16 || a.epi == EPI_F32 || a.epi == EPI_F16 || a.epi == EPI_GEGLU)) return false;
     if (a.lda % 8 || a.ldw % 8) return false;
+    // the loaders build signed 32-bit BYTE offsets against a 2 GiB buffer descriptor: larger operands stay on gemm.hip (whose
+    // launcher checks its own element-offset bound) instead of reading zeros beyond the range
+    if ((long)a.M * a.lda * 2 >= 0x7fffffffL || (long)a.N * a.ldw * 2 >= 0x7fffffffL) return false;
     return true;
 }
 

@@ -79,7 +79,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or _LIB_PATH
+    p = path or os.environ.get("RTDIFF_LIB_PATH") or _LIB_PATH          # RTDIFF_LIB_PATH: A/B builds of the same ABI (benchmarks only)
     if not os.path.exists(p):
         raise RtError(-3, f"{p} not found: build it with `python __graft_entry__.py build` "
                           "(hipcc --offload-arch=gfx950); there is no fallback path")

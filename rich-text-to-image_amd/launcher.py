@@ -43,7 +43,7 @@ def self_launch(script, argv, nproc, require_gpus=True, module=None):
     import sys
     if nproc <= 1 or "WORLD_SIZE" in os.environ:
         return None
-    if require_gpus:
+    if require_gpus and "RTDIFF_FORCE_DEVICE" not in os.environ:      # (RTDIFF_FORCE_DEVICE: every rank on one device - tests only)
         have = torch.cuda.device_count() if torch.cuda.is_available() else 0
         if have < nproc:
             return f"need {nproc} GPUs on this node for --gpus {nproc}, found {have}"
@@ -94,6 +94,17 @@ def broadcast_tensor(t, src=0, chunk_bytes=None):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return 0
     flat = t.view(-1)
+    if flat.is_cuda and dist.get_backend() == "gloo":
+        # gloo carries host memory: stage device arenas through pinned-size host chunks (tests that run two ranks on ONE GPU; the
+        # product backend is RCCL, which takes the device tensor as it is)
+        step = 1 << 28
+        for off in range(0, flat.numel(), step):
+            piece = flat[off:off + step]
+            host = piece.cpu()
+            dist.broadcast(host, src=src)
+            if dist.get_rank() != src:
+                piece.copy_(host)
+        return 1
     if chunk_bytes is None:
         if flat.dtype == torch.uint8 and flat.numel() % 8 == 0 and flat.data_ptr() % 8 == 0:
             flat = flat.view(torch.int64)

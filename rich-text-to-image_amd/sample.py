@@ -188,7 +188,10 @@ def main(argv=None):
     err = launcher.self_launch(None, argv, a.gpus, require_gpus=not a.dry_launch, module=__spec__.name if __spec__ else "rich_text_to_image_amd.sample")
     if err is not None:
         raise SystemExit(f"sample: {err}")
-    rank, local_rank, world = launcher.init_distributed("gloo" if a.dry_launch else None)
+    # RTDIFF_DIST_BACKEND / RTDIFF_FORCE_DEVICE: tests that run two ranks on ONE GPU over gloo (RCCL cannot put two ranks on a device)
+    rank, local_rank, world = launcher.init_distributed("gloo" if a.dry_launch else os.environ.get("RTDIFF_DIST_BACKEND"))
+    if "RTDIFF_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["RTDIFF_FORCE_DEVICE"])
     if world != max(1, a.gpus) and "WORLD_SIZE" in os.environ:
         raise SystemExit(f"sample: --gpus {a.gpus} but the launch environment says WORLD_SIZE={world}")
     reqs = build_requests(a)

@@ -146,6 +146,36 @@ def test_sample_cli_main_from_disk(tmp_path):
     assert os.path.exists(tmp_path / "out" / "seed3_plain.jpg") and os.path.exists(tmp_path / "out" / "seed3_rich.jpg")
 
 
+def test_sample_cli_two_ranks_receive_the_pipeline_by_broadcast(tmp_path):
+    """`python -m rich_text_to_image_amd.sample --gpus 2 --rich_text_json A B --seeds 1 2` end to end with REAL engines (SURVEY 8e,
+    BASELINE configs 4 / 5): the command re-executes itself as two ranks (launcher.self_launch, module form), rank 0 loads the
+    checkpoint, rank 1 builds its UNet engine / VAE / text encoder from the config files alone (checkpoint.load_components(weights=
+    False): zero arenas) and receives all three through launcher.broadcast_pipeline, the two requests are dealt round-robin and each
+    rank writes its own images.  One GPU here, so both ranks use device 0 and the collectives run over gloo (RTDIFF_DIST_BACKEND /
+    RTDIFF_FORCE_DEVICE; RCCL cannot place two ranks on one device) - the code path is the product's otherwise.  Rank 1's image must
+    be byte-identical to the same request sampled by a single process that loaded the weights itself."""
+    import subprocess
+    import sys
+    from rich_text_to_image_amd import sample
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    _write_dir(str(tmp_path / "ckpt"))
+    ja = json.dumps({"ops": [{"insert": "a "}, {"attributes": {"link": "a wooden fence covered in snow"}, "insert": "fence"}, {"insert": " under a night sky\n"}]})
+    jb = json.dumps({"ops": [{"insert": "a "}, {"attributes": {"font": "slabo"}, "insert": "barn"}, {"insert": " and a fence\n"}]})
+    (tmp_path / "a.json").write_text(ja); (tmp_path / "b.json").write_text(jb)
+    common = ["--load_path", str(tmp_path / "ckpt"), "--model", "SD", "--sample_steps", "12", "--num_segments", "4", "--inject_selfattn", "0.2"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(PYTHONPATH=root + os.pathsep + env.get("PYTHONPATH", ""), RTDIFF_DIST_BACKEND="gloo", RTDIFF_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "rich_text_to_image_amd.sample", "--gpus", "2", "--rich_text_json", str(tmp_path / "a.json"), str(tmp_path / "b.json"),
+                        "--seeds", "1", "2", "--run_dir", str(tmp_path / "out2")] + common, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "[rank 0] request 0 seed 1" in r.stdout and "[rank 1] request 1 seed 2" in r.stdout and "2 requests on 2 ranks" in r.stdout
+    for f in ("req0_seed1_plain.jpg", "req0_seed1_rich.jpg", "req1_seed2_plain.jpg", "req1_seed2_rich.jpg"):
+        assert os.path.exists(tmp_path / "out2" / f), f
+    sample.main(["--rich_text_json", jb, "--seed", "2", "--run_dir", str(tmp_path / "out1")] + common)
+    for kind in ("plain", "rich"):
+        assert open(tmp_path / "out2" / f"req1_seed2_{kind}.jpg", "rb").read() == open(tmp_path / "out1" / f"seed2_{kind}.jpg", "rb").read(), kind
+
+
 def test_lora_checkpoint_merged_at_load_matches_oracle_on_merged_weights(tmp_path):
     """SURVEY 8f row f4 (sample.py:29-30 AnimeXL / README.md:21-22 LoRA checkpoints): a kohya-layout LoRA file merged by
     `load_pipeline(lora_path=...)` must make the ENGINE compute what the oracle computes on explicitly merged weights, and must

@@ -309,3 +309,91 @@ def test_sdxl_vae_config5_size_decode_and_guidance_match_oracle():
         assert abs(loss - loss_ref) < t_loss * abs(loss_ref)
         assert rg < t_grad and ru < t_grad
         v.close()
+
+
+def _guidance_inputs(hw, g, n_color):
+    cm = [(torch.rand(1, 1, 8 * hw, 8 * hw, generator=g) ** 2).repeat(1, 4, 1, 1) for _ in range(n_color + 1)]     # sample.py hands over n_color + 1 masks
+    return {"target_RGB": [torch.rand(1, 3, 1, 1, generator=g) for _ in range(n_color)], "guidance_start_step": 999, "color_guidance_weight": 0.5,
+            "color_obj_atten": cm, "color_obj_atten_all": torch.rand(1, 4, hw, hw, generator=g)}
+
+
+def test_sdxl_config5_guided_loop_through_the_facade(sdxl):
+    """BASELINE config 5 as a LOOP at the full SDXL-base architecture (VERDICT r3 missing 5): `RegionDiffusionXL.sample(...,
+    use_guidance=True, inject_background=0.5)` - CFG 7.5, colour guidance through the PRECISE SDXL VAE (scaling 0.13025) after every
+    step, reference latent stream stepped while i < inject_background * n (xl.py:832) and blended at i == int(0.5 * n) (xl.py:868-872) -
+    against oracle.region_loop.rich_loop_xl with oracle.vae + torch autograd (region_diffusion_sdxl.py:849-872).  2 Euler steps, R = 2,
+    on a 64x64 latent (512x512 image: the oracle costs ~3 s per UNet forward and ~20 s per guidance gradient there; the arithmetic
+    of the 128x128 case is pinned per component by test_sdxl_config3_rich_step_matches_oracle and
+    test_sdxl_vae_config5_size_decode_and_guidance_match_oracle).  Tolerance 3e-2 on the latent change, like the unguided loops."""
+    from oracle.vae import SDXL_VAE_CONFIG, OracleVAEDecoder, random_vae_state_dict
+    from rich_text_to_image_amd.engine import VaeDecoder
+    from rich_text_to_image_amd.region_diffusion_sdxl import RegionDiffusionXL
+    eng, o = sdxl
+    hw, R, steps, gs, isa, ibg = 64, 2, 2, 7.5, 0.0, 0.5
+    g = torch.Generator().manual_seed(29)
+    emb = torch.randn(R + 1, 77, 2048, generator=g)
+    pooled = torch.randn(R + 1, 1280, generator=g)
+    tid = torch.tensor([[512.0, 512.0, 0, 0, 512.0, 512.0]])
+    m = _masks(R, hw, g)
+    masks = [m[r:r + 1] for r in range(R)]
+    lat = torch.randn(1, 4, hw, hw, generator=g)
+    tfd = dict(_guidance_inputs(hw, g, 1), word_pos=torch.tensor([4]), font_size=torch.tensor([8.0]))
+    vsd = random_vae_state_dict(SDXL_VAE_CONFIG, seed=11)
+    sched = OracleEuler(); sched.set_timesteps(steps)
+    guidance = {"vae": OracleVAEDecoder(SDXL_VAE_CONFIG, vsd), "scaling": SDXL_VAE_CONFIG["scaling_factor"]}
+    t0 = time.perf_counter()
+    ref = rich_loop_xl(o, OracleEuler(), emb, pooled, tid, masks, lat * sched.init_noise_sigma, steps, gs, tfd, isa, ibg, use_guidance=True, guidance=guidance)
+    t_ref = time.perf_counter() - t0
+    vae = VaeDecoder(SDXL_VAE_CONFIG, hw, hw, device=0, state_dict=vsd, precise=True)
+    mdl = RegionDiffusionXL(device=0, unet_state_dict="empty", config=SDXL_CONFIG, vae=vae, vae_scaling_factor=SDXL_VAE_CONFIG["scaling_factor"])
+    mdl.unet._engines[(hw, hw)] = eng                                # the module's engine (same weights as the oracle): no second 5 GB arena
+    mdl.masks = masks
+    kw = dict(prompt=None, height=8 * hw, width=8 * hw, num_inference_steps=steps, guidance_scale=gs, prompt_embeds=emb[1:], negative_prompt_embeds=emb[:1],
+              pooled_prompt_embeds=pooled[1:], negative_pooled_prompt_embeds=pooled[:1], output_type="latent", run_rich_text=True, text_format_dict=tfd,
+              inject_selfattn=isa, inject_background=ibg)
+    out = mdl.sample(latents=lat.clone(), use_guidance=True, **kw).images.cpu()
+    plain = mdl.sample(latents=lat.clone(), use_guidance=False, **kw).images.cpu()
+    mdl.unet._engines = {}
+    vae.close()
+    lat0 = lat * sched.init_noise_sigma
+    r = rel_l2(out - lat0, ref - lat0)
+    moved = rel_l2(out - lat0, plain - lat0)
+    print(f"SDXL config-5 loop (guidance + background blend, precise VAE, full architecture @64x64): latent change rel-L2 {r:.3e}; "
+          f"guidance moved the result by {moved:.3e}; oracle {t_ref:.0f} s")
+    assert moved > 1e-4                                               # the guidance step really ran
+    assert r < 3e-2
+
+
+def test_sd15_config2_guided_loop_through_the_facade(sd15):
+    """BASELINE config 2 as a LOOP at the SD-v1.5 architecture and its own size (512x512): `RegionDiffusion.produce_latents(...,
+    use_guidance=True)` - PLMS (2-step schedule = 3 iterations), R = 2, colour guidance on one region through the SD VAE (scaling
+    0.18215, single bf16 pass: rd.py:160 decodes in the checkpoint dtype) after every iteration - against oracle.region_loop.rich_loop_sd
+    with oracle.vae + autograd (region_diffusion.py:151-173)."""
+    from oracle.vae import SD_VAE_CONFIG, OracleVAEDecoder, random_vae_state_dict
+    from rich_text_to_image_amd.engine import VaeDecoder
+    from rich_text_to_image_amd.region_diffusion import RegionDiffusion
+    eng, o = sd15
+    hw, R, steps, gs = 64, 2, 2, 7.5
+    g = torch.Generator().manual_seed(31)
+    emb = torch.randn(R + 1, 77, 768, generator=g)
+    m = _masks(R, hw, g)
+    masks = [m[r:r + 1] for r in range(R)]
+    lat = torch.randn(1, 4, hw, hw, generator=g)
+    tfd = dict(_guidance_inputs(hw, g, 1), word_pos=torch.tensor([2]), font_size=torch.tensor([3.0]))
+    vsd = random_vae_state_dict(SD_VAE_CONFIG, seed=12)
+    guidance = {"vae": OracleVAEDecoder(SD_VAE_CONFIG, vsd), "scaling": SD_VAE_CONFIG["scaling_factor"]}
+    t0 = time.perf_counter()
+    ref = rich_loop_sd(o, OraclePNDM(), emb, masks, lat, steps, gs, tfd, 0, 0, use_guidance=True, guidance=guidance)
+    t_ref = time.perf_counter() - t0
+    vae = VaeDecoder(SD_VAE_CONFIG, hw, hw, device=0, state_dict=vsd)
+    mdl = RegionDiffusion(0, unet_state_dict="empty", config=SD15_CONFIG, vae=vae)
+    mdl.unet._engines[(hw, hw)] = eng
+    mdl.masks = masks
+    out = mdl.produce_latents(emb, num_inference_steps=steps, guidance_scale=gs, latents=lat.clone(), text_format_dict=tfd, use_guidance=True).cpu()
+    plain = mdl.produce_latents(emb, num_inference_steps=steps, guidance_scale=gs, latents=lat.clone(), text_format_dict=tfd, use_guidance=False).cpu()
+    mdl.unet._engines = {}
+    vae.close()
+    r, moved = rel_l2(out, ref), rel_l2(out, plain)
+    print(f"SD-v1.5 config-2 loop (PLMS + colour guidance, full architecture @64x64): final latents rel-L2 {r:.3e}; guidance moved the result by {moved:.3e}; oracle {t_ref:.0f} s")
+    assert moved > 1e-4
+    assert r < 3e-2
