@@ -36,7 +36,7 @@ __device__ long long g_attn_times[4 * 8];
 // workgroup issues half the LDS-DMA pieces per query (2 instead of 4 per wave and 64-key tile) and halves the L2 -> LDS bytes.
 // FOLD (self-attention): the running reference m of the online softmax is subtracted BY THE MATRIX PIPE: one more MFMA k step per
 // 32-key sub-tile with A = (1, 0, ...) for every key and B = (-m, 0, ...) for the lane's query, so the accumulators come out as
-// s - m and the 32 v_sub per tile and wave disappear from the VALU stream that bounds this kernel.  m is kept
+// s - m and the 32 v_sub per tile and wave disappear from the VALU stream that bounds this kernel (LABNOTES 4.3).  m is kept
 // bf16-representable (softmax is invariant to the reference; it only has to stay within 2^8 of the true running maximum), so the
 // product 1 * (-m) is exact.
 template <int DP, int KT, bool CROSS, bool RAGGED = false, int NW = 4, bool FOLD = !CROSS>

@@ -225,10 +225,179 @@ __global__ __launch_bounds__(512) void attn_store16_kernel(AttnStoreArgs p) {
     }
 }
 
-int g_store_legacy = 0;      // debug bit 5 (rt_op_gemm_debug(32)): the two-pass single-wave kernel for every shape (A/B timing)
+// ---------------------------------------------------------------------------------------------- round 4b: statistics + apply (large maps)
+// The one-pass kernel streams ALL keys of every head through each 16-query workgroup: 64 workgroups x 2.6 MB through 64 vector L1s
+// (64 B/clk each) = 41 k cycles before anything else - 102 us measured for a 1024 x 1024 map (profiles/r4_attn_store_bench.txt), i.e.
+// neither HBM nor MFMA but 64 of 256 CUs pulling K through their L1.  For maps of >= 256 keys the work is therefore cut along the
+// KEYS as well, which needs the softmax statistics up front:
+//   attn_store_stats_kernel: one wave per (head, 16 queries), all keys, online (max, sum) -> stats[h][q] = (m, 1 / (H sum))
+//   attn_store_apply_kernel: one workgroup per (16 queries, 128 keys); wave w sums the heads h = w (mod 4) in registers,
+//                            the four partial sums meet in LDS in the order w = 0..3 (deterministic), out (+)= the tile.
+// Every CU now pulls 1 / 4 of a megabyte instead of 2.6.
+template <int DP>
+__global__ __launch_bounds__(256) void attn_store_stats_kernel(AttnStoreArgs p) {
+    constexpr int KSN = DP / 32;
+    typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, q4 = lane >> 4;
+    const int h = blockIdx.y;
+    const int q0 = (blockIdx.x * 4 + wave) * 16;
+    if (q0 >= p.N) return;                                           // wave-uniform; no barriers in this kernel
+    const int qrow = q0 + l15 < p.N ? q0 + l15 : p.N - 1;
+    const bf16_t* qp = p.Q + ((size_t)p.q_row0 + qrow) * p.ldq + h * DP + q4 * 8;
+    bf16x8 qf[KSN];
+#pragma unroll
+    for (int ks = 0; ks < KSN; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 32);
+    const int ntile = p.NKpad >> 4;
+    float m = -1e30f, l = 0.f;
+    bf16x8 kf[4][KSN];
+    auto load4 = [&](int t0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int krow = (t0 + i) * 16 + l15; if (krow > p.NKrows - 1) krow = p.NKrows - 1;
+            const bf16_t* kp = p.K + ((size_t)p.k_row0 + krow) * p.ldk + h * DP + q4 * 8;
+#pragma unroll
+            for (int ks = 0; ks < KSN; ++ks) kf[i][ks] = *(const bf16x8*)(kp + ks * 32);
+        }
+    };
+    load4(0);
+    for (int t0 = 0; t0 < ntile; t0 += 4) {
+        f32x4_t s[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KSN; ++ks) s[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[i][ks], qf[ks], s[i], 0, 0, 0);
+        }
+        if (t0 + 4 < ntile) load4(t0 + 4);
+        float mx = m;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = (t0 + i) * 16 + 4 * q4 + r;
+                if (key >= p.NK) s[i][r] = -INFINITY;
+                mx = fmaxf(mx, s[i][r]);
+            }
+        float rs = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rs += __builtin_amdgcn_exp2f(s[i][r] - mx);
+        l = l * __builtin_amdgcn_exp2f(m - mx) + rs;
+        m = mx;
+    }
+    // the four lanes of a query (q4 = 0..3) hold disjoint key sets: merge (fixed order)
+#pragma unroll
+    for (int d = 16; d <= 32; d <<= 1) {
+        const float mo = __shfl_xor(m, d), lo = __shfl_xor(l, d);
+        const float mn = fmaxf(m, mo);
+        // both partners compute the same two products; add them in the order (lower lane, upper lane) so the result is symmetric
+        const float a = l * __builtin_amdgcn_exp2f(m - mn), b = lo * __builtin_amdgcn_exp2f(mo - mn);
+        l = (lane & d) ? b + a : a + b;
+        m = mn;
+    }
+    if (q4 == 0 && q0 + l15 < p.N) {
+        float2* st = (float2*)p.stats + (size_t)h * p.N + q0 + l15;
+        *st = make_float2(m, 1.f / ((float)p.H * l));
+    }
+}
+
+template <int DP>
+__global__ __launch_bounds__(256) void attn_store_apply_kernel(AttnStoreArgs p) {
+    constexpr int KSN = DP / 32;
+    constexpr int MT = 8;                                            // 128 keys per workgroup
+    typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+    __shared__ f32x4_t part[4][MT][64];                              // 32 KB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, q4 = lane >> 4;
+    const int q0 = blockIdx.x * 16, t0 = blockIdx.y * MT;
+    const int qrow = q0 + l15 < p.N ? q0 + l15 : p.N - 1;
+    const bf16_t* qbase = p.Q + ((size_t)p.q_row0 + qrow) * p.ldq + q4 * 8;
+    const bf16_t* kbase[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        int krow = (t0 + i) * 16 + l15; if (krow > p.NKrows - 1) krow = p.NKrows - 1;
+        kbase[i] = p.K + ((size_t)p.k_row0 + krow) * p.ldk + q4 * 8;
+    }
+    const float2* stat = (const float2*)p.stats + qrow;
+    f32x4_t acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    bf16x8 kf[MT][KSN], qf[KSN];
+    float2 ms = make_float2(0.f, 0.f);
+    auto load_head = [&](int h) {
+#pragma unroll
+        for (int ks = 0; ks < KSN; ++ks) qf[ks] = *(const bf16x8*)(qbase + h * DP + ks * 32);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int ks = 0; ks < KSN; ++ks) kf[i][ks] = *(const bf16x8*)(kbase[i] + h * DP + ks * 32);
+        ms = stat[(size_t)h * p.N];
+    };
+    if (wave < p.H) load_head(wave);
+    for (int h = wave; h < p.H; h += 4) {
+        f32x4_t s[MT];
+        const float m = ms.x, sc = ms.y;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            s[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KSN; ++ks) s[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[i][ks], qf[ks], s[i], 0, 0, 0);
+        }
+        if (h + 4 < p.H) load_head(h + 4);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = (t0 + i) * 16 + 4 * q4 + r;
+                const float e = key < p.NK ? __builtin_amdgcn_exp2f(s[i][r] - m) * sc : 0.f;
+                acc[i][r] += e;
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) part[wave][i][lane] = acc[i];
+    __syncthreads();
+    // wave w finishes tiles 2w, 2w + 1: partial sums of the four head groups in the order 0, 1, 2, 3
+    if (q0 + l15 < p.N) {
+        float* orow = p.out + (size_t)(q0 + l15) * p.NK;
+        const bool vec = (p.NK & 3) == 0 && (((uintptr_t)p.out) & 15) == 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = wave * 2 + j;
+            f32x4_t v = part[0][i][lane];
+            v += part[1][i][lane]; v += part[2][i][lane]; v += part[3][i][lane];
+            const int key = (t0 + i) * 16 + 4 * q4;
+            if (vec && key + 4 <= p.NK) {
+                float4* d = (float4*)(orow + key);
+                float4 o = p.overwrite ? make_float4(0.f, 0.f, 0.f, 0.f) : *d;
+                o.x += v[0]; o.y += v[1]; o.z += v[2]; o.w += v[3];
+                *d = o;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (key + r < p.NK) orow[key + r] = p.overwrite ? v[r] : orow[key + r] + v[r];
+            }
+        }
+    }
+}
+
+int g_store_legacy = 0;      // A/B timing (rt_op_gemm_debug): bit 0 (debug bit 5) the round-1 two-pass single-wave kernel for every shape; bit 1 (debug bit 6) no statistics + apply pair
 void launch_attn_store(const AttnStoreArgs& a, hipStream_t st) {
     RT_REQUIRE(a.NKpad % 32 == 0 && a.NK >= 1 && a.NK <= a.NKpad && a.NKrows >= 1 && a.H >= 1 && a.H <= 32, "attn_store: keys are padded to a multiple of 32; at most 32 heads");
-    if (a.NKpad <= 1024 && a.NKpad % 16 == 0 && !g_store_legacy) {
+    if (a.stats && a.NKpad >= 256 && a.NKpad <= 1024 && a.NKpad % 16 == 0 && a.DP <= 96 && !(g_store_legacy & 3)) {
+        // large maps: statistics pass + key-split accumulation (see above)
+        dim3 gs(cdiv(a.N, 64), a.H), ga(cdiv(a.N, 16), cdiv(a.NKpad, 128)), blk(256);
+        switch (a.DP) {
+            case 32: hipLaunchKernelGGL(attn_store_stats_kernel<32>, gs, blk, 0, st, a); hipLaunchKernelGGL(attn_store_apply_kernel<32>, ga, blk, 0, st, a); break;
+            case 64: hipLaunchKernelGGL(attn_store_stats_kernel<64>, gs, blk, 0, st, a); hipLaunchKernelGGL(attn_store_apply_kernel<64>, ga, blk, 0, st, a); break;
+            default: hipLaunchKernelGGL(attn_store_stats_kernel<96>, gs, blk, 0, st, a); hipLaunchKernelGGL(attn_store_apply_kernel<96>, ga, blk, 0, st, a); break;
+        }
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
+    if (a.NKpad <= 1024 && a.NKpad % 16 == 0 && !(g_store_legacy & 1)) {
         // every map the token-map producer consumes (32x32 self maps, N x 77 cross maps; attention_utils.py:243-248): one pass,
         // 8 waves per 16 query rows
         dim3 grid16(cdiv(a.N, 16)), block16(512);

@@ -183,6 +183,8 @@ struct AttnStoreArgs {
     float* out;                                // [N, NK] fp32 accumulator
     int H, N, NK, NKpad, NKrows, DP;
     int overwrite;                             // 1: out = avg(P); 0: out += avg(P)
+    float* stats;                              // optional scratch [H][N][2] fp32 (softmax max, 1 / (H sum) per (head, query)): enables the
+                                               // statistics + key-split apply pair for maps of >= 256 keys; null: one-pass kernel
 };
 void launch_attn_store(const AttnStoreArgs& a, hipStream_t st);
 

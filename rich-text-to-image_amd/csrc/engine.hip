@@ -518,6 +518,7 @@ struct rt_engine {
                 bf16_t* qk = ws.b16((size_t)M * 2 * HD);
                 bf16_t* vt = ws.b16((size_t)HD * M);
                 bf16_t* o = ws.b16((size_t)M * HD);
+                float* store_stats = ws.f32((size_t)t.heads * HW * 2);      // softmax statistics of the token-map accumulation (attn_store.hip)
                 // Q,K are only needed for streams that some stream attends with (injected region streams use the
                 // text_ref stream's Q,K: attention_processor.py:522-524 discards their own scores)
                 int nqk = 0;
@@ -536,7 +537,7 @@ struct rt_engine {
                         AttnStoreArgs sa{}; sa.Q = qk; sa.ldq = 2 * HD; sa.q_row0 = (long)in.store_stream * HW;
                         sa.K = qk + HD; sa.ldk = 2 * HD; sa.k_row0 = (long)in.store_stream * HW;
                         sa.out = k.store[0]; sa.H = t.heads; sa.N = HW; sa.NK = HW; sa.NKpad = HW; sa.NKrows = HW; sa.DP = t.DP;
-                        sa.overwrite = k.store_mode[0] == 2;
+                        sa.overwrite = k.store_mode[0] == 2; sa.stats = store_stats;
                         prof_begin(RT_PROF_ATTN_STORE, 2.0 * 2.0 * t.heads * (double)HW * HW * t.d, 8.0 * HW * HW + 2.0 * 2.0 * HW * HD);
                         launch_attn_store(sa, stream);
                         prof_end();
@@ -1107,6 +1108,27 @@ static bf16_t* op_zero_page() {       // one page per DEVICE (a thread that driv
     if (!z) { HIP_CHECK(hipMalloc((void**)&z, 256)); HIP_CHECK(hipMemset(z, 0, 256)); }
     return z;
 }
+// statistics scratch of rt_op_attention_probs_avg: one buffer per (device, stream), grown on demand (never under capture: null then,
+// which selects the one-pass kernel)
+static float* op_store_stats(size_t floats, hipStream_t st) {
+    struct Buf { float* p = nullptr; size_t n = 0; };
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, Buf> bufs;
+    int dev = 0; HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    Buf& b = bufs[std::make_pair(dev, st)];
+    if (floats > b.n) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(st, &cap);
+        if (cap != hipStreamCaptureStatusNone) return nullptr;
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (b.p) (void)hipFree(b.p);
+        b.p = nullptr; b.n = 0;
+        HIP_CHECK(hipMalloc((void**)&b.p, floats * 4));
+        b.n = floats;
+    }
+    return b.p;
+}
 #define OP_TRY(...)                                                          \
     try { __VA_ARGS__; return RT_OK; }                                              \
     catch (const rt_error& ex) { g_op_error = ex.what(); return ex.code; }   \
@@ -1114,7 +1136,7 @@ static bf16_t* op_zero_page() {       // one page per DEVICE (a thread that driv
 
 const char* rt_op_last_error(void) { return g_op_error.c_str(); }
 extern int g_store_legacy;
-int rt_op_gemm_debug(int d) { gemm_set_debug(d); g_store_legacy = (d & 32) ? 1 : 0; return RT_OK; }
+int rt_op_gemm_debug(int d) { gemm_set_debug(d); g_store_legacy = ((d & 32) ? 1 : 0) | ((d & 64) ? 2 : 0); return RT_OK; }
 int rt_op_gemm_force_config(int cfg) {
     if (cfg < -1 || cfg > 8) return RT_E_INVALID;
     gemm_force_config(cfg);
@@ -1179,7 +1201,7 @@ int rt_op_gemm16_variant(const void* A, const void* W, const float* bias, void* 
 // processor's arithmetic (models/attention_processor.py:476-545; font-size softmax :386-401) as ONE call:
 //   trunk_out = trunk_in + to_out( softmax_fs( to_q(x) K[prompt]^T ) V[prompt] ) + b_out
 // K / V^T come from the per-prompt cache (77 keys padded to 96; step invariant), Q and O live in caller-provided scratch.  Three
-// launches (to_q GEMM, 96-key attention, to_out GEMM + fp16 residual): why they are not one kernel is measured in DESIGN.md 4.7.
+// launches (to_q GEMM, 96-key attention, to_out GEMM + fp16 residual): why the fused form is not faster is measured in LABNOTES.md R4.1 / 4.8.
 int rt_op_cross_attn_block(const void* x, const void* wq, const void* wo, const float* bo, const void* kcache, const void* vtcache, int ldvt,
                            const int* prompt_host, const int* wset_host, const float* wabs, const float* wsgn, const void* trunk_in,
                            void* trunk_out, void* q_scratch, void* o_scratch, int B, int N, int C, int H, int DP, void* stream) {
@@ -1256,6 +1278,7 @@ int rt_op_attention_probs_avg(const void* Q, int ldq, long long q_row0, const vo
     OP_TRY({
         AttnStoreArgs a{}; a.Q = (const bf16_t*)Q; a.ldq = ldq; a.q_row0 = (long)q_row0; a.K = (const bf16_t*)K; a.ldk = ldk; a.k_row0 = (long)k_row0;
         a.out = out; a.H = H; a.N = N; a.NK = NK; a.NKpad = NKpad; a.NKrows = NKrows; a.DP = DP; a.overwrite = accumulate ? 0 : 1;
+        a.stats = op_store_stats((size_t)H * N * 2, (hipStream_t)stream);
         launch_attn_store(a, (hipStream_t)stream);
     })
 }

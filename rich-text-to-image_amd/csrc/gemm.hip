@@ -592,7 +592,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pp_kernel(GemmArgs p) {
 
 // ================================================================================================
 // Wave-specialised variant: NL loader waves + WMxWN compute waves, 3-slot LDS ring, one s_barrier per K tile.
-// Measured motivation (s_memtime phase probe on MI355X): inside the GEMM loop one
+// Measured motivation (s_memtime phase probe on MI355X, LABNOTES.md 4.1): inside the GEMM loop one
 // global_load_lds_dwordx4 costs the ISSUING wave ~110-140 cycles, i.e. ~1000 cycles per K tile when every
 // wave stages its own share, during which that wave issues no MFMA (in-order issue); the matrix pipe then
 // idles ~40 % of the time.  Here the DMA issue slots are paid by waves that do nothing else, the compute
@@ -902,7 +902,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
 
 // ================================================================================================
 // 3x3 stride-1 convolution on 16x16 pixel patches (conv3p_kernel).  The implicit-GEMM kernels above fetch every input
-// pixel nine times (once per tap) through the L2 -> LDS copy path, which is what bounds them.  Here a
+// pixel nine times (once per tap) through the L2 -> LDS copy path, which is what bounds them (LABNOTES.md 4.1).  Here a
 // block owns a 16x16 output patch x 160 output channels; per 64-channel chunk the 18x18 input HALO is copied to LDS
 // once and the nine taps read their A fragments from it at shifted rows, so the copy traffic per k step drops from
 // 53 KB (A 32 KB + W 20 KB) to 25 KB (halo/9 = 4.6 KB + W 20 KB).  k order: (chunk, tap, c) - different from the

@@ -1,6 +1,6 @@
 """Host logic of the GEMM tile rule (csrc/gemm16.hip::gemm16_pick through rt_op_gemm16_pick; no GPU): the summation class is a pure function
 of ONE stream's shape - never of the batch - which is what makes a stream computed alone and inside a batch give the same bits
-(DESIGN 4.7), and the routing decisions DESIGN quotes for the SDXL / SD-v1.5 shapes."""
+(LABNOTES 4.7), and the routing decisions it quotes for the SDXL / SD-v1.5 shapes."""
 import ctypes as C
 
 import pytest

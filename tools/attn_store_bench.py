@@ -19,8 +19,8 @@ for name, H, N, NK, NKpad, ldq in (("self 1024x1024 (1280 ch)", 20, 1024, 1024, 
     Q = (torch.randn(2 * N, ldq, device=DEV) * 0.5).bfloat16()
     K = Q[:, H * DP:] if ldq == 2 * H * DP else (torch.randn(8 * 96, H * DP, device=DEV) * 0.5).bfloat16()
     out = torch.zeros(N, NK, device=DEV)
-    for legacy in (0, 1):
-        lib.rt_op_gemm_debug(32 if legacy else 0)
+    for legacy, label in ((0, "round 4 default       "), (64, "one-pass (round 4a)   "), (32, "two-pass (round 1)    ")):
+        lib.rt_op_gemm_debug(legacy)
 
         def run():
             chk(lib.rt_op_attention_probs_avg(_ptr(Q), ldq, C.c_longlong(N), C.c_void_p(K.data_ptr()), K.stride(0), C.c_longlong(N if NK == N else 96), _ptr(out),
@@ -35,5 +35,5 @@ for name, H, N, NK, NKpad, ldq in (("self 1024x1024 (1280 ch)", 20, 1024, 1024, 
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 20 * 1e3
         by = 8.0 * N * NK + 2.0 * (N + (NK if NK == N else 96)) * H * DP
-        print(f"{name}: {'two-pass (round 1)' if legacy else 'one-pass (round 4)'} {us:8.1f} us   {by / us / 1e6:.3f} TB/s of algorithmic bytes ({by / 1e6:.1f} MB)")
+        print(f"{name}: {label} {us:8.1f} us   {by / us / 1e6:.3f} TB/s of algorithmic bytes ({by / 1e6:.1f} MB)")
 lib.rt_op_gemm_debug(0)
