@@ -87,9 +87,20 @@ static __device__ __forceinline__ void xattn_stage_head(const GemmArgs& p, char*
 }
 
 // One (16-query row tile, head) unit of a wave.  qrow = first LDS row of the tile, hcol = byte column of the head inside the Q tile.
+#ifdef RT_G16_TIMING
+__device__ long long g_xa_seg[8192 * 8];
+#define XA_T(i) { const long long now_ = __builtin_readcyclecounter(); xa_acc[i] += now_ - xa_last; xa_last = now_; }
+#else
+#define XA_T(i)
+#endif
 template <bool FS>
-static __device__ __forceinline__ void xattn_unit(char* smem, int kvoff, int qrow, int hcol, int nk_valid, int lane) {
+static __device__ __forceinline__ void xattn_unit(char* smem, int kvoff, int qrow, int hcol, int nk_valid, int lane
+#ifdef RT_G16_TIMING
+                                                  , long long* xa_acc, long long& xa_last
+#endif
+                                                  ) {
     const int l15 = lane & 15, q4 = lane >> 4;
+    XA_T(0)                                                          // barrier wait + refill issue in front of the unit
     char* qp = smem + (qrow + l15) * XA_QS + hcol;
     const bf16x8 qf0 = *(const bf16x8*)(qp + q4 * 16), qf1 = *(const bf16x8*)(qp + 64 + q4 * 16);
     const char* kp = smem + kvoff + l15 * 128;
@@ -102,6 +113,7 @@ static __device__ __forceinline__ void xattn_unit(char* smem, int kvoff, int qro
         s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(kp + j * 2048 + o0), qf0, s[j], 0, 0, 0);
         s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(kp + j * 2048 + o1), qf1, s[j], 0, 0, 0);
     }
+    XA_T(1)                                                          // Q / K fragment reads + 12 MFMAs
     // softmax over the 96 (77 valid) keys of the lane's query: 24 values here, the rest in lanes l15 + 16 {1, 2, 3}
     float mx = -INFINITY;
 #pragma unroll
@@ -132,6 +144,7 @@ static __device__ __forceinline__ void xattn_unit(char* smem, int kvoff, int qro
     sum += __shfl_xor(sum, 16);
     sum += __shfl_xor(sum, 32);
     const float inv = 1.f / sum;
+    XA_T(2)                                                          // softmax
     // O^T = V^T P^T: three 32-key steps, four 16-row d tiles
     f32x4_t o[4];
 #pragma unroll
@@ -157,8 +170,10 @@ static __device__ __forceinline__ void xattn_unit(char* smem, int kvoff, int qro
         const unsigned long long w64_ = ((unsigned long long)hi_ << 32) | lo_;                                                 \
         asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(qaddr), "v"(w64_), "n"((DT_) * 32) : "memory");                      \
     }
+    XA_T(3)                                                          // V^T reads + 12 MFMAs
     XA_OWRITE(0) XA_OWRITE(1) XA_OWRITE(2) XA_OWRITE(3)
 #undef XA_OWRITE
+    XA_T(4)
 }
 
 template <int TMW, int TNW, int WN>
@@ -185,19 +200,29 @@ static __device__ __forceinline__ void xattn_tail(const GemmArgs& p, char* smem,
     }
     const int qrow = wave * 16;
     G16_T(3)
+#ifdef RT_G16_TIMING
+    long long xa_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xa_last = __builtin_readcyclecounter();
+#define XA_TARGS , xa_acc, xa_last
+#else
+#define XA_TARGS
+#endif
     // phase h: every wave does (its row tile, head h).  K/V pieces retire in issue order: heads 0, 1 (main loop), 2 (above), 3, 4.
 #define XA_PHASE(H_, KV_, BEHIND_, REFILL_HEAD_, REFILL_KV_)                                                          \
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(BEHIND_) : "memory");                           \
     __builtin_amdgcn_s_barrier();                                                                                     \
     if (REFILL_HEAD_ >= 0) xattn_stage_head(p, smem, REFILL_KV_, head0 + (REFILL_HEAD_ < 0 ? 0 : REFILL_HEAD_), prompt, wave, lane); \
-    if (fs) xattn_unit<true>(smem, KV_, qrow, (H_) * 128, p.xa_nk_valid, lane);                                       \
-    else xattn_unit<false>(smem, KV_, qrow, (H_) * 128, p.xa_nk_valid, lane);
+    if (fs) xattn_unit<true>(smem, KV_, qrow, (H_) * 128, p.xa_nk_valid, lane XA_TARGS);                              \
+    else xattn_unit<false>(smem, KV_, qrow, (H_) * 128, p.xa_nk_valid, lane XA_TARGS);
     XA_PHASE(0, XA_KVA, 6, -1, 0)
     XA_PHASE(1, XA_KVB, 3, 3, XA_KVA)
     XA_PHASE(2, XA_KVC, 3, 4, XA_KVB)
     XA_PHASE(3, XA_KVA, 3, -1, 0)
     XA_PHASE(4, XA_KVB, 0, -1, 0)
 #undef XA_PHASE
+#undef XA_TARGS
+#ifdef RT_G16_TIMING
+    if (tid == 0) for (int i = 0; i < 8; ++i) g_xa_seg[blockIdx.x * 8 + i] = xa_acc[i];
+#endif
     G16_T(5)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -870,4 +895,5 @@ int gemm16_pick(const GemmArgs& a, int weights_on_rows, int* wstat) {
 
 #ifdef RT_G16_TIMING
 void gemm16_read_times(long long* dst, int n) { HIP_CHECK(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_g16_times), (size_t)n * 8)); }
+void gemm16_read_xa_segments(long long* dst, int n) { HIP_CHECK(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_xa_seg), (size_t)n * 8)); }
 #endif

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <algorithm>
 void gemm16_read_times(long long* dst, int n);
+void gemm16_read_xa_segments(long long* dst, int n);
 
 int main() {
     const size_t AE = (size_t)28672 * 1280;
@@ -53,6 +54,14 @@ int main() {
             first = std::min(first, t[w * 8 + 0]); last = std::max(last, t[w * 8 + 4]);
         }
         printf("%s: to_q alone (variant %d) %.1f us | fused to_q + attention %.1f us, %d workgroups\n", sh.name, v, us_q, us_f, nwg);
+        {
+            std::vector<long long> sg((size_t)nwg * 8);
+            gemm16_read_xa_segments(sg.data(), nwg * 8);
+            double a[5] = {0, 0, 0, 0, 0};
+            for (int w = 0; w < nwg; ++w) for (int i = 0; i < 5; ++i) a[i] += (double)sg[w * 8 + i];
+            printf("   attention phases, wave 0, cycles summed over the 5 heads (mean): wait + refill issue %.0f | Q/K reads + QK^T %.0f | softmax %.0f | V^T reads + PV %.0f | O write %.0f\n",
+                   a[0] / nwg, a[1] / nwg, a[2] / nwg, a[3] / nwg, a[4] / nwg);
+        }
         printf("   cycles per workgroup (mean): prologue %.0f | K loop %.0f | Q->LDS + KV2 issue %.0f | 5 phases %.0f | barrier %.0f | store issue %.0f | retire %.0f | total %.0f ; first entry -> last retire %lld\n",
                seg[0] / nwg, seg[1] / nwg, seg[2] / nwg, seg[3] / nwg, seg[4] / nwg, seg[5] / nwg, seg[6] / nwg, tot / nwg, last - first);
     }
