@@ -206,7 +206,7 @@ int rt_op_gemm_force_config(int cfg);
  * implicit-GEMM kernels; bit 1 keep gemm16.hip out; bit 2 no split-K; bit 3 stride-1 3x3 convs stay on the patch kernel (not on the
  * gemm16 main loop); bit 4 cross-attention as to_q GEMM + attention launch instead of the fused kernel;
  * bit 5 token-map accumulation on the round-1 two-pass kernel (csrc/attn_store.hip); bit 6 large maps on the one-pass kernel instead of
- * the statistics + key-split apply pair */
+ * the statistics + key-split apply pair; bit 7 the precise VAE's hi / lo contractions as three launches instead of one */
 int rt_op_gemm_debug(int flags);
 
 /* ---- VAE decoder: colour guidance (rd.py:151-168, xl.py:849-867) and plain decode (rd.py:227-236) ----

@@ -134,6 +134,10 @@ struct GemmArgs {
     int split_tiles;                 // 128x128 output tiles of ONE batch entry's share of the problem (0: unknown).  The split-K rule
                                      // uses it instead of the actual tile count, so a stream's result does not depend on how many
                                      // other streams share the launch (batch invariance); see splitk_slices in gemm.hip
+    // Triple-pass contraction of the VAE's precise mode (vae.hip): out = A W^T + A_lo W^T + A W_lo^T accumulated in ONE fp32 accumulator
+    // (operands as bf16 pairs v = hi + lo).  Null: single pass.  The 3x3 convolution kernels run it as one launch with a three times
+    // longer K loop (no fp32 read-modify-write of the output between passes); launch_gemm falls back to three launches elsewhere.
+    const bf16_t* A_lo; const bf16_t* W_lo;
     // EPI_XATTN (launch_xattn_fused): A = LayerNorm'd tokens [B * xa_tokens, K], W = packed to_q [H * 64, K] (pre-scaled by
     // d^-1/2 log2 e), out = attention output O [M, ldo] bf16.  K / V^T: the per-prompt cross-attention cache (AttnArgs layout).
     const bf16_t* xa_k; const bf16_t* xa_vt;

@@ -971,16 +971,25 @@ __global__ __launch_bounds__(512) void conv3p_kernel(GemmArgs p) {
         if (row >= p.N) row = p.N - 1;
         b_off[i] = row * p.ldw;
     }
+    // Precise VAE (p.A_lo != null): the three passes A W, A_lo W, A W_lo run as ONE K loop of 3 nc1 chunks - chunk c belongs to pass
+    // c / nc1 and reads channel chunk c % nc1 of that pass's operands - so the fp32 output is written once instead of being
+    // read-modify-written by two more launches (537 MB each way at 1024^2 x 128 channels: those launches were HBM bound).
+    const int nc1 = p.Cin >> 6;
     auto stage_halo = [&](int slot, int chunk, int i) {
         const int key = ((a_g[i] << 2) | (lrow >> 1)) & 7;
-        const bf16_t* src = a_off[i] >= 0 ? p.A + a_off[i] + chunk * 64 + ((pslot ^ key) << 3) : p.zero;
+        const int pass = chunk >= 2 * nc1 ? 2 : (chunk >= nc1 ? 1 : 0);
+        const bf16_t* base = pass == 1 ? p.A_lo : p.A;
+        const bf16_t* src = a_off[i] >= 0 ? base + a_off[i] + (chunk - pass * nc1) * 64 + ((pslot ^ key) << 3) : p.zero;
         glds16(src, sA + slot * ASLOT + a_g[i] * 1024);
     };
-    auto stage_w = [&](int slot, int k0) {
+    auto stage_w = [&](int slot, int c3, int t3) {          // W tile of (chunk c3, tap t3)
+        const int pass = c3 >= 2 * nc1 ? 2 : (c3 >= nc1 ? 1 : 0);
+        const bf16_t* base = pass == 2 ? p.W_lo : p.W;
+        const int k0 = t3 * p.Cin + (c3 - pass * nc1) * 64;
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int key = ((b_g[i] << 2) | (lrow >> 1)) & 7;
-            glds16(p.W + b_off[i] + k0 + ((pslot ^ key) << 3), sB + slot * BSLOT + b_g[i] * 1024);
+            glds16(base + b_off[i] + k0 + ((pslot ^ key) << 3), sB + slot * BSLOT + b_g[i] * 1024);
         }
     };
 
@@ -1004,7 +1013,7 @@ __global__ __launch_bounds__(512) void conv3p_kernel(GemmArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
 
-    const int nc = p.Cin >> 6;
+    const int nc = nc1 * (p.A_lo ? 3 : 1);
     const int nsteps = nc * 9;
     auto wait_vm = [&](int n) {                     // n is wave-uniform: 0, 1, NB, NB + 1 or 2 NB
         if (n >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -1018,9 +1027,9 @@ __global__ __launch_bounds__(512) void conv3p_kernel(GemmArgs p) {
     // prologue: whole halo of chunk 0, W tiles of steps 0..2 (nsteps >= 9); halo + W(0) must have landed
 #pragma unroll
     for (int i = 0; i < NAH; ++i) stage_halo(0, 0, i);
-    stage_w(0, 0);
-    stage_w(1, p.Cin);
-    stage_w(2, 2 * p.Cin);
+    stage_w(0, 0, 0);
+    stage_w(1, 0, 1);
+    stage_w(2, 0, 2);
     wait_vm(2 * NB);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -1073,7 +1082,7 @@ __global__ __launch_bounds__(512) void conv3p_kernel(GemmArgs p) {
                     if (tap < NAH && next_chunk) stage_halo((chunk + 1) & 1, chunk + 1, tap);
                     if (s + 3 < nsteps) {
                         const int s3 = s + 3, c3 = s3 / 9, t3 = s3 - c3 * 9;
-                        stage_w(s3 % 3, t3 * p.Cin + c3 * 64);
+                        stage_w(s3 % 3, c3, t3);
                     }
                     fa[nxt] = *(const bf16x8*)(narow + ((hi ^ nkeya) << 4));
 #pragma unroll
@@ -1214,6 +1223,7 @@ static int g_use16 = 1;
 static int g_splitk = 1;
 static int g_conv16 = 1;
 static int g_xattn = 1;
+static int g_no_triple = 0;
 #ifdef RT_PROBE
 int g_conv3p_tn = 0;          // probe override of the patch kernel's column-tile count
 #endif
@@ -1223,6 +1233,7 @@ int g_conv3p_tn = 0;          // probe override of the patch kernel's column-til
 void gemm_set_debug(int flags) {
     g_conv_patch = (flags & 1) ? 0 : 1; g_use16 = (flags & 2) ? 0 : 1; g_splitk = (flags & 4) ? 0 : 1; g_conv16 = (flags & 8) ? 0 : 1;
     g_xattn = (flags & 16) ? 0 : 1;
+    g_no_triple = ((flags & 128) ? 1 : 0) | ((flags & 256) ? 2 : 0) | ((flags & 512) ? 4 : 0);   // (bits 8 / 9: only the gemm16 / only the patch-kernel route)              // bit 7: the precise VAE's contractions as three launches (round 3) instead of one
 }
 bool gemm_xattn_enabled() { return g_xattn != 0 && g_use16 != 0 && g_force_cfg < 0; }
 
@@ -1442,6 +1453,26 @@ void launch_gemm(const GemmArgs& a, hipStream_t st) {
     // In-place residual (out == res) is safe: every element is read and written by the same thread.
     // split-K is a function of the shape only (not of a forced tile configuration, not of stream capture): the same problem
     // always takes the same path.  Debug bit 2 (rt_op_gemm_debug(4)) switches it off for A/B tests.
+    if (a.A_lo || a.W_lo) {
+        // precise VAE contraction A W + A_lo W + A W_lo.  One launch where the kernel runs the three passes as one K loop (3x3
+        // convolutions on the gemm16 main loop and on the patch kernel, fp32 output); everywhere else three launches that accumulate
+        // in the fp32 output, as round 3 did.
+        RT_REQUIRE(a.A_lo && a.W_lo && a.epi == EPI_F32, "gemm: a hi / lo contraction needs both low parts and an fp32 output");
+        bool fused = false;
+        if ((a.mode == A_CONV3 || a.mode == A_CONV3_UP2) && g_force_cfg < 0 && (g_splitk ? splitk_slices(a) : 1) == 1 && !(g_no_triple & 1)) {
+            int ws = 0;
+            const bool to16 = a.mode == A_CONV3 && g_use16 && g_conv16 && g_conv_patch && !a.prefer_patch_conv && gemm16_pick(a, 0, &ws) >= 0;
+            fused = (to16 && !(g_no_triple & 2)) || (!to16 && conv_patch_eligible(a) && !(g_no_triple & 4));        // exactly the two routes below that take these problems
+        }
+        if (!fused) {
+            GemmArgs b = a; b.A_lo = nullptr; b.W_lo = nullptr;
+            launch_gemm(b, st);
+            b.bias = nullptr; b.res = a.out; b.ldres = a.ldo;
+            b.A = a.A_lo; launch_gemm(b, st);
+            b.A = a.A; b.W = a.W_lo; launch_gemm(b, st);
+            return;
+        }
+    }
     const int ksl = g_splitk ? splitk_slices(a) : 1;
     // patch convolutions that cannot fill the chip (< 128 workgroups) go through the split-K implicit GEMM as well
     const bool patch_underfilled = ksl > 1 && a.mode != A_DENSE;

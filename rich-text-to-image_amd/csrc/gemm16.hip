@@ -337,23 +337,25 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void gemm16_kernel(GemmArgs p, i
         pisA[i] = isA;
         ldst[i] = (isA ? 0 : BM * 128) + gl * 1024;
     }
-    const int nk = p.K / BK16;                                       // host guarantees K % 128 == 0 / conv: 9 * Cin / 64, nk >= S + 1
+    // conv, precise VAE: three passes (A W, A_lo W, A W_lo) as one K loop of 3 x 9 x Cin / 64 tiles
+    const bool triple = MODE == A_CONV3 && p.A_lo != nullptr;
+    const int nk = (p.K / BK16) * (triple ? 3 : 1);                  // host guarantees K % 128 == 0 / conv: 9 * Cin / 64, nk >= S + 1
     // conv: (tap, chunk) of the NEXT K tile to be issued, carried as scalars (tiles are issued strictly in order)
     const int nch = MODE == A_CONV3 ? p.Cin / BK16 : 1;
     const unsigned a_range = MODE == A_CONV3 ? (unsigned)p.M * (unsigned)p.Cin * 2u : 0x7fffffffu;
-    int is_tap = 0, is_chunk = 0, is_ky = 0, is_kx = 0;
+    int is_tap = 0, is_chunk = 0, is_ky = 0, is_kx = 0, is_pass = 0;
     int is_pix = -p.Win - 1;                                         // pixel shift of the tap, advanced incrementally (a (ky, kx) product in the
                                                                      // loop made hipcc build a 9-entry table in scratch memory)
     auto stage_piece = [&](int t, int slot_off, int i) {             // piece i of K tile t -> ring slot at slot_off
         if (MODE == A_CONV3 && pisA[i]) {
             const int shift = is_pix * p.Cin * 2;                                       // scalar: (ky - 1) * Win + (kx - 1) pixels
             const int vo = ((tapmask[MODE == A_CONV3 ? i : 0] >> is_tap) & 1) ? voff[i] + shift : RT_G16_OOB;
-            glds16_buf(p.A, vo, is_chunk * (BK16 * 2), smem + slot_off + ldst[i], a_range);
+            glds16_buf(is_pass == 1 ? p.A_lo : p.A, vo, is_chunk * (BK16 * 2), smem + slot_off + ldst[i], a_range);
         } else {
             // conv weights are packed [Cout][tap][Cin]: the K offset of tile (tap, chunk) is tap * Cin + chunk * 64 (= t * 64 in the
             // tap-major order)
             const int wk = MODE == A_CONV3 ? (is_tap * p.Cin + is_chunk * BK16) * 2 : t * (BK16 * 2);
-            glds16_buf(pisA[i] ? (const void*)p.A : (const void*)p.W, voff[i], wk, smem + slot_off + ldst[i]);
+            glds16_buf(pisA[i] ? (const void*)p.A : (const void*)(MODE == A_CONV3 && is_pass == 2 ? p.W_lo : p.W), voff[i], wk, smem + slot_off + ldst[i]);
         }
     };
     // K-tile order of the convolution.  Round 3 ran (tap, chunk): for each tap the whole channel range of the tile's pixels streams
@@ -365,9 +367,10 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void gemm16_kernel(GemmArgs p, i
     auto tile_issued = [&]() {                                       // every piece of a K tile went out: advance (tap, chunk)
         if (MODE == A_CONV3) {
 #ifdef RT_G16_CONV_TAP_MAJOR
-            if (++is_chunk == nch) { is_chunk = 0; ++is_tap; if (++is_kx == 3) { is_kx = 0; ++is_ky; is_pix += p.Win - 2; } else ++is_pix; }
+            if (++is_chunk == nch) { is_chunk = 0; ++is_tap; if (++is_kx == 3) { is_kx = 0; ++is_ky; is_pix += p.Win - 2; } else ++is_pix;
+                                      if (is_tap == 9) { is_tap = 0; is_kx = 0; is_ky = 0; is_pix = -p.Win - 1; ++is_pass; } }
 #else
-            if (++is_tap == 9) { is_tap = 0; is_kx = 0; is_pix = -p.Win - 1; ++is_chunk; }
+            if (++is_tap == 9) { is_tap = 0; is_kx = 0; is_pix = -p.Win - 1; if (++is_chunk == nch) { is_chunk = 0; ++is_pass; } }
             else if (++is_kx == 3) { is_kx = 0; is_pix += p.Win - 2; }
             else ++is_pix;
 #endif

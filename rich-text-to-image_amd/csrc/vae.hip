@@ -182,15 +182,18 @@ struct rt_vae {
 
     // ---------------------------------------------------------------- launch helpers
     void gemm1(const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias, int M, int N, int K, void* out, int ldo, int epi,
-               const float* res, int ldres) {
+               const float* res, int ldres, const bf16_t* A_lo = nullptr, const bf16_t* W_lo = nullptr) {
         GemmArgs g{}; g.A = A; g.W = W; g.bias = bias; g.out = out; g.res = res; g.zero = zero; g.mode = A_DENSE; g.epi = epi;
+        g.A_lo = A_lo; g.W_lo = W_lo;
         g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldo = ldo; g.ldres = ldres;
         launch_gemm(g, stream);
     }
-    void conv1(const bf16_t* in, int mode, const bf16_t* W, const float* bias, int N, int K, int H, int Wd, int CinP, void* out, int epi, const float* res) {
+    void conv1(const bf16_t* in, int mode, const bf16_t* W, const float* bias, int N, int K, int H, int Wd, int CinP, void* out, int epi, const float* res,
+               const bf16_t* in_lo = nullptr, const bf16_t* W_lo = nullptr) {
         int Ho = H, Wo = Wd;
         if (mode == A_CONV3_UP2) { Ho = 2 * H; Wo = 2 * Wd; }
         GemmArgs g{}; g.A = in; g.W = W; g.bias = bias; g.out = out; g.res = res; g.zero = zero; g.mode = mode; g.epi = epi;
+        g.A_lo = in_lo; g.W_lo = W_lo;
         g.M = Ho * Wo; g.N = N; g.K = K; g.ldw = K; g.ldo = N; g.ldres = N; g.rows_per_batch = Ho * Wo; g.Hin = H; g.Win = Wd; g.Cin = CinP;
         g.Hout = Ho; g.Wout = Wo;
         RT_REQUIRE(K == 9 * CinP, "vae conv: weight/input channel mismatch");
@@ -207,11 +210,8 @@ struct rt_vae {
     // ---- dense  out(fp32) = A W^T (+bias) (+res): one pass, or hi*hi + lo*hi + hi*lo accumulated in place (precise)
     void gemm_f32(BT A, int lda, const MatW& W, int M, float* out, int ldo, const float* res = nullptr, int ldres = 0, bool bias = true) {
         if (dry) return;
-        gemm1(A.hi, lda, W.w, W.K, bias ? W.b : nullptr, M, W.N, W.K, out, ldo, EPI_F32, res, ldres);
-        if (precise) {
-            gemm1(A.lo, lda, W.w, W.K, nullptr, M, W.N, W.K, out, ldo, EPI_F32, out, ldo);
-            gemm1(A.hi, lda, W.w_lo, W.K, nullptr, M, W.N, W.K, out, ldo, EPI_F32, out, ldo);
-        }
+        // precise: hi*hi + lo*hi + hi*lo as ONE contraction call (launch_gemm fuses the passes where the kernel can, else three launches)
+        gemm1(A.hi, lda, W.w, W.K, bias ? W.b : nullptr, M, W.N, W.K, out, ldo, EPI_F32, res, ldres, precise ? A.lo : nullptr, precise ? W.w_lo : nullptr);
     }
     // ---- dense with a bf16 operand as the result (precise: fp32 result, then split into the pair)
     BT gemm_b(BT A, int lda, const MatW& W, int M, bool bias = true) {
@@ -224,11 +224,7 @@ struct rt_vae {
     // ---- raw operands (attention score / PV products): both sides are pairs
     void raw_f32(BT A, int lda, BT W, int ldw, int M, int N, int K, float* out, int ldo) {
         if (dry) return;
-        gemm1(A.hi, lda, W.hi, ldw, nullptr, M, N, K, out, ldo, EPI_F32, nullptr, 0);
-        if (precise) {
-            gemm1(A.lo, lda, W.hi, ldw, nullptr, M, N, K, out, ldo, EPI_F32, out, ldo);
-            gemm1(A.hi, lda, W.lo, ldw, nullptr, M, N, K, out, ldo, EPI_F32, out, ldo);
-        }
+        gemm1(A.hi, lda, W.hi, ldw, nullptr, M, N, K, out, ldo, EPI_F32, nullptr, 0, precise ? A.lo : nullptr, precise ? W.lo : nullptr);
     }
     BT raw_b(BT A, int lda, BT W, int ldw, int M, int N, int K) {
         const size_t n = (size_t)M * N;
@@ -240,11 +236,7 @@ struct rt_vae {
     // ---- 3x3 convolutions
     void conv_f32(BT in, int mode, const MatW& W, int H, int Wd, int CinP, float* out, const float* res = nullptr, bool bias = true) {
         if (dry) return;
-        conv1(in.hi, mode, W.w, bias ? W.b : nullptr, W.N, W.K, H, Wd, CinP, out, EPI_F32, res);
-        if (precise) {
-            conv1(in.lo, mode, W.w, nullptr, W.N, W.K, H, Wd, CinP, out, EPI_F32, out);
-            conv1(in.hi, mode, W.w_lo, nullptr, W.N, W.K, H, Wd, CinP, out, EPI_F32, out);
-        }
+        conv1(in.hi, mode, W.w, bias ? W.b : nullptr, W.N, W.K, H, Wd, CinP, out, EPI_F32, res, precise ? in.lo : nullptr, precise ? W.w_lo : nullptr);
     }
     BT conv_b(BT in, int mode, const MatW& W, int H, int Wd, int CinP, bool bias = true) {
         const size_t n = (size_t)H * Wd * W.N;                     // (only stride-1 same-size convolutions produce operands)

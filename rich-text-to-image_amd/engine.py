@@ -84,14 +84,16 @@ def load_library(path=None):
         raise RtError(-3, f"{p} not found: build it with `python __graft_entry__.py build` "
                           "(hipcc --offload-arch=gfx950); there is no fallback path")
     lib = C.CDLL(p)
-    for s in _SYMBOLS:
+    # RTDIFF_ALLOW_MISSING_SYMBOLS: A/B runs against an OLDER build of the library (benchmarks / regression hunts only)
+    names = [s for s in _SYMBOLS if hasattr(lib, s)] if os.environ.get("RTDIFF_ALLOW_MISSING_SYMBOLS") else _SYMBOLS
+    for s in names:
         getattr(lib, s)          # AttributeError if a declared symbol is missing
     lib.rt_last_error.restype = C.c_char_p
     lib.rt_op_last_error.restype = C.c_char_p
     lib.rt_last_error.argtypes = [C.c_void_p]
     lib.rt_vae_last_error.restype = C.c_char_p
     lib.rt_vae_last_error.argtypes = [C.c_void_p]
-    for name in _SYMBOLS:
+    for name in names:
         if name not in ("rt_last_error", "rt_op_last_error", "rt_vae_last_error"):
             getattr(lib, name).restype = C.c_int
     flags = int(os.environ.get("RTDIFF_DEBUG_FLAGS", "0"))      # A/B switches of rt_op_gemm_debug (benchmarks only)
