@@ -559,7 +559,7 @@ struct rt_engine {
                         g.xa_k = k.kcache; g.xa_vt = k.vtcache; g.xa_ldk = HD; g.xa_ldvt = cfg.max_prompts * 96; g.xa_tokens = HW; g.xa_nk_valid = 77;
                         g.xa_wabs = wabs; g.xa_wsgn = wsgn;
                         for (int b = 0; b < B; ++b) { g.xa_prompt[b] = in.prompt[b]; g.xa_wset[b] = in.fontsize[b] ? 1 : -1; }
-                        prof_begin(RT_PROF_GEMM_DENSE, 2.0 * M * HD * C + 4.0 * B * t.heads * (double)HW * 77 * t.d);
+                        prof_begin(RT_PROF_XATTN_FUSED, 2.0 * M * HD * C + 4.0 * B * t.heads * (double)HW * 77 * t.d);
                         launch_xattn_fused(g, stream);
                         prof_end();
                     }
