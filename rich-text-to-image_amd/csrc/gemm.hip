@@ -1263,6 +1263,9 @@ static void launch_conv3p(const GemmArgs& a, hipStream_t st) {
     const double c5 = cost(5, 1.0), c3 = cost(3, 0.72), c2 = cost(2, 0.55);
     int tn = 5;
     double best = c5;
+    // 128-channel column tiles where the channel count is a multiple of 128 but not of 160 (the VAE's 128 / 256 / 512-wide layers: a
+    // 160-wide tile would multiply 20 - 37 % clamped duplicate columns); round 4, same k order as every other TN
+    if (a.N % 128 == 0 && a.N % 160 != 0) { const double c4 = cost(4, 0.86); if (c4 < best * 0.97) { tn = 4; best = c4; } }
     if (c3 < best * 0.97) { tn = 3; best = c3; }
     if (c2 < best * 0.97) { tn = 2; best = c2; }
 #ifdef RT_PROBE
@@ -1270,6 +1273,7 @@ static void launch_conv3p(const GemmArgs& a, hipStream_t st) {
 #endif
     if (tn == 2) launch_conv3p_tn<EPI, UP2, 2>(a, ntm, st);
     else if (tn == 3) launch_conv3p_tn<EPI, UP2, 3>(a, ntm, st);
+    else if (tn == 4) launch_conv3p_tn<EPI, UP2, 4>(a, ntm, st);
     else launch_conv3p_tn<EPI, UP2, 5>(a, ntm, st);
 }
 static bool conv_patch_eligible(const GemmArgs& a) {

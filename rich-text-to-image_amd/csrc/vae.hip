@@ -199,7 +199,9 @@ struct rt_vae {
         RT_REQUIRE(K == 9 * CinP, "vae conv: weight/input channel mismatch");
         // one image: the 224 x 256 tiles of the GEMM-loop convolution fill the chip only from 256^2 x 256 channels upwards (SD 64^2
         // latent: 13.1 ms per guidance call with every layer on it, 11.3 ms on the patch kernel; SDXL 128^2: 39.7 vs 41.0 the other way)
-        g.prefer_patch_conv = (long)g.M * N < 192L * 224 * 256;
+        // ... and every hi / lo (precise) contraction: as ONE launch of three passes the patch kernel runs the 128-channel layers at 1.6 PF
+        // where the GEMM-loop form of the 256-channel layers reaches 0.86 (profiles/r4_vae_precise_kernel_stats.csv)
+        g.prefer_patch_conv = in_lo != nullptr || (long)g.M * N < 192L * 224 * 256;
         launch_gemm(g, stream);
     }
     void split(const float* x, BT o, size_t n) { if (!dry) launch_cast_f32_bf16(x, o.hi, n, stream, o.lo); }

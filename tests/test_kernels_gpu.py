@@ -262,7 +262,8 @@ def test_conv3x3_implicit_gemm(mode, B, H, W_, Cin, Cout):
 
 
 @pytest.mark.parametrize("B,H,W_,Cin,Cout,epi", [(2, 32, 32, 64, 96, 1), (1, 16, 48, 128, 200, 1), (3, 16, 16, 192, 160, 0), (2, 32, 16, 64, 320, 2),
-                                                  (7, 32, 32, 1280, 1280, 1), (2, 64, 64, 640, 320, 2)])
+                                                  (7, 32, 32, 1280, 1280, 1), (2, 64, 64, 640, 320, 2),
+                                                  (1, 64, 64, 128, 128, 1), (1, 32, 32, 256, 256, 1), (2, 16, 32, 64, 512, 0)])   # 128-channel column tiles (VAE widths)
 def test_conv3x3_patch_kernel(B, H, W_, Cin, Cout, epi):
     """The 16x16-patch kernel (halo staged once per 64-channel chunk) against torch AND against the implicit-GEMM kernels
     it replaces (same inputs, `rt_op_gemm_debug(1)` routes around it): k order differs, so agreement is to fp32 rounding."""
