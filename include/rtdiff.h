@@ -159,6 +159,14 @@ int rt_op_gemm16_pick(int conv3x3, int epi, int streams, int rows_per_stream, in
  * Dense only, K % 128 == 0, K >= 256; epi as rt_op_gemm (0, 1, 3, 4). */
 int rt_op_gemm16_variant(const void* A, const void* W, const float* bias, void* out, const void* res, int epi, int M, int N, int K, int lda,
                          int ldw, int ldo, int ldres, int weights_on_rows, int variant, int wstat, void* stream);
+/* attn1's two projections of one LayerNorm output X [M, K] bf16 (models/attention_processor.py:495-506: to_q / to_k / to_v read the same
+ * hidden states) exactly as the engine launches them: qk[Mqk, Nqk] = X[:Mqk] Wqk^T + bqk (stacked, head-padded to_q | to_k; Mqk <= M: the
+ * injected region streams of a rich-text step need no Q / K of their own) and vt[Nv, M] = Wv X^T.  Where the 16x16x32 family has the pair
+ * of tiles (SDXL: both attention levels, 7 and 4 streams) they go out as ONE grouped launch (csrc/gemm16.hip, gemm16_dual_kernel: the
+ * unchanged tile bodies, bit-identical with two launches; rt_op_gemm_debug bit 13 forces two launches); *grouped (may be NULL) says which. */
+int rt_op_gemm_pair_pick(int streams_qk, int streams, int rows_per_stream, int Nqk, int Nv, int K);   /* host-only: 4 / 2 = grouped (tile of Q|K), -1 = two launches */
+int rt_op_gemm_qk_vt(const void* X, int ldx, int K, int rows_per_stream, const void* Wqk, const float* bqk, int Mqk, int Nqk, void* qk, int ldqk,
+                     const void* Wv, int Nv, int M, void* vt, int ldvt, int* grouped, void* stream);
 /* The SDXL cross-attention block the north star names, as one call (replaces attn2 of BasicTransformerBlock, models/attention.py:169-189,
  * processor arithmetic models/attention_processor.py:476-545, font-size softmax :386-401):
  *   trunk_out[B*N, C] (fp16) = trunk_in + to_out(softmax_fs(to_q(x) K[prompt]^T) V[prompt]) + bo
@@ -207,7 +215,8 @@ int rt_op_gemm_force_config(int cfg);
  * implicit-GEMM kernels; bit 1 keep gemm16.hip out; bit 2 no split-K; bit 3 stride-1 3x3 convs stay on the patch kernel (not on the
  * gemm16 main loop); bit 4 cross-attention as to_q GEMM + attention launch instead of the fused kernel;
  * bit 5 token-map accumulation on the round-1 two-pass kernel (csrc/attn_store.hip); bit 6 large maps on the one-pass kernel instead of
- * the statistics + key-split apply pair; bit 7 the precise VAE's hi / lo contractions as three launches instead of one */
+ * the statistics + key-split apply pair; bit 7 the precise VAE's hi / lo contractions as three launches instead of one;
+ * bit 13 attn1's Q|K and V^T projections as two launches instead of one grouped launch */
 int rt_op_gemm_debug(int flags);
 
 /* ---- VAE decoder: colour guidance (rd.py:151-168, xl.py:849-867) and plain decode (rd.py:227-236) ----

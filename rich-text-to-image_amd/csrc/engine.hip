@@ -413,6 +413,24 @@ struct rt_engine {
         launch_gemm(g, stream);
         prof_end();
     }
+    // attn1: the stacked Q|K projection of the first Mqk rows and V^T of all M rows read the same LayerNorm output: ONE grouped launch
+    // where gemm16.hip has the pair of tiles (launch_gemm_pair), otherwise one launch each - the same tile bodies either way
+    void gemm_qk_vt(const bf16_t* X, int ldx, const MatW& Wqk, int Mqk, bf16_t* qk, int ldqk, const MatW& Wv, int M, bf16_t* vt, int ldvt) {
+        GemmArgs a{}; a.A = X; a.W = Wqk.w; a.bias = Wqk.b; a.out = qk; a.zero = zero;
+        a.mode = A_DENSE; a.epi = EPI_BF16; a.M = Mqk; a.N = Wqk.N; a.K = Wqk.K; a.lda = ldx; a.ldw = Wqk.K; a.ldo = ldqk; a.temb_ld = Wqk.N;
+        GemmArgs b{}; b.A = Wv.w; b.W = X; b.bias = nullptr; b.out = vt; b.zero = zero;
+        b.mode = A_DENSE; b.epi = EPI_BF16; b.M = Wv.N; b.N = M; b.K = Wv.K; b.lda = Wv.K; b.ldw = ldx; b.ldo = ldvt;
+        b.weights_on_rows = 1;
+        if (cur_hw > 0) {
+            a.split_tiles = cdiv(cur_hw, 128) * cdiv(Wqk.N, 128); a.rows_per_stream = cur_hw;
+            b.split_tiles = cdiv(Wv.N, 128) * cdiv(cur_hw, 128); b.rows_per_stream = cur_hw;
+        }
+        const bool ra = run_gemm(a), rb = run_gemm(b);
+        if (!ra || !rb) return;
+        prof_begin(RT_PROF_GEMM_DENSE, 2.0 * Mqk * Wqk.N * Wqk.K + 2.0 * M * Wv.N * Wv.K);
+        launch_gemm_pair(a, b, stream);
+        prof_end();
+    }
     void conv3(const bf16_t* in, int mode, const MatW& W, int B, int Hin, int Win, int CinP, void* out, int epi,
                const void* res = nullptr, const float* temb = nullptr) {
         int Hout = Hin, Wout = Win;
@@ -523,8 +541,7 @@ struct rt_engine {
                 // text_ref stream's Q,K: attention_processor.py:522-524 discards their own scores)
                 int nqk = 0;
                 for (int b = 0; b < B; ++b) nqk = std::max(nqk, in.qk_src[b] + 1);
-                gemm(n, C, k.qk1, nqk * HW, qk, 2 * HD, EPI_BF16);
-                gemm_vt(k.v1, n, C, M, vt, M);
+                gemm_qk_vt(n, C, k.qk1, nqk * HW, qk, 2 * HD, k.v1, M, vt, M);
                 if (!dry()) {
                     AttnArgs a{}; a.Q = qk; a.ldq = 2 * HD; a.K = qk + HD; a.ldk = 2 * HD; a.VT = vt; a.ldvt = M; a.O = o; a.ldo = HD;
                     for (int b = 0; b < B; ++b) { a.q_src[b] = in.qk_src[b]; a.k_src[b] = in.qk_src[b]; a.v_src[b] = b; a.wset[b] = 0; }
@@ -1195,6 +1212,34 @@ int rt_op_gemm16_variant(const void* A, const void* W, const float* bias, void* 
         g.mode = A_DENSE; g.epi = epi; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldo = ldo; g.ldres = ldres; g.weights_on_rows = weights_on_rows;
         if (variant < 0) { int ws = 0; variant = gemm16_pick(g, weights_on_rows, &ws); wstat = ws; RT_REQUIRE(variant >= 0, "rt_op_gemm16_variant: the family has no tile for this shape"); }
         launch_gemm16_variant(g, variant, wstat, (hipStream_t)stream);
+    })
+}
+// Host-only query of the grouped-launch rule (tests): tile variant of the Q|K problem (4: 224 x 320, 2: 224 x 256) when attn1's two
+// projections go out as one grouped launch for `streams_qk` / `streams` streams of `rows_per_stream` tokens, -1 when as two launches.
+int rt_op_gemm_pair_pick(int streams_qk, int streams, int rows_per_stream, int Nqk, int Nv, int K) {
+    try {
+        GemmArgs a{}; a.mode = A_DENSE; a.epi = EPI_BF16; a.M = streams_qk * rows_per_stream; a.N = Nqk; a.K = K; a.lda = K; a.ldw = K; a.ldo = Nqk;
+        GemmArgs b{}; b.mode = A_DENSE; b.epi = EPI_BF16; b.M = Nv; b.N = streams * rows_per_stream; b.K = K; b.lda = K; b.ldw = K; b.ldo = b.N; b.weights_on_rows = 1;
+        a.rows_per_stream = b.rows_per_stream = rows_per_stream;
+        a.split_tiles = cdiv(rows_per_stream, 128) * cdiv(Nqk, 128); b.split_tiles = cdiv(Nv, 128) * cdiv(rows_per_stream, 128);
+        return gemm_pair_is_grouped(a, b) ? gemm16_pair_variant(a, b) : -1;
+    } catch (...) { return -3; }
+}
+// attn1's two projections of one LayerNorm output X [M, K] as the engine launches them (launch_gemm_pair): qk[Mqk, Nqk] = X[:Mqk] Wqk^T + bqk
+// and vt[Nv, M] = Wv X^T.  *grouped = 1 when they went out as ONE grouped launch (gemm16_dual_kernel), 0 when as two launches.
+int rt_op_gemm_qk_vt(const void* X, int ldx, int K, int rows_per_stream, const void* Wqk, const float* bqk, int Mqk, int Nqk, void* qk, int ldqk,
+                     const void* Wv, int Nv, int M, void* vt, int ldvt, int* grouped, void* stream) {
+    OP_TRY({
+        GemmArgs a{}; a.A = (const bf16_t*)X; a.W = (const bf16_t*)Wqk; a.bias = bqk; a.out = qk; a.zero = op_zero_page();
+        a.mode = A_DENSE; a.epi = EPI_BF16; a.M = Mqk; a.N = Nqk; a.K = K; a.lda = ldx; a.ldw = K; a.ldo = ldqk; a.temb_ld = Nqk;
+        GemmArgs b{}; b.A = (const bf16_t*)Wv; b.W = (const bf16_t*)X; b.out = vt; b.zero = a.zero;
+        b.mode = A_DENSE; b.epi = EPI_BF16; b.M = Nv; b.N = M; b.K = K; b.lda = K; b.ldw = ldx; b.ldo = ldvt; b.weights_on_rows = 1;
+        if (rows_per_stream > 0) {
+            a.rows_per_stream = b.rows_per_stream = rows_per_stream;
+            a.split_tiles = cdiv(rows_per_stream, 128) * cdiv(Nqk, 128); b.split_tiles = cdiv(Nv, 128) * cdiv(rows_per_stream, 128);
+        }
+        if (grouped) *grouped = gemm_pair_is_grouped(a, b) ? 1 : 0;
+        launch_gemm_pair(a, b, (hipStream_t)stream);
     })
 }
 // The block BASELINE.json's north star names: attn2 of a BasicTransformerBlock (models/attention.py:169-189) with the reference

@@ -1224,6 +1224,7 @@ static int g_splitk = 1;
 static int g_conv16 = 1;
 static int g_xattn = 1;
 static int g_no_triple = 0;
+static int g_pair = 1;
 #ifdef RT_PROBE
 int g_conv3p_tn = 0;          // probe override of the patch kernel's column-tile count
 #endif
@@ -1233,6 +1234,7 @@ int g_conv3p_tn = 0;          // probe override of the patch kernel's column-til
 void gemm_set_debug(int flags) {
     g_conv_patch = (flags & 1) ? 0 : 1; g_use16 = (flags & 2) ? 0 : 1; g_splitk = (flags & 4) ? 0 : 1; g_conv16 = (flags & 8) ? 0 : 1;
     g_xattn = (flags & 16) ? 0 : 1;
+    g_pair = (flags & 8192) ? 0 : 1;                                  // bit 13: attn1's Q|K and V^T projections as two launches instead of one grouped launch
     g_no_triple = ((flags & 128) ? 1 : 0) | ((flags & 256) ? 2 : 0) | ((flags & 512) ? 4 : 0);   // (bits 8 / 9: only the gemm16 / only the patch-kernel route)              // bit 7: the precise VAE's contractions as three launches (round 3) instead of one
 }
 bool gemm_xattn_enabled() { return g_xattn != 0 && g_use16 != 0 && g_force_cfg < 0; }
@@ -1433,7 +1435,7 @@ static void launch_gemm_splitk(const GemmArgs& a, int S, hipStream_t st) {
     HIP_CHECK(hipGetLastError());
 }
 
-void launch_gemm(const GemmArgs& a, hipStream_t st) {
+static void check_gemm_args(const GemmArgs& a) {
     RT_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem");
     RT_REQUIRE(a.K % 8 == 0 && a.ldw % 8 == 0, "gemm: K and ldw must be multiples of 8");
     RT_REQUIRE(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0, "gemm: operands must be 16-B aligned");
@@ -1454,6 +1456,10 @@ void launch_gemm(const GemmArgs& a, hipStream_t st) {
     if (a.res) RT_REQUIRE(a.ldres % 4 == 0 && ((uintptr_t)a.res & 15) == 0, "gemm: residual must be 16-B aligned");
     if (a.bias) RT_REQUIRE(((uintptr_t)a.bias & 15) == 0, "gemm: bias must be 16-B aligned");
     if (a.temb) RT_REQUIRE(a.temb_ld % 4 == 0 && ((uintptr_t)a.temb & 15) == 0, "gemm: temb must be 16-B aligned");
+}
+
+void launch_gemm(const GemmArgs& a, hipStream_t st) {
+    check_gemm_args(a);
     // In-place residual (out == res) is safe: every element is read and written by the same thread.
     // split-K is a function of the shape only (not of a forced tile configuration, not of stream capture): the same problem
     // always takes the same path.  Debug bit 2 (rt_op_gemm_debug(4)) switches it off for A/B tests.
@@ -1504,4 +1510,20 @@ void launch_gemm(const GemmArgs& a, hipStream_t st) {
         if (v >= 0) { launch_gemm16_variant(a, v, wstat, st); return; }
     }
     launch_with_cfg(a, pick_config(a), st);
+}
+
+// Two independent dense problems that read the same activations (attn1: the stacked Q|K projection and V^T = Wv X^T): ONE grouped
+// launch of the 16x16x32 family where both take it and a grouped instantiation exists (gemm16.hip, gemm16_dual_kernel: the same tile
+// bodies, bit-identical results), otherwise one launch each.  Like every routing decision here a function of the shapes only.
+bool gemm_pair_is_grouped(const GemmArgs& a, const GemmArgs& b) {
+    return g_pair && g_force_cfg < 0 && g_use16 && a.mode == A_DENSE && b.mode == A_DENSE && (g_splitk ? splitk_slices(a) : 1) == 1 &&
+           (g_splitk ? splitk_slices(b) : 1) == 1 && gemm16_pair_variant(a, b) >= 0;
+}
+void launch_gemm_pair(const GemmArgs& a, const GemmArgs& b, hipStream_t st) {
+    if (gemm_pair_is_grouped(a, b)) {
+        check_gemm_args(a); check_gemm_args(b);
+        if (launch_gemm16_pair(a, b, st)) return;
+    }
+    launch_gemm(a, st);
+    launch_gemm(b, st);
 }

@@ -258,459 +258,31 @@ static __device__ __forceinline__ void xattn_tail(const GemmArgs& p, char* smem,
 // the lane's pixel address shifted by the tap, with the padding taps sent out of the descriptor's range so that they read as zeros.
 // It re-reads every input pixel nine times (tap-inner K order: from the vL1D / L2), which the patch kernel of gemm.hip avoids, but runs the 224-row / K-split
 // main loop whose LDS array is not the bottleneck: 32^2 x 1280 -> 1280 for 7 streams is a 7168 x 1280 x 11520 GEMM.
+//
+// The body of one output tile lives in gemm16_body.inl (see there why it is included twice).  `bid_in` = the workgroup's linear id inside
+// ITS problem's grid: blockIdx.x for a plain launch, blockIdx.x minus the first problem's workgroups inside a grouped launch.
+template <int MODE, int EPI, int TMW, int TNW, int WM, int WN, int WK, int S>
+static __device__ __forceinline__ void gemm16_tile(const GemmArgs& p, const int wstat, const unsigned bid_in) {
+#include "gemm16_body.inl"
+}
+
 template <int MODE, int EPI, int TMW, int TNW, int WM, int WN, int WK, int S>
 __global__ __launch_bounds__(WM * WN * WK * 64) void gemm16_kernel(GemmArgs p, int wstat) {
-    constexpr int NW = WM * WN * WK;                       // 8 waves (two per SIMD) or 4 waves (one per SIMD, 512 registers each)
-    static_assert(NW == 8 || NW == 4, "4 or 8 waves");
-    static_assert(WK == 1 || (WK == 2 && S == 3), "K split over at most two waves (3-slot ring)");
-    constexpr int BM = WM * TMW * 16, BN = WN * TNW * 16;
-    constexpr int STAGE = (BM + BN) * 128;                 // bytes per ring slot: A rows then W rows, 128 B (64 k) each
-    constexpr int GA = BM / 8, GB = BN / 8, GT = GA + GB;  // 8-row groups = one wave-wide LDS-DMA each
-    constexpr int PW = (GT + NW - 1) / NW;                 // LDS-DMA pieces per wave and K tile
-    constexpr int KS = 2 / WK;                             // 32-deep k steps per K tile and wave
-    static_assert(EPI != EPI_GEGLU || TNW % 4 == 0, "GEGLU: a wave owns whole packed 64-column blocks [32 value | 32 gate]");
-    static_assert((S - 2) * PW <= 63 && S >= 2 && S <= 3, "ring depth");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    G16_T(0)
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kh = WK == 2 ? (wave & 1) : 0;
-    const int wq = WK == 2 ? (wave >> 1) : wave;
-    const int wm = wq / WN, wn = wq % WN;
+    const unsigned bid_in = blockIdx.x;
+#include "gemm16_body.inl"
+}
 
-    // ---- tile mapping.  Default: XCD-aware bijective remap (each XCD gets a contiguous run of tiles) + groups of 4 tile rows x all
-    // tile columns.  wstat (wide N, e.g. GEGLU): every XCD owns ntn/8 tile COLUMNS for all tile rows, so its share of W stays in its
-    // 4 MiB L2 for the whole launch and W is fetched from HBM exactly once (the grouped order re-fetched the 26 MB GEGLU weight 7 x).
-    const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM, nwg = ntm * ntn;
-    int tm, tn;
-    if (wstat) {
-        const int cpx = ntn >> 3, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;   // host guarantees ntn % 8 == 0
-        tn = xcd * cpx + idx % cpx; tm = idx / cpx;
-    } else {
-        int bid = blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        constexpr int GRP = 4;
-        const int gsz = GRP * ntn;
-        const int first_m = (bid / gsz) * GRP;
-        const int gm = (ntm - first_m) < GRP ? (ntm - first_m) : GRP;
-        tm = first_m + (bid % gsz) % gm; tn = (bid % gsz) / gm;
-    }
-    const int m0 = tm * BM, n0 = tn * BN;
-    // EPI_XATTN: the tile's stream (a 128-row tile never straddles: xa_tokens % 128 == 0), its prompt / multiplier set, first head
-    const int xa_b = EPI == EPI_XATTN ? m0 / p.xa_tokens : 0;
-    const int xa_prompt = EPI == EPI_XATTN ? p.xa_prompt[xa_b] : 0, xa_wset = EPI == EPI_XATTN ? p.xa_wset[xa_b] : -1;
-    const int xa_head0 = n0 >> 6;
-
-    // ---- loader: piece i of this wave copies 8-row group g = i*NW + wave of the (A rows | W rows) list.  Buffer-descriptor LDS-DMA
-    // (buffer_load_dwordx4 ... offen lds, guide T8): per piece ONE 32-bit VGPR byte offset, the K-tile offset is a scalar (soffset)
-    // and the operand base sits in an SGPR descriptor - the flat form kept a 64-bit address per piece alive and spilled in the loop.
-    const int lrow = lane >> 3, pslot = lane & 7;
-    int voff[PW];                       // byte offset of this lane's 16-B chunk at k0 = 0 (conv: of its pixel's channel vector)
-    int ldst[PW];                       // LDS byte offset of the group inside a ring slot (wave-uniform)
-    bool pisA[PW];                      // wave-uniform
-    int tapmask[MODE == A_CONV3 ? PW : 1];   // conv, A pieces: bit t set <=> tap t of this lane's pixel lies inside the image
-#pragma unroll
-    for (int i = 0; i < PW; ++i) {
-        int g = i * NW + wave; if (g > GT - 1) g = GT - 1;          // tail duplicates copy the same bytes to the same place
-        const bool isA = g < GA;
-        const int gl = isA ? g : g - GA;
-        int row = (isA ? m0 : n0) + gl * 8 + lrow;
-        const int lim = isA ? p.M : p.N;
-        if (row >= lim) row = lim - 1;
-        const int key = ((gl << 2) | (lrow >> 1)) & 7;              // (tile row >> 1) & 7
-        if (MODE == A_CONV3 && isA) {
-            const int b = row / p.rows_per_batch, pix = row - b * p.rows_per_batch;
-            const int y = pix / p.Win, x = pix - y * p.Win;
-            voff[i] = (row * p.Cin + ((pslot ^ key) << 3)) * 2;     // NHWC, stride 1: output pixel index == input pixel index
-            int m = 0;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-                if (yy >= 0 && yy < p.Hin && xx >= 0 && xx < p.Win) m |= 1 << t;
-            }
-            tapmask[MODE == A_CONV3 ? i : 0] = m;
-        } else {
-            voff[i] = (row * (isA ? p.lda : p.ldw) + ((pslot ^ key) << 3)) * 2;
-            if (MODE == A_CONV3) tapmask[MODE == A_CONV3 ? i : 0] = 0;
-        }
-        pisA[i] = isA;
-        ldst[i] = (isA ? 0 : BM * 128) + gl * 1024;
-    }
-    // conv, precise VAE: three passes (A W, A_lo W, A W_lo) as one K loop of 3 x 9 x Cin / 64 tiles
-    const bool triple = MODE == A_CONV3 && p.A_lo != nullptr;
-    const int nk = (p.K / BK16) * (triple ? 3 : 1);                  // host guarantees K % 128 == 0 / conv: 9 * Cin / 64, nk >= S + 1
-    // conv: (tap, chunk) of the NEXT K tile to be issued, carried as scalars (tiles are issued strictly in order)
-    const int nch = MODE == A_CONV3 ? p.Cin / BK16 : 1;
-    const unsigned a_range = MODE == A_CONV3 ? (unsigned)p.M * (unsigned)p.Cin * 2u : 0x7fffffffu;
-    int is_tap = 0, is_chunk = 0, is_ky = 0, is_kx = 0, is_pass = 0;
-    int is_pix = -p.Win - 1;                                         // pixel shift of the tap, advanced incrementally (a (ky, kx) product in the
-                                                                     // loop made hipcc build a 9-entry table in scratch memory)
-    auto stage_piece = [&](int t, int slot_off, int i) {             // piece i of K tile t -> ring slot at slot_off
-        if (MODE == A_CONV3 && pisA[i]) {
-            const int shift = is_pix * p.Cin * 2;                                       // scalar: (ky - 1) * Win + (kx - 1) pixels
-            const int vo = ((tapmask[MODE == A_CONV3 ? i : 0] >> is_tap) & 1) ? voff[i] + shift : RT_G16_OOB;
-            glds16_buf(is_pass == 1 ? p.A_lo : p.A, vo, is_chunk * (BK16 * 2), smem + slot_off + ldst[i], a_range);
-        } else {
-            // conv weights are packed [Cout][tap][Cin]: the K offset of tile (tap, chunk) is tap * Cin + chunk * 64 (= t * 64 in the
-            // tap-major order)
-            const int wk = MODE == A_CONV3 ? (is_tap * p.Cin + is_chunk * BK16) * 2 : t * (BK16 * 2);
-            glds16_buf(pisA[i] ? (const void*)p.A : (const void*)(MODE == A_CONV3 && is_pass == 2 ? p.W_lo : p.W), voff[i], wk, smem + slot_off + ldst[i]);
-        }
-    };
-    // K-tile order of the convolution.  Round 3 ran (tap, chunk): for each tap the whole channel range of the tile's pixels streams
-    // by, so the nine re-reads of a pixel are a full A panel apart (224 rows x Cin x 2 B = 573 KB per workgroup, 18 MB per XCD against
-    // 4 MiB of L2): 615 - 936 MB per launch came over the fabric for 221 MB of operands (profiles/r3_pmc_traffic.json).  Round 4:
-    // (chunk, tap) - the nine taps of one 64-channel chunk follow each other, the shifted rows they re-read are 28 KB per workgroup
-    // and still in the vL1D / L2.  Same k order as the patch kernel of gemm.hip.  -DRT_G16_CONV_TAP_MAJOR builds the old order (A/B
-    // timing: `make tapmajor` + RTDIFF_LIB_PATH).
-    auto tile_issued = [&]() {                                       // every piece of a K tile went out: advance (tap, chunk)
-        if (MODE == A_CONV3) {
-#ifdef RT_G16_CONV_TAP_MAJOR
-            if (++is_chunk == nch) { is_chunk = 0; ++is_tap; if (++is_kx == 3) { is_kx = 0; ++is_ky; is_pix += p.Win - 2; } else ++is_pix;
-                                      if (is_tap == 9) { is_tap = 0; is_kx = 0; is_ky = 0; is_pix = -p.Win - 1; ++is_pass; } }
-#else
-            if (++is_tap == 9) { is_tap = 0; is_kx = 0; is_pix = -p.Win - 1; if (++is_chunk == nch) { is_chunk = 0; ++is_pass; } }
-            else if (++is_kx == 3) { is_kx = 0; is_pix += p.Win - 2; }
-            else ++is_pix;
-#endif
-            (void)is_ky;
-        }
-    };
-
-    // ---- fragments: lane (l15, q): row l15 of a 16-row tile, 16-B chunk c = 4*khalf + q of the 128-B row
-    const int l15 = lane & 15, q4 = lane >> 4;
-    const int key = (l15 >> 1) & 7;                                  // tile bases are multiples of 16 rows: the key depends on l15 only
-    int aoff[KS], boff[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const int c = (WK == 2 ? kh : ks) * 4 + q4;
-        aoff[ks] = (wm * TMW * 16 + l15) * 128 + ((c ^ key) << 4);
-        boff[ks] = BM * 128 + (wn * TNW * 16 + l15) * 128 + ((c ^ key) << 4);
-    }
-    f32x4_t acc[TMW][TNW];
-#pragma unroll
-    for (int i = 0; i < TMW; ++i)
-#pragma unroll
-        for (int j = 0; j < TNW; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    // ---- prologue: all S slots in flight; tile 0 landed; fragments of k step 0 in registers
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-#pragma unroll
-        for (int i = 0; i < PW; ++i) stage_piece(s, s * STAGE, i);
-        tile_issued();
-    }
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 1) * PW) : "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    G16_T(1)
-    bf16x8 fa[TMW], fb[2][TNW];
-#pragma unroll
-    for (int j = 0; j < TNW; ++j) fb[0][j] = *(const bf16x8*)(smem + boff[0] + j * 2048);
-#pragma unroll
-    for (int i = 0; i < TMW; ++i) fa[i] = *(const bf16x8*)(smem + aoff[0] + i * 2048);
-
-    // One k step.  CUR: which W fragment set it multiplies.  KSI: k step inside the tile.  NEXT: 0 = no further step,
-    // 1 = next step is in the same K tile, 2 = next step opens K tile t+1: wait for it (BEHIND = K tiles that may stay in flight
-    // behind it) + barrier, then - REFILL - copy tile t+S into tile t's slot.
-    // cur_off / nxt_off: LDS byte offsets of the slots of tiles t and t+1 (scalars carried by the loop; no modulo arithmetic in
-    // the loop: hipcc's strength reduction turned `% 3` into per-fragment VGPR induction variables that spilled).
-    auto kstep = [&](int t, int cur_off, int nxt_off, auto cur_c, auto ksi_c, auto next_c, auto refill_c, auto behind_c) {
-        constexpr int CUR = decltype(cur_c)::value, KSI = decltype(ksi_c)::value, NEXT = decltype(next_c)::value;
-        constexpr bool REFILL = decltype(refill_c)::value != 0;
-        constexpr int BEHIND = decltype(behind_c)::value;
-        constexpr int NKS = NEXT == 1 ? KSI + 1 : 0;                 // k step index of the next step inside its tile
-        const int rd = __builtin_amdgcn_readfirstlane(NEXT == 2 ? nxt_off : cur_off);
-        const char* na = smem + rd + aoff[NKS];
-        const char* nbb = smem + rd + boff[NKS];
-        // row 0 first: its operands were read a whole step ago, and the last fragment read of the previous step (issued behind
-        // that step's last MFMA row) retires behind these MFMAs instead of in front of the barrier
-#pragma unroll
-        for (int j = 0; j < TNW; ++j) {
-#if RT_G16_ABLATE == 2
-            asm volatile("" ::"v"(fb[CUR][j]), "v"(fa[0]));
-#else
-            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[CUR][j], fa[0], acc[0][j], 0, 0, 0);
-#endif
-        }
-        if constexpr (NEXT == 2) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // every fragment read of tile t is retired: its slot may be refilled
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BEHIND * PW) : "memory");   // this wave's pieces of tile t+1 landed
-            __builtin_amdgcn_s_barrier();
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (NEXT != 0) {
-#pragma unroll
-            for (int j = 0; j < TNW; ++j) fb[CUR ^ 1][j] = *(const bf16x8*)(nbb + j * 2048);
-            fa[0] = *(const bf16x8*)(na);
-        }
-#pragma unroll
-        for (int i = 1; i < TMW; ++i) {
-#pragma unroll
-            for (int j = 0; j < TNW; ++j) {
-#if RT_G16_ABLATE == 2
-                asm volatile("" ::"v"(fb[CUR][j]), "v"(fa[i]));
-#else
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[CUR][j], fa[i], acc[i][j], 0, 0, 0);
-#endif
-            }
-            if constexpr (NEXT != 0) fa[i] = *(const bf16x8*)(na + i * 2048);
-            if constexpr (NEXT == 2 && REFILL) {
-                // LDS-DMA issue slots spread behind the MFMA rows (a piece costs its wave 60-200 cycles of issue under load)
-                constexpr int PPR = (PW + TMW - 2) / (TMW - 1);      // pieces per MFMA row
-#if RT_G16_ABLATE != 1
-#pragma unroll
-                for (int pc = 0; pc < PPR; ++pc) { const int pi = (i - 1) * PPR + pc; if (pi < PW) stage_piece(t + S, cur_off, pi); }
-#endif
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if constexpr (NEXT == 2 && REFILL) tile_issued();
-    };
-    using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>; using C2 = std::integral_constant<int, 2>;
-    using CS2 = std::integral_constant<int, S - 2>;
-    int cur_off = 0, nxt_off = STAGE;
-    auto advance = [&]() { cur_off = nxt_off; nxt_off = nxt_off + STAGE == S * STAGE ? 0 : nxt_off + STAGE; };
-    // Tiles t <= nk-S-1 refill their slot (steady state); the last S tiles do not, and the wait in front of tile t+1 allows exactly
-    // the min(S-2, nk-2-t) younger tiles that were issued: no dummy copies, nothing to drain behind the loop.
-    if constexpr (KS == 1) {
-        // K-split class: CUR alternates per tile, so tiles run in pairs; the host guarantees an even tile count, S = 3, nk >= 4
-        int t = 0;
-        for (; t + 6 <= nk; t += 2) {
-            kstep(t, cur_off, nxt_off, C0{}, C0{}, C2{}, C1{}, CS2{}); advance();
-            kstep(t + 1, cur_off, nxt_off, C1{}, C0{}, C2{}, C1{}, CS2{}); advance();
-        }
-        kstep(t, cur_off, nxt_off, C0{}, C0{}, C2{}, C1{}, CS2{}); advance();            // t = nk-4: the last refill (tile nk-1)
-        kstep(t + 1, cur_off, nxt_off, C1{}, C0{}, C2{}, C0{}, C1{}); advance();         // nk-3: tile nk-1 may stay in flight
-        kstep(t + 2, cur_off, nxt_off, C0{}, C0{}, C2{}, C0{}, C0{}); advance();         // nk-2
-        kstep(t + 3, cur_off, nxt_off, C1{}, C0{}, C0{}, C0{}, C0{});                    // nk-1
-    } else {
-        int t = 0;
-        for (; t + S < nk; ++t) {
-            kstep(t, cur_off, nxt_off, C0{}, C0{}, C1{}, C0{}, C0{});
-            kstep(t, cur_off, nxt_off, C1{}, C1{}, C2{}, C1{}, CS2{}); advance();
-        }
-        if constexpr (S == 3) {                                                          // t = nk-3
-            kstep(t, cur_off, nxt_off, C0{}, C0{}, C1{}, C0{}, C0{});
-            kstep(t, cur_off, nxt_off, C1{}, C1{}, C2{}, C0{}, C1{}); advance(); ++t;
-        }
-        kstep(t, cur_off, nxt_off, C0{}, C0{}, C1{}, C0{}, C0{});                        // t = nk-2
-        kstep(t, cur_off, nxt_off, C1{}, C1{}, C2{}, C0{}, C0{}); advance(); ++t;
-        if constexpr (EPI == EPI_XATTN) {
-            // nothing of the ring is in flight any more: K / V^T of the tile's first two heads, into the LDS beyond the ring,
-            // land behind the last K tile's MFMAs
-            xattn_stage_head(p, smem, XA_KVA, xa_head0, xa_prompt, wave, lane);
-            xattn_stage_head(p, smem, XA_KVB, xa_head0 + 1, xa_prompt, wave, lane);
-        }
-        kstep(t, cur_off, nxt_off, C0{}, C0{}, C1{}, C0{}, C0{});                        // t = nk-1
-        kstep(t, cur_off, nxt_off, C1{}, C1{}, C0{}, C0{}, C0{});
-    }
-    G16_T(2)
-    if constexpr (EPI == EPI_XATTN) {
-        xattn_tail<TMW, TNW, WN>(p, smem, acc, m0, n0, wm, wn, wave, lane, tid, xa_prompt, xa_head0, xa_wset);
-        return;
-    }
-
-    // ---- which 16-row tiles this wave finishes: K-split: kh = 0 owns row tiles [0, H0), kh = 1 owns [H0, TMW)
-    constexpr int H0 = WK == 2 ? (TMW + 1) / 2 : TMW;
-    auto owned = [&](int i) { return WK == 1 || ((i < H0) == (kh == 0)); };           // wave-uniform
-    constexpr bool F16 = EPI == EPI_F16;
-    constexpr bool TEMB = EPI == EPI_BF16_TEMB;                      // bf16 out + the per-image time-embedding row (resnet.py:611-613)
-    constexpr bool F32 = EPI == EPI_F32 || F16;                      // fp32 slab; F16: fp16 in HBM (output and residual), rounded once
-    constexpr int ES = F32 ? 4 : 2;
-    constexpr int TNO = EPI == EPI_GEGLU ? TNW / 2 : TNW;            // 16-column output tiles per wave
-    const int NO = EPI == EPI_GEGLU ? (p.N >> 1) : p.N;
-    const int wcol0 = n0 + wn * TNW * 16;                            // first (packed) column of this wave
-    const int ocol0 = EPI == EPI_GEGLU ? (wcol0 >> 1) : wcol0;
-    // fp16 residual of the owned tiles: requested NOW, ahead of the K-split exchange / the first slab transposes, so that its HBM
-    // round trip is paid once and in the shadow of that work (issued tile by tile inside the store loop it was paid TMW times:
-    // 14.5 k of the 51 k cycles of a 7168 x 1280 x 1280 launch, profiles/r3_gemm16_probe_v1_timing.txt)
-    constexpr int IPR = TNO * 16 / 8;                                // 8-column items per row
-    constexpr int NIT = (16 * IPR + 63) / 64;
-    // a rolling window of RW owned tiles (static register indices: the s-th owned tile of a wave is tile s or H0 + s)
-    constexpr int NOWN = WK == 2 ? H0 : TMW;                         // owned tiles of the kh = 0 half (kh = 1 owns TMW - H0 <= H0)
-    constexpr int RW = NOWN < 4 ? NOWN : 4;
-    uint4 rres[F16 ? RW : 1][F16 ? NIT : 1];
-    auto load_res = [&](int s_own, int slot) {                       // residual of the s_own-th owned tile -> window slot (static)
-        const int i = (WK == 2 && kh == 1) ? H0 + s_own : s_own;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int idx = it * 64 + lane;
-            const int r = idx / IPR, c8 = idx - r * IPR;
-            int row = m0 + (wm * TMW + i) * 16 + r; if (row >= p.M) row = p.M - 1;
-            int col = ocol0 + c8 * 8; if (col >= NO) col = 0;
-            if (F16) rres[F16 ? slot : 0][F16 ? it : 0] = (r < 16 && i < TMW) ? *(const uint4*)((const f16_t*)p.res + (size_t)row * p.ldres + col) : uint4{0, 0, 0, 0};
-        }
-    };
-    // K-split forms: ahead of the exchange (its round trip, 7 - 8 k cycles for the chip-wide 18 MB burst, hides behind the LDS pass:
-    // 29.4 vs 31.6 us per 7168 x 1280 x 1280 launch); class A has no exchange to hide behind and measured better with the request
-    // after the post-loop barrier (ff.net.2 28672 x 640 x 2560: 74.1 -> 69.7 us, to_out 640: 30.2 -> 28.6 us)
-    constexpr bool RES_EARLY = WK == 2;
-    if constexpr (F16 && RES_EARLY) {
-        if (p.res) {
-#pragma unroll
-            for (int s_own = 0; s_own < RW; ++s_own) load_res(s_own, s_own);
-        }
-    }
-    // bias of this wave's columns: requested here as well (the fragment registers of the main loop are dead), so that its round trip
-    // (1.0-1.3 k cycles when it opened the epilogue, profiles/r3_gemm16_probe_v5_epilogue_breakdown.txt) hides behind the barrier / exchange
-    float bias_v[TNO][4], bias_g[EPI == EPI_GEGLU ? TNO : 1][4];
-    auto load_bias = [&]() {
-#pragma unroll
-    for (int t = 0; t < TNO; ++t) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { bias_v[t][e] = 0.f; if (EPI == EPI_GEGLU) bias_g[t][e] = 0.f; }
-        if (p.bias) {
-            if constexpr (EPI == EPI_GEGLU) {
-                // packed columns: per 64-block [32 value | 32 gate]; output tile t (16 columns) = value tile 4*(t/2) + t%2, gate + 2
-                const int col = wcol0 + ((t >> 1) * 4 + (t & 1)) * 16 + 4 * q4;
-                if (col + 32 + 4 <= p.N) {
-                    const float4 b0 = *(const float4*)(p.bias + col), b1 = *(const float4*)(p.bias + col + 32);
-                    bias_v[t][0] = b0.x; bias_v[t][1] = b0.y; bias_v[t][2] = b0.z; bias_v[t][3] = b0.w;
-                    bias_g[t][0] = b1.x; bias_g[t][1] = b1.y; bias_g[t][2] = b1.z; bias_g[t][3] = b1.w;
-                }
-            } else {
-                const int col = wcol0 + t * 16 + 4 * q4;
-                if (col < p.N) {
-                    const float4 b0 = *(const float4*)(p.bias + col);
-                    bias_v[t][0] = b0.x; bias_v[t][1] = b0.y; bias_v[t][2] = b0.z; bias_v[t][3] = b0.w;
-                }
-            }
-        }
-    }
-    };
-    constexpr bool BIAS_EARLY = !F16 && MODE == A_DENSE;                                // (the fp16-trunk forms hold the residual window here: hoisting the bias too spills)
-    if constexpr (BIAS_EARLY) load_bias();
-    // raw barriers from here on: a __syncthreads() carries s_waitcnt vmcnt(0) and would wait for the residual round trip
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                                    // every wave left the ring: exchange buffers + transpose slabs
-
-    // ---- K-split reduction through LDS in ONE pass: every wave parks the partial sums of the row tiles its partner owns, one
-    // barrier, every wave adds its partner's partials to the tiles it owns (kh = 0 + kh = 1 in that order in both halves).
-    if constexpr (WK == 2) {
-        static_assert((NW / 2) * TMW * TNW * 1024 <= S * STAGE, "exchange region");
-        char* xr = smem + (size_t)wq * (TMW * TNW * 1024) + lane * 16;
-#pragma unroll
-        for (int i = 0; i < TMW; ++i) {
-            if (owned(i)) continue;
-#pragma unroll
-            for (int j = 0; j < TNW; ++j) *(f32x4_t*)(xr + (i * TNW + j) * 1024) = acc[i][j];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-#pragma unroll
-        for (int i = 0; i < TMW; ++i) {
-            if (!owned(i)) continue;
-#pragma unroll
-            for (int j = 0; j < TNW; ++j) {
-                const f32x4_t o = *(const f32x4_t*)(xr + (i * TNW + j) * 1024);
-                acc[i][j] = kh == 0 ? acc[i][j] + o : o + acc[i][j];
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                // the exchange region becomes the transpose slabs
-    }
-    G16_T(3)
-    if constexpr (F16 && !RES_EARLY) {
-        if (p.res) {
-#pragma unroll
-            for (int s_own = 0; s_own < RW; ++s_own) load_res(s_own, s_own);
-        }
-    }
-
-    // ---- epilogue: lane (l15, q4) holds row l15 and columns 4*q4 .. +3 of every 16x16 tile.  Each wave transposes one 16-row tile
-    // at a time through its private slab and moves row-contiguous 16-B chunks to / from HBM (guide T21).
-    constexpr int RS = TNO * 16 * ES + 16;                           // slab row stride (16-B pad: conflict-free 16-B column writes)
-    static_assert(NW * 16 * RS <= S * STAGE, "slabs");
-    char* slab = smem + (size_t)wave * 16 * RS;
-    if constexpr (!BIAS_EARLY) load_bias();
-#ifdef RT_G16_TIMING
-    { float bsum = 0.f; for (int t = 0; t < TNO; ++t) bsum += bias_v[t][0]; asm volatile("" ::"v"(bsum)); G16_T(5) }
-#endif
-#pragma unroll
-    for (int i = 0; i < TMW; ++i) {
-        if (!owned(i)) continue;
-        // registers -> slab
-#pragma unroll
-        for (int t = 0; t < TNO; ++t) {
-            float v[4];
-            if constexpr (EPI == EPI_GEGLU) {
-                const int tv = (t >> 1) * 4 + (t & 1);
-#pragma unroll
-                for (int e = 0; e < 4; e += 2) {                     // two gates per packed-fp32 issue slot
-                    const f32x2 gt = {acc[i][tv + 2][e] + bias_g[t][e], acc[i][tv + 2][e + 1] + bias_g[t][e + 1]};
-                    const f32x2 vl = {acc[i][tv][e] + bias_v[t][e], acc[i][tv][e + 1] + bias_v[t][e + 1]};
-                    const f32x2 o = vl * gelu_erf_x2(gt);
-                    v[e] = o.x; v[e + 1] = o.y;
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][t][e] + bias_v[t][e];
-            }
-            if constexpr (TEMB) {
-                int row = m0 + (wm * TMW + i) * 16 + l15; if (row >= p.M) row = p.M - 1;
-                const int col = wcol0 + t * 16 + 4 * q4;
-                if (col < p.N) {
-                    const float4 tv = *(const float4*)(p.temb + (size_t)(row / p.rows_per_batch) * p.temb_ld + col);
-                    v[0] += tv.x; v[1] += tv.y; v[2] += tv.z; v[3] += tv.w;
-                }
-            }
-            char* dst = slab + l15 * RS + (t * 16 + 4 * q4) * ES;
-            if constexpr (F32) *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
-            else { uint2 w; w.x = pack_bf16x2(v[0], v[1]); w.y = pack_bf16x2(v[2], v[3]); *(uint2*)dst = w; }
-        }
-        // slab -> HBM (LDS operations of one wave execute in order: no barrier)
-        const int row0 = m0 + (wm * TMW + i) * 16;
-        if constexpr (F16) {
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int idx = it * 64 + lane;
-                const int r = idx / IPR, c8 = idx - r * IPR;
-                const int row = row0 + r, col = ocol0 + c8 * 8;
-                if (r >= 16 || row >= p.M || col >= NO) continue;
-                const float4 a0 = *(const float4*)(slab + r * RS + c8 * 32), a1 = *(const float4*)(slab + r * RS + c8 * 32 + 16);
-                float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-                if (p.res) {
-                    const f16_t* rh = (const f16_t*)&rres[F16 ? ((i < H0 ? i : i - H0) % RW) : 0][it];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += (float)rh[e];
-                }
-                uint4 o; f16_t* oh = (f16_t*)&o;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) oh[e] = (f16_t)v[e];
-                *(uint4*)((f16_t*)p.out + (size_t)row * p.ldo + col) = o;
-            }
-            // the window slot of this tile is free: request the residual of the owned tile RW positions further on
-            const int s_own = i < H0 ? i : i - H0;                   // compile-time after unrolling
-            if (s_own + RW < NOWN && p.res) load_res(s_own + RW, s_own % RW);
-        } else {
-            constexpr int CPR = TNO * 16 * ES / 16;                  // 16-B chunks per row
-#pragma unroll
-            for (int idx0 = 0; idx0 < 16 * CPR; idx0 += 64) {
-                const int idx = idx0 + lane;
-                const int r = idx / CPR, ch = idx - r * CPR;
-                const int row = row0 + r, col = ocol0 + ch * (16 / ES);
-                if (r >= 16 || row >= p.M || col >= NO) continue;
-                const uint4 qv = *(const uint4*)(slab + r * RS + ch * 16);
-                if constexpr (F32) {
-                    float4 o = make_float4(__uint_as_float(qv.x), __uint_as_float(qv.y), __uint_as_float(qv.z), __uint_as_float(qv.w));
-                    if (p.res) { const float4 rv = *(const float4*)((const float*)p.res + (size_t)row * p.ldres + col); o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w; }
-                    *(float4*)((float*)p.out + (size_t)row * p.ldo + col) = o;
-                } else {
-                    *(uint4*)((bf16_t*)p.out + (size_t)row * p.ldo + col) = qv;
-                }
-            }
-        }
-#ifdef RT_G16_TIMING
-        if (i == (WK == 2 && kh == 1 ? H0 : 0)) G16_T(6)
-#endif
-    }
-#ifdef RT_G16_TIMING
-    G16_T(7)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    G16_T(4)
-#endif
+// Grouped launch: two INDEPENDENT dense problems as one grid - attn1's stacked Q|K projection (class A, 224 x 320 / 224 x 256 tiles)
+// and V^T = Wv X^T (class B transposed, 160 x 224 tiles) read the same LayerNorm output (models/attention_processor.py:495-506).  The
+// first nwg_a workgroups run problem A's tiles, the rest problem B's, each with the unchanged tile body (bit-identical with the two
+// separate launches); B's workgroups start on the CUs A's tiles leave, so A's epilogue burst and B's prologue overlap and one kernel
+// boundary (launch ramp + the write-back of what A left dirty) disappears per attn1.  B's XCD-aware tile order survives any nwg_a:
+// workgroups are dealt to the XCDs round-robin by blockIdx.x, so B's local id & 7 names the hardware XCD rotated by nwg_a & 7 - a
+// relabelling of the XCDs, which is all the bijective remap needs (same label <=> same L2).
+template <int TMW_A, int TNW_A, int TMW_B, int TNW_B>
+__global__ __launch_bounds__(512) void gemm16_dual_kernel(GemmArgs pa, GemmArgs pb, int nwg_a) {
+    if ((int)blockIdx.x < nwg_a) gemm16_tile<A_DENSE, EPI_BF16, TMW_A, TNW_A, 2, 4, 1, 2>(pa, 0, blockIdx.x);
+    else gemm16_tile<A_DENSE, EPI_BF16, TMW_B, TNW_B, 2, 2, 2, 3>(pb, 0, blockIdx.x - (unsigned)nwg_a);
 }
 
 // ---------------------------------------------------------------------------------------------- launch
@@ -834,6 +406,36 @@ void launch_gemm16_variant(const GemmArgs& a, int v, int wstat, hipStream_t st) 
         case EPI_F16: launch_e<A_DENSE, EPI_F16>(a, v, wstat, st); break;
         default: launch_e<A_DENSE, EPI_GEGLU>(a, v, wstat, st); break;
     }
+}
+
+template <int TMW_A, int TNW_A, int TMW_B, int TNW_B>
+static void launch_dual_v(const GemmArgs& a, const GemmArgs& b, hipStream_t st) {
+    constexpr int BMA = 2 * TMW_A * 16, BNA = 4 * TNW_A * 16, BMB = 2 * TMW_B * 16, BNB = 2 * TNW_B * 16;
+    constexpr int LDS_A = 2 * (BMA + BNA) * 128, LDS_B = 3 * (BMB + BNB) * 128, LDS = LDS_A > LDS_B ? LDS_A : LDS_B;
+    static bool attr = false;
+    if (!attr) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)gemm16_dual_kernel<TMW_A, TNW_A, TMW_B, TNW_B>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr = true;
+    }
+    const int nwg_a = cdiv(a.M, BMA) * cdiv(a.N, BNA), nwg_b = cdiv(b.M, BMB) * cdiv(b.N, BNB);
+    hipLaunchKernelGGL((gemm16_dual_kernel<TMW_A, TNW_A, TMW_B, TNW_B>), dim3(nwg_a + nwg_b), dim3(512), LDS, st, a, b, nwg_a);
+    HIP_CHECK(hipGetLastError());
+}
+// Grouped launch of (a: tokens on the rows, class A) + (b: weights on the rows, class B transposed).  Returns false - nothing launched -
+// when the pair of tiles gemm16_pick gives the two problems has no grouped instantiation; the caller then launches them one by one.
+int gemm16_pair_variant(const GemmArgs& a_in, const GemmArgs& b_in) {            // variant of problem a (4 or 2) when a grouped form exists, else -1
+    if (a_in.mode != A_DENSE || b_in.mode != A_DENSE || a_in.epi != EPI_BF16 || b_in.epi != EPI_BF16 || a_in.weights_on_rows || !b_in.weights_on_rows) return -1;
+    if (a_in.res || b_in.res || a_in.A_lo || b_in.A_lo) return -1;
+    int wa = 0, wb = 0;
+    const int va = gemm16_pick(a_in, 0, &wa), vb = gemm16_pick(b_in, 1, &wb);
+    if (vb != 6 || wa || wb || !(va == 4 || va == 2)) return -1;
+    return va;
+}
+bool launch_gemm16_pair(const GemmArgs& a_in, const GemmArgs& b_in, hipStream_t st) {
+    const int va = gemm16_pair_variant(a_in, b_in);
+    if (va < 0) return false;
+    if (va == 4) launch_dual_v<7, 5, 5, 7>(a_in, b_in, st); else launch_dual_v<7, 4, 5, 7>(a_in, b_in, st);
+    return true;
 }
 
 // Tile choice, a pure function of the shape (no timing): the CLASS (A / B, i.e. the accumulation order of an output element) follows

@@ -53,3 +53,20 @@ def test_convolutions_only_where_one_image_contributes_enough_tiles(pick):
     assert pick(1, EPI_TEMB, 3, 256, 1280, 1280)[0] == -1           # SD-v1.5 16^2
     assert pick(1, EPI_F32, 1, 4096, 512, 512)[0] == 2              # a 64^2 x 512 VAE layer passes the rule (38 tiles); the single-image VAE
     #                                                                 opts out on its own through GemmArgs.prefer_patch_conv (vae.hip)
+
+
+def test_grouped_qk_vt_launch_rule():
+    """attn1's Q|K + V^T projections go out as one grouped launch (gemm16_dual_kernel) exactly where both problems have their tile in
+    the grouped instantiations: SDXL's two attention levels with 7 streams (Q|K on 224x320) and with the 4 Q|K streams of an injected
+    step (224x256); everything else - SD-v1.5 (K = 320 is outside the family), the 2-stream plain pass (128-row tiles), 16x16 maps -
+    stays on two launches.  Results are bit-identical either way
+    (tests/test_kernels_gpu.py), so this rule MAY look at the batch."""
+    lib = load_library()
+    f = lib.rt_op_gemm_pair_pick
+    assert f(7, 7, 1024, 2560, 1280, 1280) == 4
+    assert f(4, 7, 1024, 2560, 1280, 1280) == 2
+    assert f(7, 7, 4096, 1280, 640, 640) == 4
+    assert f(4, 7, 4096, 1280, 640, 640) == 2
+    assert f(2, 2, 1024, 2560, 1280, 1280) == -1
+    assert f(3, 3, 4096, 640, 320, 320) == -1
+    assert f(7, 7, 256, 2560, 1280, 1280) == -1

@@ -169,6 +169,44 @@ def test_gemm16_family_classes_and_reference(M, N, K):
         report("gemm16 V^T", t6, Wv.float() @ X.float().t(), **BF16_OUT)
 
 
+@pytest.mark.parametrize("streams_qk,streams,rps,C_,HD,expect", [(7, 7, 1024, 1280, 1280, 4), (4, 7, 1024, 1280, 1280, 2), (7, 7, 4096, 640, 640, 4),
+                                                                  (4, 7, 4096, 640, 640, 2), (2, 2, 1024, 1280, 1280, -1), (3, 3, 256, 1280, 1280, -1)])
+def test_grouped_qk_vt_launch_is_bit_identical_with_two_launches(streams_qk, streams, rps, C_, HD, expect):
+    """attn1's stacked Q|K projection and V^T = Wv X^T of one LayerNorm output (models/attention_processor.py:495-506) as ONE grouped
+    launch (csrc/gemm16.hip, gemm16_dual_kernel): the same tile bodies on one grid, so the bits must equal the two separate launches
+    (rt_op_gemm_debug bit 13) at the SDXL shapes of a rich-text step - 7 streams, and 4 streams' Q|K while the region streams are
+    injected - and the shapes without a grouped form (plain pass, small maps) must simply take two launches."""
+    import ctypes as C
+    from rich_text_to_image_amd.engine import load_library, _ptr
+    lib = load_library()
+    M, Mqk = streams * rps, streams_qk * rps
+    X = bf(rnd(M, C_, seed=1))
+    Wqk, Wv = bf(rnd(2 * HD, C_, seed=2, scale=C_ ** -0.5)), bf(rnd(HD, C_, seed=3, scale=C_ ** -0.5))
+    bqk = rnd(2 * HD, seed=4).to(DEV)
+    assert lib.rt_op_gemm_pair_pick(streams_qk, streams, rps, 2 * HD, HD, C_) == expect
+
+    def run(flags):
+        qk = torch.full((M, 2 * HD), 7.0, device=DEV, dtype=torch.bfloat16)          # rows >= Mqk must stay untouched
+        vt = torch.zeros(HD, M, device=DEV, dtype=torch.bfloat16)
+        grouped = C.c_int(-1)
+        lib.rt_op_gemm_debug(flags)
+        try:
+            rc = lib.rt_op_gemm_qk_vt(_ptr(X), C_, C_, rps, _ptr(Wqk), _ptr(bqk), Mqk, 2 * HD, _ptr(qk), 2 * HD, _ptr(Wv), HD, M, _ptr(vt), M,
+                                      C.byref(grouped), None)
+        finally:
+            lib.rt_op_gemm_debug(0)
+        assert rc == 0, lib.rt_op_last_error().decode()
+        torch.cuda.synchronize()
+        return qk, vt, grouped.value
+    qk1, vt1, g1 = run(0)
+    qk2, vt2, g2 = run(8192)
+    assert g1 == (1 if expect >= 0 else 0) and g2 == 0
+    assert torch.equal(qk1, qk2) and torch.equal(vt1, vt2)
+    assert bool((qk1[Mqk:] == 7.0).all())
+    report(f"grouped Q|K {Mqk}x{2 * HD}x{C_}", qk1[:Mqk], X[:Mqk].float() @ Wqk.float().t() + bqk, **BF16_OUT)
+    report(f"grouped V^T {HD}x{M}x{C_}", vt1, Wv.float() @ X.float().t(), **BF16_OUT)
+
+
 def test_gemm16_geglu_epilogue_and_w_stationary_mapping():
     M, C = 1000, 256
     A = bf(rnd(M, C, seed=7))
