@@ -55,9 +55,10 @@ def generate(model, param, model_type='SD', run_dir=None, color_guidance_weight=
 
     t0 = time.time()
     seed_everything(seed)
+    seg_cache = {}       # both calls cluster the same recorded maps with the same seed: the second reuses the first's segmentation
     color_obj_masks = get_token_maps(model.selfattn_maps, model.crossattn_maps, model.n_maps, run_dir, height // 8, width // 8,
                                      color_target_token_ids[:-1], seed, base_tokens, segment_threshold=segment_threshold,
-                                     num_segments=num_segments)
+                                     num_segments=num_segments, cache=seg_cache)
     color_obj_atten_all = torch.zeros_like(color_obj_masks[-1])
     for m in color_obj_masks[:-1]:
         color_obj_atten_all += m
@@ -66,7 +67,7 @@ def generate(model, param, model_type='SD', run_dir=None, color_guidance_weight=
     seed_everything(seed)
     model.masks = get_token_maps(model.selfattn_maps, model.crossattn_maps, model.n_maps, run_dir, height // 8, width // 8,
                                  region_target_token_ids[:-1], seed, base_tokens, segment_threshold=segment_threshold,
-                                 num_segments=num_segments)
+                                 num_segments=num_segments, cache=seg_cache)
     model.remove_tokenmap_hooks()
     timings['token_maps'] = time.time() - t0
 

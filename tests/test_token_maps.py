@@ -26,6 +26,45 @@ def test_get_token_maps_port_matches_reference_function():
         assert got[0, 6 * 2, 6 * 2] > 0.9 and got[0, 6 * 2, 24 * 2] > 0.9 and got[1, 24 * 2, 25 * 2] > 0.9 and got[2, 30, 32] > 0.9
 
 
+def test_segmentation_cache_gives_the_uncached_masks_and_clusters_once(monkeypatch):
+    """sample.py calls get_token_maps twice on the same recorded maps (reference sample.py:78-95); with `cache=` the second call must
+    return exactly what an uncached call returns and must not run SpectralClustering again."""
+    import sklearn.cluster
+    from rich_text_to_image_amd.attention_utils import get_token_maps
+    selfm, crossm = synthetic_attention_maps(0)
+    toks_a, toks_b = [torch.tensor([2, 3])], [torch.tensor([2, 3]), torch.tensor([6])]
+    kw = dict(seed=4, segment_threshold=0.3, num_segments=5, device="cpu")
+    ref_a = get_token_maps(selfm, crossm, {}, None, 64, 64, toks_a, **kw)
+    ref_b = get_token_maps(selfm, crossm, {}, None, 64, 64, toks_b, **kw)
+    calls = []
+    real = sklearn.cluster.SpectralClustering
+
+    class Counting(real):
+        def fit_predict(self, X, y=None):
+            calls.append(1)
+            return super().fit_predict(X, y)
+    monkeypatch.setattr(sklearn.cluster, "SpectralClustering", Counting)
+    cache = {}
+    got_a = get_token_maps(selfm, crossm, {}, None, 64, 64, toks_a, cache=cache, **kw)
+    got_b = get_token_maps(selfm, crossm, {}, None, 64, 64, toks_b, cache=cache, **kw)
+    assert len(calls) == 1
+    for g, r in zip(got_a + got_b, ref_a + ref_b):
+        assert torch.equal(g, r)
+    # another seed / segment count is another key: clustered again
+    get_token_maps(selfm, crossm, {}, None, 64, 64, toks_b, cache=cache, seed=5, segment_threshold=0.3, num_segments=5, device="cpu")
+    assert len(calls) == 2
+
+
+def test_same_size_bicubic_antialias_resize_is_the_identity():
+    """The port drops the reference's resize of the 32 x 32 self-attention maps to 32 x 32 (attention_utils.py:246-251): it must be
+    the identity, bit for bit, in this torch build - including the reference's permute / reshape round trip around it."""
+    g = torch.Generator().manual_seed(0)
+    m = torch.rand(1, 1024, 1024, generator=g) * torch.logspace(-6, 0, 1024).unsqueeze(0)
+    a = m.reshape(1, 32, 32, 1024).permute([3, 0, 1, 2]).float().cpu()
+    b = torch.nn.functional.interpolate(a, (32, 32), mode='bicubic', antialias=True)
+    assert torch.equal(b.permute([1, 2, 3, 0]).reshape(1, 1024, 1024), m)
+
+
 def test_layer_lists_match_the_reference_names():
     from rich_text_to_image_amd import attention_utils as au
     from rich_text_to_image_amd.engine import Engine, SD15_CONFIG, SDXL_CONFIG
