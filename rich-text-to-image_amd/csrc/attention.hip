@@ -39,7 +39,7 @@ __device__ long long g_attn_times[4 * 8];
 // s - m and the 32 v_sub per tile and wave disappear from the VALU stream that bounds this kernel (LABNOTES 4.3).  m is kept
 // bf16-representable (softmax is invariant to the reference; it only has to stay within 2^8 of the true running maximum), so the
 // product 1 * (-m) is exact.
-template <int DP, int KT, bool CROSS, bool RAGGED = false, int NW = 4, bool FOLD = !CROSS>
+template <int DP, int KT, bool CROSS, bool RAGGED = false, int NW = 4, bool FOLD = !CROSS, int PRIO = 0>
 __global__ __launch_bounds__(NW * 64, (CROSS && DP <= 64) ? 3 : 1) void attn_kernel(AttnArgs p) {
     constexpr int NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -51,6 +51,11 @@ __global__ __launch_bounds__(NW * 64, (CROSS && DP <= 64) ? 3 : 1) void attn_ker
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
+    if constexpr (PRIO == 3) {                                        // (probe) a fixed priority per wave of the workgroup: 0, 1, 2, 3
+        if (wave == 1) __builtin_amdgcn_s_setprio(1);
+        else if (wave == 2) __builtin_amdgcn_s_setprio(2);
+        else if (wave == 3) __builtin_amdgcn_s_setprio(3);
+    }
     // XCD-aware work mapping.  Workgroups are dealt to the 8 XCDs round-robin by linear id; the query blocks of one (batch entry,
     // head) all stream the same K / V^T, so they must share an L2: give every XCD a contiguous run of the (h, b, query block)
     // space, query block fastest (bijective for any grid size).  Before this the 8 query blocks of a 1024-token head sat on 8
@@ -140,6 +145,12 @@ __global__ __launch_bounds__(NW * 64, (CROSS && DP <= 64) ? 3 : 1) void attn_ker
         const char* vs_ = ks_ + TILE;
 
         // ---- S^T = K Q^T
+        // Wave priority: the four co-resident waves of a SIMD are in different phases; a wave in an MFMA phase issues sparsely (one
+        // MFMA per 32 - 64 cycles of matrix-pipe time) while the waves in their softmax keep the issue port busy with quarter-rate
+        // v_exp_f32.  Raised priority for the MFMA phases lets those sparse issues go first, so the matrix pipe runs beside the other
+        // waves' VALU work instead of queueing behind it.
+        if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(2);
+        if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(0);
         f32x16 s[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -157,6 +168,8 @@ __global__ __launch_bounds__(NW * 64, (CROSS && DP <= 64) ? 3 : 1) void attn_ker
             }
             if constexpr (FOLD) s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qm, s[j], 0, 0, 0);      // s - m
         }
+        if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0);
+        if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(2);                   // (probe) the opposite: the softmax phases first
         AT_T(1)
         // ---- online softmax (lane holds 16 of the 32 keys of each sub-tile for its query: 8*hi + [0,8) and 16 + 8*hi + [0,8); partner = lane^32)
         float mx = FOLD ? (kt == 0 ? -INFINITY : 0.f) : m;          // FOLD: s is already relative to m
@@ -231,6 +244,8 @@ __global__ __launch_bounds__(NW * 64, (CROSS && DP <= 64) ? 3 : 1) void attn_ker
         AT_T(2)
 
         // ---- O^T += V^T P^T
+        if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(2);
+        if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int kk = 0; kk < KT / 16; ++kk) {
             const int j = kk >> 1, hh = kk & 1;
@@ -245,6 +260,7 @@ __global__ __launch_bounds__(NW * 64, (CROSS && DP <= 64) ? 3 : 1) void attn_ker
                 o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
             }
         }
+        if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0);
         AT_T(3)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         AT_T(4)
@@ -285,23 +301,37 @@ __global__ __launch_bounds__(NW * 64, (CROSS && DP <= 64) ? 3 : 1) void attn_ker
     }
 }
 
-template <int DP, int KT, bool CROSS, bool RAGGED = false, int NW = 4, bool FOLD = !CROSS>
-static void launch_t(const AttnArgs& a, hipStream_t st) {
+// s_setprio 2 in the MFMA phases / 0 in the softmax (PRIO = 1): 942 -> 950 TFLOP/s at 4096 tokens, 716 -> 732 at 1024 stand-alone, the
+// self-attention class of a step 13.19 -> 12.75 ms per two steps (profiles/r4_attn_probe_setprio.txt, r4_ab_attn_setprio.jsonl).  The
+// opposite assignment (softmax first) measured 915 / 699, a fixed priority per wave 800 / 568.  rt_op_gemm_debug bit 14 switches it off.
+int g_attn_prio = 1;
+void attention_set_prio(int on) { g_attn_prio = on ? 1 : 0; }
+template <int DP, int KT, bool CROSS, bool RAGGED, int NW, bool FOLD, int PRIO>
+static void launch_tp(const AttnArgs& a, hipStream_t st) {
     // K / V^T double buffer (+ the cross-attention multipliers); the epilogue reuses it as NW slabs of 32 x (DP*2 + 16) bytes
     size_t lds = 4 * (size_t)KT * DP * 2 + (CROSS ? 2 * KT * sizeof(float) : 0);
     const size_t slabs = (size_t)NW * 32 * (DP * 2 + 16);
     if (slabs > lds) lds = slabs;
     static bool attr = false;
     if (!attr) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)attn_kernel<DP, KT, CROSS, RAGGED, NW, FOLD>,
+        HIP_CHECK(hipFuncSetAttribute((const void*)attn_kernel<DP, KT, CROSS, RAGGED, NW, FOLD, PRIO>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
     AttnArgs aa = a;
     aa.nqb = cdiv(a.N, 32 * NW);
     dim3 grid(aa.nqb * a.H * a.B), block(NW * 64);
-    hipLaunchKernelGGL((attn_kernel<DP, KT, CROSS, RAGGED, NW, FOLD>), grid, block, lds, st, aa);
+    hipLaunchKernelGGL((attn_kernel<DP, KT, CROSS, RAGGED, NW, FOLD, PRIO>), grid, block, lds, st, aa);
     HIP_CHECK(hipGetLastError());
+}
+template <int DP, int KT, bool CROSS, bool RAGGED = false, int NW = 4, bool FOLD = !CROSS>
+static void launch_t(const AttnArgs& a, hipStream_t st) {
+#ifdef RT_PROBE
+    if (g_attn_prio == 2) { launch_tp<DP, KT, CROSS, RAGGED, NW, FOLD, 2>(a, st); return; }
+    if (g_attn_prio == 3) { launch_tp<DP, KT, CROSS, RAGGED, NW, FOLD, 3>(a, st); return; }
+#endif
+    if (g_attn_prio) launch_tp<DP, KT, CROSS, RAGGED, NW, FOLD, 1>(a, st);
+    else launch_tp<DP, KT, CROSS, RAGGED, NW, FOLD, 0>(a, st);
 }
 
 #ifdef RT_PROBE

@@ -183,6 +183,7 @@ struct AttnArgs {
     int nqb;                     // set by launch_attention: 128-query blocks per (batch entry, head)
 };
 void launch_attention(const AttnArgs& a, hipStream_t st);
+void attention_set_prio(int on);   // s_setprio around the MFMA phases of attn_kernel (default on; rt_op_gemm_debug bit 14 clears it)
 
 // head-averaged probabilities of one stream, accumulated over calls (token-map producer)
 struct AttnStoreArgs {

@@ -1153,7 +1153,7 @@ static float* op_store_stats(size_t floats, hipStream_t st) {
 
 const char* rt_op_last_error(void) { return g_op_error.c_str(); }
 extern int g_store_legacy;
-int rt_op_gemm_debug(int d) { gemm_set_debug(d); g_store_legacy = ((d & 32) ? 1 : 0) | ((d & 64) ? 2 : 0); return RT_OK; }
+int rt_op_gemm_debug(int d) { gemm_set_debug(d); g_store_legacy = ((d & 32) ? 1 : 0) | ((d & 64) ? 2 : 0); attention_set_prio(((d >> 14) & 1) ^ 1); return RT_OK; }
 int rt_op_gemm_force_config(int cfg) {
     if (cfg < -1 || cfg > 8) return RT_E_INVALID;
     gemm_force_config(cfg);

@@ -11,10 +11,11 @@ int main() {
       for (bf16_t* dst : {Q, K, VT}) { for (auto& v : h) { x = x * 1664525u + 1013904223u; v = (uint16_t)(0x3c00 | ((x >> 9) & 0x83ff) | ((x >> 3) & 0x8000)); }
         hipMemcpy(dst, h.data(), h.size() * 2, hipMemcpyHostToDevice); } }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int mode : {0, 1, 0, 1, 2})                                // 0: round-2 softmax (v_sub), 1: -m folded into the MFMAs (FOLD), 2: FOLD, 8 waves
+    for (int mode : {1, 1, 3, 4, 5, 1, 3, 4, 5, 1, 3, 4, 5})        // 0: round-2 softmax (v_sub), 1: -m folded into the MFMAs (FOLD), 2: FOLD, 8 waves,
+                                                                    // 3: FOLD + s_setprio 2 in the MFMA phases, 4: ... in the softmax phases instead, 5: fixed priority per wave
     for (auto sh : shs) {
         const int nw = mode == 2 ? 8 : 4;
-        g_attn_nw = nw; g_attn_nofold = mode == 0;
+        g_attn_nw = nw; g_attn_nofold = mode == 0; g_attn_prio = mode >= 3 ? mode - 2 : 0;
         AttnArgs a{}; a.Q = Q; a.ldq = sh.H * DP; a.K = K; a.ldk = sh.H * DP; a.VT = VT; a.ldvt = sh.B * sh.N; a.O = O; a.ldo = sh.H * DP;
         for (int b = 0; b < sh.B; ++b) { a.q_src[b] = a.k_src[b] = a.v_src[b] = b; a.wset[b] = 0; }
         a.B = sh.B; a.H = sh.H; a.N = sh.N; a.NK = sh.N; a.nk_valid = sh.N; a.DP = DP; a.cross = 0;
