@@ -149,13 +149,14 @@ int rt_op_attention(const void* Q, int ldq, const void* K, int ldk, const void* 
 /* Host-only query of the shape rule of csrc/gemm16.hip (no device needed; tests/test_gemm16_pick.py): the tile variant a problem of `streams`
  * streams x rows_per_stream rows takes (ids below; -1: not in the family / stays on gemm.hip or the patch convolution; -2: conv3x3 query
  * with a non-square map).  conv3x3 = 1: stride-1 3x3 convolution with Cin = K_or_Cin input channels on a square map of rows_per_stream
- * pixels.  *w_stationary = 1 when the launch uses the W-stationary tile -> XCD order.  The summation CLASS of the answer ({2,3,4,5,8} /
- * {0,1} / {6,7} / -1) never depends on `streams`; inside a class the tile shape follows the batch. */
+ * pixels.  *w_stationary = 1 when the launch uses the W-stationary tile -> XCD order.  The summation CLASS of the answer ({2,3,4,5,8,10,11} /
+ * {0,1,9} / {6,7,12} / -1) never depends on `streams`; inside a class the tile shape follows the batch. */
 int rt_op_gemm16_pick(int conv3x3, int epi, int streams, int rows_per_stream, int N, int K_or_Cin, int weights_on_rows, int* w_stationary);
 /* One tile variant of the 16x16x32-MFMA GEMM family (csrc/gemm16.hip; tests / micro-benchmarks - rt_op_gemm picks by shape):
  * 0: 224x160 K-split  1: 128x160 K-split  2: 224x256  3: 256x256  4: 224x320  5: 256x320  6: 160x224 K-split (V^T)  7: 160x128 K-split
- * 8: 128x256;  -1: the variant the shape rule picks.  Variants {2,3,4,5,8} (class A) give the same bits as each other and as every
- * tile configuration of csrc/gemm.hip; {0,1} and {6,7} (class B: two K halves summed at the end) are bit-identical pairs.
+ * 8: 128x256  9: 64x160 K-split  10: 128x320  11: 64x320  12: 160x64 K-split (V^T) - 9..12: the small batches of the plain pass / SD-v1.5;
+ * -1: the variant the shape rule picks.  Variants {2,3,4,5,8,10,11} (class A) give the same bits as each other and as every
+ * tile configuration of csrc/gemm.hip; {0,1,9} and {6,7,12} (class B: two K halves summed at the end) are bit-identical sets.
  * Dense only, K % 128 == 0, K >= 256; epi as rt_op_gemm (0, 1, 3, 4). */
 int rt_op_gemm16_variant(const void* A, const void* W, const float* bias, void* out, const void* res, int epi, int M, int N, int K, int lda,
                          int ldw, int ldo, int ldres, int weights_on_rows, int variant, int wstat, void* stream);

@@ -157,7 +157,7 @@ void gemm_force_config(int cfg);   // -1: shape-based choice; 0..8: force a gemm
 void gemm_set_debug(int d);        // bit 0: eligible 3x3 convolutions through the implicit-GEMM kernels; bit 1: keep gemm16.hip out; bit 4: no fused cross-attention
 bool gemm_xattn_enabled();         // the fused to_q + cross-attention kernel is allowed (debug bit 4 clear, gemm16 on, no forced configuration)
 // gemm16.hip: 16x16x32-MFMA family (224-row tiles, intra-tile K split); dense problems with K % 64 == 0 only
-#define RT_G16_NVAR 9
+#define RT_G16_NVAR 13
 bool gemm16_supported(const GemmArgs& a);
 int gemm16_pick(const GemmArgs& a, int weights_on_rows, int* wstat);      // variant id or -1; pure function of the shape
 void launch_gemm16_variant(const GemmArgs& a, int variant, int wstat, hipStream_t st);

@@ -298,6 +298,10 @@ static const G16Var kVar[RT_G16_NVAR] = {
     {160, 224, 2, 3, 0},   // 6  class B transposed: V^T = Wv X^T (rows = head channels, columns = tokens)
     {160, 128, 2, 3, 0},   // 7  class B transposed, 128 token columns
     {128, 256, 1, 3, 1},   // 8  class A, 128 rows
+    {64, 160, 2, 3, 0},    // 9  class B, 64 rows: batches that leave half of the chip idle on 128-row tiles (the 2-stream plain pass, SD-v1.5's 3 - 5 streams)
+    {128, 320, 1, 2, 0},   // 10 class A, 320 columns, 128 rows  } the 640-channel level of the same small batches (its class is A whatever
+    {64, 320, 1, 3, 0},    // 11 class A, 320 columns, 64 rows   } the batch: 224-row tiles give 74 workgroups for 2 streams)
+    {160, 64, 2, 3, 0},    // 12 class B transposed, 64 token columns (V^T of the same small batches)
     // (measured and dropped, profiles/r3_gemm16_probe_v2_timing.txt: FOUR-wave forms of 224x160 / 224x320 / 224x256 - one wave per
     //  SIMD with its accumulators in AGPRs, no K split / no exchange - run their K loop at 46 k instead of 25.5 k cycles: a single
     //  compiler-scheduled wave does not keep the matrix pipe fed.  The kernel template still takes WM*WN*WK == 4.)
@@ -338,6 +342,10 @@ static void launch_e(const GemmArgs& a, int v, int wstat, hipStream_t st) {
                 case 5: launch_v<MODE, EPI, 8, 5, 2, 4, 1, 2>(a, wstat, st); return;
                 case 6: launch_v<MODE, EPI, 5, 7, 2, 2, 2, 3>(a, wstat, st); return;
                 case 7: launch_v<MODE, EPI, 5, 4, 2, 2, 2, 3>(a, wstat, st); return;
+                case 9: launch_v<MODE, EPI, 2, 5, 2, 2, 2, 3>(a, wstat, st); return;
+                case 10: launch_v<MODE, EPI, 4, 5, 2, 4, 1, 2>(a, wstat, st); return;
+                case 11: launch_v<MODE, EPI, 2, 5, 2, 4, 1, 3>(a, wstat, st); return;
+                case 12: launch_v<MODE, EPI, 5, 2, 2, 2, 2, 3>(a, wstat, st); return;
                 default: break;
             }
         }
@@ -468,8 +476,14 @@ int gemm16_pick(const GemmArgs& a, int weights_on_rows, int* wstat) {
         if (a.N % 256 == 0) return (long)cdiv(rps, 224) * (a.N / 256) >= 30 ? 2 : -1;
         return -1;
     }
+    // Small batches (the 2-stream plain pass, SD-v1.5's 3 - 5 streams): where the tiles above would leave half of the chip idle, 64-row
+    // (64-token) tiles of the SAME class that still fit one round of 256 workgroups.  Measured (profiles/r4_gemm16_probe_small_batch.txt):
+    // 2048 x 1280 x 5120 39.6 -> 34.8 us, 3072 x 640 x 640 9.6 -> 7.6, 768 x 1280 x 1280 12.8 -> 9.8 (class B); 8192 x 640 x 640
+    // 22.2 -> 11.8, 8192 x 640 x 2560 59.0 -> 31.0, 8192 x 1280 x 640 20.5 -> 16.6 (class A); a second round loses (5120 x 640 x 640: 10.7 ->
+    // 13.7).  Same class => same bits, so - unlike the class - this choice may look at the batch.
     if (weights_on_rows) {
         if (a.epi != EPI_BF16 || a.M % 160 != 0) return -1;
+        if ((long)(a.M / 160) * cdiv(a.N, 64) <= 256) return 12;
         return cost(160, 224, 1.0) <= cost(160, 128, 1.2) ? 6 : 7;
     }
     if (a.epi == EPI_GEGLU) {
@@ -491,9 +505,16 @@ int gemm16_pick(const GemmArgs& a, int weights_on_rows, int* wstat) {
             const double cc = cost(c[0], c[1], c[0] == 128 ? 1.2 : 1.0);
             if (cc < bc) { bc = cc; best = c[2]; }
         }
+        if (best >= 0 && (long)cdiv(a.M, kVar[best].BM) * (a.N / kVar[best].BN) <= 128) {     // half of the chip or more would idle
+            if ((long)cdiv(a.M, 64) * (a.N / 320) <= 256) return 11;
+            if ((long)cdiv(a.M, 128) * (a.N / 320) <= 256) return 10;
+        }
         return best;
     }
-    if (a.N % 160 == 0) return cost(224, 160, 1.0) <= cost(128, 160, 1.2) ? 0 : 1;     // class B
+    if (a.N % 160 == 0) {                                                             // class B
+        if ((long)cdiv(a.M, 64) * (a.N / 160) <= 256) return 9;
+        return cost(224, 160, 1.0) <= cost(128, 160, 1.2) ? 0 : 1;
+    }
     return -1;
 }
 

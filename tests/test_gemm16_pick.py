@@ -27,7 +27,7 @@ def test_variant_never_depends_on_the_number_of_streams(pick):
               (1, EPI_TEMB, 1024, 1280, 1280), (1, EPI_F16, 4096, 640, 640), (1, EPI_F16, 16384, 320, 320), (1, EPI_TEMB, 1024, 640, 320)]
     # what must not move is the CLASS (summation order): A = one ascending sum over k (variants 2, 3, 4, 5, 8: bit-identical with each
     # other and with gemm.hip), B = K-split (0, 1), B^T (6, 7), or "not in the family"; inside a class the tile follows the actual M
-    cls = {-1: "none", 0: "B", 1: "B", 2: "A", 3: "A", 4: "A", 5: "A", 8: "A", 6: "BT", 7: "BT"}
+    cls = {-1: "none", 0: "B", 1: "B", 9: "B", 2: "A", 3: "A", 4: "A", 5: "A", 8: "A", 10: "A", 11: "A", 6: "BT", 7: "BT", 12: "BT"}
     for conv, epi, rps, N, K in shapes:
         got = {cls[pick(conv, epi, s, rps, N, K)[0]] for s in (1, 2, 3, 5, 7, 8)}
         assert len(got) == 1, (conv, epi, rps, N, K, got)
@@ -70,3 +70,23 @@ def test_grouped_qk_vt_launch_rule():
     assert f(2, 2, 1024, 2560, 1280, 1280) == -1
     assert f(3, 3, 4096, 640, 320, 320) == -1
     assert f(7, 7, 256, 2560, 1280, 1280) == -1
+
+
+def test_small_batches_take_64_row_tiles_of_the_same_class(pick):
+    """The 2-stream plain pass and SD-v1.5's 3-stream steps leave half of the chip idle on 128- / 224-row tiles: where 64-row (64-token)
+    tiles of the SAME class fit one round of 256 workgroups they are taken (measured: profiles/r4_gemm16_probe_small_batch.txt); the
+    7-stream shapes of a rich-text step are untouched."""
+    assert pick(0, EPI_F16, 2, 1024, 1280, 1280)[0] == 9             # plain pass to_out 1280: 32 x 8 = 256 tiles
+    assert pick(0, EPI_F16, 2, 1024, 1280, 5120)[0] == 9
+    assert pick(0, EPI_F16, 3, 1024, 640, 640)[0] == 9               # SD-v1.5, 3 streams, 32^2 x 640
+    assert pick(0, EPI_F16, 5, 1024, 640, 640)[0] == 1               # 5 streams: 80 x 4 = 320 tiles would start a second round
+    assert pick(0, EPI_F16, 3, 256, 1280, 1280)[0] == 9              # SD-v1.5 16^2 x 1280
+    assert pick(0, EPI_F16, 2, 4096, 640, 640)[0] == 11              # plain pass, 640-channel level (class A): 128 x 2 = 256 tiles of 64 x 320
+    assert pick(0, EPI_F16, 2, 4096, 640, 2560)[0] == 11
+    assert pick(0, EPI_BF16, 2, 4096, 1280, 640)[0] == 2             # its Q|K keeps 224 x 256 (185 tiles: more than half of the chip)
+    assert pick(0, EPI_BF16, 2, 1024, 1280, 1280, vt=1)[0] == 12     # V^T: 8 x 32 = 256 tiles of 160 x 64
+    assert pick(0, EPI_BF16, 2, 4096, 640, 640, vt=1)[0] == 7        # 4 x 128 = 512 of those: stays on 160 x 128
+    for args in [(0, EPI_F16, 7, 1024, 1280, 1280), (0, EPI_F16, 7, 4096, 640, 640), (0, EPI_BF16, 7, 1024, 2560, 1280), (0, EPI_BF16, 4, 1024, 2560, 1280),
+                 (0, EPI_BF16, 4, 4096, 1280, 640)]:
+        assert pick(*args)[0] in (0, 2, 4), args
+    assert pick(0, EPI_BF16, 7, 1024, 1280, 1280, vt=1)[0] == 6

@@ -148,13 +148,15 @@ def test_gemm16_family_classes_and_reference(M, N, K):
     finally:
         lib.rt_op_gemm_force_config(-1)
         lib.rt_op_gemm_debug(0)
-    cls_a = [v for v in (2, 3, 4, 8) if N % {2: 256, 3: 256, 4: 320, 8: 256}[v] == 0]
+    cls_a = [v for v in (2, 3, 4, 8, 10, 11) if N % {2: 256, 3: 256, 4: 320, 8: 256, 10: 320, 11: 320}[v] == 0]
     for v in cls_a:
         out = _gemm16(A, W, bias, 1, v, res=res32)
         assert torch.equal(out, old), f"class A variant {v} differs from gemm.hip at {M}x{N}x{K}: max {(out - old).abs().max().item()}"
     b0 = _gemm16(A, W, bias, 1, 0, res=res32)
     b1 = _gemm16(A, W, bias, 1, 1, res=res32)
-    assert torch.equal(b0, b1), f"class B variants differ at {M}x{N}x{K}"
+    b9 = _gemm16(A, W, bias, 1, 9, res=res32)
+    assert torch.equal(b0, b1) and torch.equal(b0, b9), f"class B variants differ at {M}x{N}x{K}"
+    assert torch.equal(_gemm16(A, W, bias, 4, 0, res=res16), _gemm16(A, W, bias, 4, 9, res=res16))
     report(f"gemm16 class B f32+res {M}x{N}x{K}", b0, ref + res32, **F32_OUT)
     report(f"gemm16 class B bf16 {M}x{N}x{K}", _gemm16(A, W, bias, 0, 0), ref, **BF16_OUT)
     report(f"gemm16 class B f16 trunk {M}x{N}x{K}", _gemm16(A, W, bias, 4, 0, res=res16), ref + res16.float(), atol=4e-3, rtol=1.5e-3)
@@ -165,7 +167,8 @@ def test_gemm16_family_classes_and_reference(M, N, K):
         Wv, X = (A, W) if M % 160 == 0 else (W, A)
         t6 = _gemm16(Wv, X, None, 0, 6, vt=1)
         t7 = _gemm16(Wv, X, None, 0, 7, vt=1)
-        assert torch.equal(t6, t7)
+        t12 = _gemm16(Wv, X, None, 0, 12, vt=1)
+        assert torch.equal(t6, t7) and torch.equal(t6, t12)
         report("gemm16 V^T", t6, Wv.float() @ X.float().t(), **BF16_OUT)
 
 

@@ -3,7 +3,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -DRT_PROBE tools/probes/gemm16_bench.hip \
 //         rich-text-to-image_amd/csrc/gemm16.hip -o tools/probes/gemm16_bench        (two translation units)
 #include "../../rich-text-to-image_amd/csrc/gemm.hip"
-static const struct { int BM, BN; } kVar[RT_G16_NVAR] = {{224, 160}, {128, 160}, {224, 256}, {256, 256}, {224, 320}, {256, 320}, {160, 224}, {160, 128}, {128, 256}};
+static const struct { int BM, BN; } kVar[RT_G16_NVAR] = {{224, 160}, {128, 160}, {224, 256}, {256, 256}, {224, 320}, {256, 320}, {160, 224}, {160, 128}, {128, 256}, {64, 160}, {128, 320}, {64, 320}, {160, 64}};
 #include <vector>
 #include <cstring>
 #include <cmath>
@@ -48,6 +48,7 @@ int main(int argc, char** argv) {
     hipMemset(zero, 0, 256);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const bool quick = argc > 1 && !strcmp(argv[1], "q");
+    const bool small_only = argc > 1 && !strcmp(argv[1], "s");      // only the small-batch cases (plain pass, SD-v1.5)
 
     // name, M, N, K, epi, residual, weights_on_rows, {old configs}, {new variants}, try wstat 0 and 1
     const Case cases[] = {
@@ -67,11 +68,25 @@ int main(int argc, char** argv) {
         {"V^T 640", 640, 28672, 640, EPI_BF16, 0, 1, {0, -1, -1}, {6, 7, -1, 4, -1, -1}, 0},
         {"ragged rows (M = 5000), f32 + res", 5000, 1280, 1280, EPI_F32, 1, 0, {2, -1, -1}, {0, 1, -1, -1, -1, -1}, 0},
         {"5 streams 1280", 5120, 1280, 1280, EPI_F16, 1, 0, {2, 0, -1}, {0, 1, -1, -1, -1, -1}, 0},
+        {"plain pass (2 streams) to_out 1280", 2048, 1280, 1280, EPI_F16, 1, 0, {2, -1, -1}, {1, 9, -1, -1, -1, -1}, 0},
+        {"plain pass (2 streams) ff.net.2 1280", 2048, 1280, 5120, EPI_F16, 1, 0, {2, -1, -1}, {1, 9, -1, -1, -1, -1}, 0},
+        {"plain pass (2 streams) to_out 640", 8192, 640, 640, EPI_F16, 1, 0, {8, -1, -1}, {4, 10, 11, 1, -1, -1}, 0},
+        {"plain pass (2 streams) ff.net.2 640", 8192, 640, 2560, EPI_F16, 1, 0, {8, -1, -1}, {4, 10, 11, -1, -1, -1}, 0},
+        {"plain pass (2 streams) Q|K 640", 8192, 1280, 640, EPI_BF16, 0, 0, {8, -1, -1}, {4, 10, 11, -1, -1, -1}, 0},
+        {"plain pass (2 streams) Q|K 1280", 2048, 2560, 1280, EPI_BF16, 0, 0, {2, -1, -1}, {8, 4, 10, 11, -1, -1}, 0},
+        {"plain pass (2 streams) V^T 1280", 1280, 2048, 1280, EPI_BF16, 0, 1, {2, -1, -1}, {6, 7, 12, -1, -1, -1}, 0},
+        {"SD-v1.5 3 streams V^T 640", 640, 3072, 640, EPI_BF16, 0, 1, {0, -1, -1}, {7, 12, -1, -1, -1, -1}, 0},
+        {"SD-v1.5 3 streams V^T 1280 (16^2)", 1280, 768, 1280, EPI_BF16, 0, 1, {2, -1, -1}, {7, 12, -1, -1, -1, -1}, 0},
+        {"SD-v1.5 3 streams 32^2 x 640 to_out", 3072, 640, 640, EPI_F16, 1, 0, {8, -1, -1}, {1, 9, -1, -1, -1, -1}, 0},
+        {"SD-v1.5 3 streams 32^2 x 640 ff.net.2", 3072, 640, 2560, EPI_F16, 1, 0, {8, -1, -1}, {1, 9, -1, -1, -1, -1}, 0},
+        {"SD-v1.5 3 streams 16^2 x 1280 to_out", 768, 1280, 1280, EPI_F16, 1, 0, {2, -1, -1}, {1, 9, -1, -1, -1, -1}, 0},
+        {"SD-v1.5 5 streams 32^2 x 640 to_out", 5120, 640, 640, EPI_F16, 1, 0, {8, -1, -1}, {1, 9, -1, -1, -1, -1}, 0},
         {"4096^3 bf16", 4096, 4096, 4096, EPI_BF16, 0, 0, {3, 7, -1}, {3, -1, -1, -1, -1, -1}, 0},
         {"8192x4096x4096 bf16", 8192, 4096, 4096, EPI_BF16, 0, 0, {7, -1, -1}, {3, -1, -1, -1, -1, -1}, 0},
     };
     for (const Case& c : cases) {
         if (quick && c.M * (long)c.N > 40000000L) continue;
+        if (small_only && !(strstr(c.name, "plain pass") || strstr(c.name, "SD-v1.5"))) continue;
         GemmArgs g{}; g.A = A; g.W = W; g.zero = zero; g.mode = A_DENSE; g.epi = c.epi; g.bias = bias;
         g.M = c.M; g.N = c.N; g.K = c.K; g.lda = c.K; g.ldw = c.K; g.ldo = c.epi == EPI_GEGLU ? c.N / 2 : c.N;
         if (c.vt) g.bias = nullptr;
@@ -141,7 +156,7 @@ int main(int argc, char** argv) {
         }
         fflush(stdout);
     }
-    {   // 3x3 stride-1 convolutions: patch kernel (gemm.hip conv3p_kernel) against the implicit GEMM of gemm16.hip
+    if (!small_only) {   // 3x3 stride-1 convolutions: patch kernel (gemm.hip conv3p_kernel) against the implicit GEMM of gemm16.hip
         struct Cv { int B, H, W, Cin, Cout, epi, v; } cs[] = {{7, 32, 32, 1280, 1280, EPI_BF16, 0}, {7, 32, 32, 2560, 1280, EPI_F16, 0}, {7, 32, 32, 1920, 1280, EPI_BF16, 0},
             {7, 64, 64, 640, 640, EPI_BF16, 4}, {7, 64, 64, 1280, 640, EPI_F16, 4}, {7, 64, 64, 960, 640, EPI_BF16, 4}, {7, 128, 128, 320, 320, EPI_BF16, 4},
             {7, 128, 128, 640, 320, EPI_F16, 4}, {3, 20, 24, 128, 320, EPI_BF16, 4}};
