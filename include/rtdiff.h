@@ -163,9 +163,9 @@ int rt_op_gemm16_variant(const void* A, const void* W, const float* bias, void* 
 /* attn1's two projections of one LayerNorm output X [M, K] bf16 (models/attention_processor.py:495-506: to_q / to_k / to_v read the same
  * hidden states) exactly as the engine launches them: qk[Mqk, Nqk] = X[:Mqk] Wqk^T + bqk (stacked, head-padded to_q | to_k; Mqk <= M: the
  * injected region streams of a rich-text step need no Q / K of their own) and vt[Nv, M] = Wv X^T.  Where the 16x16x32 family has the pair
- * of tiles (SDXL: both attention levels, 7 and 4 streams) they go out as ONE grouped launch (csrc/gemm16.hip, gemm16_dual_kernel: the
+ * of tiles (SDXL: both attention levels with 7, 4 and - the plain pass - 2 streams) they go out as ONE grouped launch (csrc/gemm16.hip, gemm16_dual_kernel: the
  * unchanged tile bodies, bit-identical with two launches; rt_op_gemm_debug bit 13 forces two launches); *grouped (may be NULL) says which. */
-int rt_op_gemm_pair_pick(int streams_qk, int streams, int rows_per_stream, int Nqk, int Nv, int K);   /* host-only: 4 / 2 = grouped (tile of Q|K), -1 = two launches */
+int rt_op_gemm_pair_pick(int streams_qk, int streams, int rows_per_stream, int Nqk, int Nv, int K);   /* host-only: 0..3 = grouped (which tile pair), -1 = two launches */
 int rt_op_gemm_qk_vt(const void* X, int ldx, int K, int rows_per_stream, const void* Wqk, const float* bqk, int Mqk, int Nqk, void* qk, int ldqk,
                      const void* Wv, int Nv, int M, void* vt, int ldvt, int* grouped, void* stream);
 /* The SDXL cross-attention block the north star names, as one call (replaces attn2 of BasicTransformerBlock, models/attention.py:169-189,

@@ -60,7 +60,9 @@ def _segment(selfattn_maps, crossattn_maps, seed, num_segments, resolution):
         # attention_utils.py:246-251 resizes every kept map to (resolution, resolution) - but only maps that already ARE 32 x 32 get
         # here, and a same-size bicubic(antialias) resize returns its input bit for bit (weights 1 / 0; pinned by
         # tests/test_token_maps.py::test_same_size_bicubic_antialias_resize_is_the_identity): 60 resizes of 1024 x 1024 skipped
-        maps32.append(attn_map.reshape(1, resolution ** 2, res_map ** 2).float().cpu())
+        maps32.append(attn_map.reshape(1, resolution ** 2, res_map ** 2).float())
+    # averaged where the maps live: the facades hand over GPU tensors (240 MB at SDXL) and only the 1024 x 1024 result crosses to the host
+    # (the reference moves every map to the CPU first, attention_utils.py:246; fp32 mean either way)
     affinity = torch.cat(maps32).mean(0).cpu().numpy()
     seed_everything(seed)
     sc = SpectralClustering(num_segments, affinity='precomputed', n_init=100, assign_labels='kmeans')

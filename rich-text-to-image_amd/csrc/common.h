@@ -161,7 +161,7 @@ bool gemm_xattn_enabled();         // the fused to_q + cross-attention kernel is
 bool gemm16_supported(const GemmArgs& a);
 int gemm16_pick(const GemmArgs& a, int weights_on_rows, int* wstat);      // variant id or -1; pure function of the shape
 void launch_gemm16_variant(const GemmArgs& a, int variant, int wstat, hipStream_t st);
-int gemm16_pair_variant(const GemmArgs& a, const GemmArgs& b);                   // host-only: tile variant of `a` in the grouped form, -1: none
+int gemm16_pair_variant(const GemmArgs& a, const GemmArgs& b);                   // host-only: id of the grouped instantiation (0..3), -1: none
 bool launch_gemm16_pair(const GemmArgs& a, const GemmArgs& b, hipStream_t st);   // grouped launch (gemm16.hip); false: not launched, no grouped form
 bool gemm_pair_is_grouped(const GemmArgs& a, const GemmArgs& b);                // host-only: would launch_gemm_pair take the grouped launch?
 void launch_gemm_pair(const GemmArgs& a, const GemmArgs& b, hipStream_t st);     // gemm.hip: the grouped launch where it exists (debug bit 13 clear), else two launch_gemm calls

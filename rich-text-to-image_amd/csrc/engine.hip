@@ -1214,8 +1214,9 @@ int rt_op_gemm16_variant(const void* A, const void* W, const float* bias, void* 
         launch_gemm16_variant(g, variant, wstat, (hipStream_t)stream);
     })
 }
-// Host-only query of the grouped-launch rule (tests): tile variant of the Q|K problem (4: 224 x 320, 2: 224 x 256) when attn1's two
-// projections go out as one grouped launch for `streams_qk` / `streams` streams of `rows_per_stream` tokens, -1 when as two launches.
+// Host-only query of the grouped-launch rule (tests): which grouped instantiation attn1's two projections take for `streams_qk` / `streams`
+// streams of `rows_per_stream` tokens - 0: 224x320 + 160x224, 1: 224x256 + 160x224, 2: 128x256 + 160x64, 3: 224x256 + 160x128 (Q|K tile +
+// V^T tile) - or -1: two launches.
 int rt_op_gemm_pair_pick(int streams_qk, int streams, int rows_per_stream, int Nqk, int Nv, int K) {
     try {
         GemmArgs a{}; a.mode = A_DENSE; a.epi = EPI_BF16; a.M = streams_qk * rows_per_stream; a.N = Nqk; a.K = K; a.lda = K; a.ldw = K; a.ldo = Nqk;

@@ -279,9 +279,9 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void gemm16_kernel(GemmArgs p, i
 // boundary (launch ramp + the write-back of what A left dirty) disappears per attn1.  B's XCD-aware tile order survives any nwg_a:
 // workgroups are dealt to the XCDs round-robin by blockIdx.x, so B's local id & 7 names the hardware XCD rotated by nwg_a & 7 - a
 // relabelling of the XCDs, which is all the bijective remap needs (same label <=> same L2).
-template <int TMW_A, int TNW_A, int TMW_B, int TNW_B>
+template <int TMW_A, int TNW_A, int S_A, int TMW_B, int TNW_B>
 __global__ __launch_bounds__(512) void gemm16_dual_kernel(GemmArgs pa, GemmArgs pb, int nwg_a) {
-    if ((int)blockIdx.x < nwg_a) gemm16_tile<A_DENSE, EPI_BF16, TMW_A, TNW_A, 2, 4, 1, 2>(pa, 0, blockIdx.x);
+    if ((int)blockIdx.x < nwg_a) gemm16_tile<A_DENSE, EPI_BF16, TMW_A, TNW_A, 2, 4, 1, S_A>(pa, 0, blockIdx.x);
     else gemm16_tile<A_DENSE, EPI_BF16, TMW_B, TNW_B, 2, 2, 2, 3>(pb, 0, blockIdx.x - (unsigned)nwg_a);
 }
 
@@ -416,33 +416,43 @@ void launch_gemm16_variant(const GemmArgs& a, int v, int wstat, hipStream_t st) 
     }
 }
 
-template <int TMW_A, int TNW_A, int TMW_B, int TNW_B>
+template <int TMW_A, int TNW_A, int S_A, int TMW_B, int TNW_B>
 static void launch_dual_v(const GemmArgs& a, const GemmArgs& b, hipStream_t st) {
     constexpr int BMA = 2 * TMW_A * 16, BNA = 4 * TNW_A * 16, BMB = 2 * TMW_B * 16, BNB = 2 * TNW_B * 16;
-    constexpr int LDS_A = 2 * (BMA + BNA) * 128, LDS_B = 3 * (BMB + BNB) * 128, LDS = LDS_A > LDS_B ? LDS_A : LDS_B;
+    constexpr int LDS_A = S_A * (BMA + BNA) * 128, LDS_B = 3 * (BMB + BNB) * 128, LDS = LDS_A > LDS_B ? LDS_A : LDS_B;
     static bool attr = false;
     if (!attr) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)gemm16_dual_kernel<TMW_A, TNW_A, TMW_B, TNW_B>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        HIP_CHECK(hipFuncSetAttribute((const void*)gemm16_dual_kernel<TMW_A, TNW_A, S_A, TMW_B, TNW_B>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr = true;
     }
     const int nwg_a = cdiv(a.M, BMA) * cdiv(a.N, BNA), nwg_b = cdiv(b.M, BMB) * cdiv(b.N, BNB);
-    hipLaunchKernelGGL((gemm16_dual_kernel<TMW_A, TNW_A, TMW_B, TNW_B>), dim3(nwg_a + nwg_b), dim3(512), LDS, st, a, b, nwg_a);
+    hipLaunchKernelGGL((gemm16_dual_kernel<TMW_A, TNW_A, S_A, TMW_B, TNW_B>), dim3(nwg_a + nwg_b), dim3(512), LDS, st, a, b, nwg_a);
     HIP_CHECK(hipGetLastError());
 }
 // Grouped launch of (a: tokens on the rows, class A) + (b: weights on the rows, class B transposed).  Returns false - nothing launched -
 // when the pair of tiles gemm16_pick gives the two problems has no grouped instantiation; the caller then launches them one by one.
-int gemm16_pair_variant(const GemmArgs& a_in, const GemmArgs& b_in) {            // variant of problem a (4 or 2) when a grouped form exists, else -1
+int gemm16_pair_variant(const GemmArgs& a_in, const GemmArgs& b_in) {            // id of the grouped instantiation (0..3), -1: none
     if (a_in.mode != A_DENSE || b_in.mode != A_DENSE || a_in.epi != EPI_BF16 || b_in.epi != EPI_BF16 || a_in.weights_on_rows || !b_in.weights_on_rows) return -1;
     if (a_in.res || b_in.res || a_in.A_lo || b_in.A_lo) return -1;
     int wa = 0, wb = 0;
     const int va = gemm16_pick(a_in, 0, &wa), vb = gemm16_pick(b_in, 1, &wb);
-    if (vb != 6 || wa || wb || !(va == 4 || va == 2)) return -1;
-    return va;
+    if (wa || wb) return -1;
+    // instantiated pairs (Q|K tile, V^T tile): 7 / 4 streams of a rich-text step at both SDXL attention levels; the 2-stream plain pass
+    if (vb == 6 && va == 4) return 0;                                 // 224 x 320 + 160 x 224
+    if (vb == 6 && va == 2) return 1;                                 // 224 x 256 + 160 x 224
+    if (vb == 12 && va == 8) return 2;                                // 128 x 256 + 160 x 64  (2 x 1024 tokens x 1280 channels: 160 + 256 workgroups)
+    if (vb == 7 && va == 2) return 3;                                 // 224 x 256 + 160 x 128 (2 x 4096 tokens x 640 channels: 185 + 256)
+    return -1;
 }
 bool launch_gemm16_pair(const GemmArgs& a_in, const GemmArgs& b_in, hipStream_t st) {
     const int va = gemm16_pair_variant(a_in, b_in);
     if (va < 0) return false;
-    if (va == 4) launch_dual_v<7, 5, 5, 7>(a_in, b_in, st); else launch_dual_v<7, 4, 5, 7>(a_in, b_in, st);
+    switch (va) {
+        case 0: launch_dual_v<7, 5, 2, 5, 7>(a_in, b_in, st); break;
+        case 1: launch_dual_v<7, 4, 2, 5, 7>(a_in, b_in, st); break;
+        case 2: launch_dual_v<4, 4, 3, 5, 2>(a_in, b_in, st); break;
+        default: launch_dual_v<7, 4, 2, 5, 4>(a_in, b_in, st); break;
+    }
     return true;
 }
 

@@ -203,7 +203,7 @@ class RegionDiffusion:
                 continue
             tgt = self.crossattn_maps if name.endswith("attn2") else self.selfattn_maps
             if name.endswith("attn2") and name in tgt and not isinstance(tgt[name], list):
-                tgt[name] = tgt[name] + m.cpu()
+                tgt[name] = tgt[name] + m                # (on the GPU: get_token_maps averages there)
             else:
-                tgt[name] = m.cpu()
+                tgt[name] = m
             eng.attn_store_enable(name, 0)

@@ -181,5 +181,6 @@ class RegionDiffusionXL:
             if m is None:
                 continue
             tgt = self.crossattn_maps if name.endswith("attn2") else self.selfattn_maps
-            tgt[name] = (tgt[name] + m.cpu()) if (name in tgt and not isinstance(tgt[name], list)) else m.cpu()
+            # the maps stay on the GPU (60 x 4 MB at SDXL): get_token_maps averages them there and moves ONE 1024 x 1024 affinity to the host
+            tgt[name] = (tgt[name] + m) if (name in tgt and not isinstance(tgt[name], list)) else m
             eng.attn_store_enable(name, 0)

@@ -20,14 +20,14 @@ def rel_l2(a, b):
 def _check(model, g):
     for k in g["self_names"]:
         assert k in model.selfattn_maps, k
-        m = model.selfattn_maps[k]
+        m = model.selfattn_maps[k].cpu()
         assert m.shape == (1, 1024, 1024)
         r = rel_l2(m[0, ::16], g["self_maps_rows"][k])
         rs = (m[0].sum(-1) - g["self_maps_rowsum"][k]).abs().max().item()
         print(f"self {k}: rel-L2 {r:.3e}, rowsum err {rs:.2e}")
         assert r < 3e-2 and rs < 2e-2 * g["self_maps_rowsum"][k].max().item()
     for k in g["cross_names"]:
-        m = model.crossattn_maps[k]
+        m = model.crossattn_maps[k].cpu()
         r = rel_l2(m[0], g["cross_maps"][k])
         print(f"cross {k}: rel-L2 {r:.3e}")
         assert m.shape[-1] == 77 and r < 3e-2

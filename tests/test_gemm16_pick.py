@@ -57,17 +57,19 @@ def test_convolutions_only_where_one_image_contributes_enough_tiles(pick):
 
 def test_grouped_qk_vt_launch_rule():
     """attn1's Q|K + V^T projections go out as one grouped launch (gemm16_dual_kernel) exactly where both problems have their tile in
-    the grouped instantiations: SDXL's two attention levels with 7 streams (Q|K on 224x320) and with the 4 Q|K streams of an injected
-    step (224x256); everything else - SD-v1.5 (K = 320 is outside the family), the 2-stream plain pass (128-row tiles), 16x16 maps -
-    stays on two launches.  Results are bit-identical either way
+    the grouped instantiations: SDXL's two attention levels with 7 streams (Q|K on 224x320), with the 4 Q|K streams of an injected
+    step (224x256) and with the 2 streams of the plain pass; everything else - SD-v1.5 (K = 320 is outside the family), other batch
+    sizes, 16x16 maps - stays on two launches.  Results are bit-identical either way
     (tests/test_kernels_gpu.py), so this rule MAY look at the batch."""
     lib = load_library()
     f = lib.rt_op_gemm_pair_pick
-    assert f(7, 7, 1024, 2560, 1280, 1280) == 4
-    assert f(4, 7, 1024, 2560, 1280, 1280) == 2
-    assert f(7, 7, 4096, 1280, 640, 640) == 4
-    assert f(4, 7, 4096, 1280, 640, 640) == 2
-    assert f(2, 2, 1024, 2560, 1280, 1280) == -1
+    assert f(7, 7, 1024, 2560, 1280, 1280) == 0
+    assert f(4, 7, 1024, 2560, 1280, 1280) == 1
+    assert f(7, 7, 4096, 1280, 640, 640) == 0
+    assert f(4, 7, 4096, 1280, 640, 640) == 1
+    assert f(2, 2, 1024, 2560, 1280, 1280) == 2                      # plain pass: 128x256 + 160x64
+    assert f(2, 2, 4096, 1280, 640, 640) == 3                        # plain pass, 640-channel level: 224x256 + 160x128
+    assert f(3, 3, 1024, 2560, 1280, 1280) == -1
     assert f(3, 3, 4096, 640, 320, 320) == -1
     assert f(7, 7, 256, 2560, 1280, 1280) == -1
 

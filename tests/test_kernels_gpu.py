@@ -172,13 +172,14 @@ def test_gemm16_family_classes_and_reference(M, N, K):
         report("gemm16 V^T", t6, Wv.float() @ X.float().t(), **BF16_OUT)
 
 
-@pytest.mark.parametrize("streams_qk,streams,rps,C_,HD,expect", [(7, 7, 1024, 1280, 1280, 4), (4, 7, 1024, 1280, 1280, 2), (7, 7, 4096, 640, 640, 4),
-                                                                  (4, 7, 4096, 640, 640, 2), (2, 2, 1024, 1280, 1280, -1), (3, 3, 256, 1280, 1280, -1)])
+@pytest.mark.parametrize("streams_qk,streams,rps,C_,HD,expect", [(7, 7, 1024, 1280, 1280, 0), (4, 7, 1024, 1280, 1280, 1), (7, 7, 4096, 640, 640, 0),
+                                                                  (4, 7, 4096, 640, 640, 1), (2, 2, 1024, 1280, 1280, 2), (2, 2, 4096, 640, 640, 3),
+                                                                  (3, 3, 1024, 1280, 1280, -1), (3, 3, 256, 1280, 1280, -1)])
 def test_grouped_qk_vt_launch_is_bit_identical_with_two_launches(streams_qk, streams, rps, C_, HD, expect):
     """attn1's stacked Q|K projection and V^T = Wv X^T of one LayerNorm output (models/attention_processor.py:495-506) as ONE grouped
     launch (csrc/gemm16.hip, gemm16_dual_kernel): the same tile bodies on one grid, so the bits must equal the two separate launches
     (rt_op_gemm_debug bit 13) at the SDXL shapes of a rich-text step - 7 streams, and 4 streams' Q|K while the region streams are
-    injected - and the shapes without a grouped form (plain pass, small maps) must simply take two launches."""
+    injected - and of the 2-stream plain pass; shapes without a grouped form (other batch sizes, small maps) must simply take two launches."""
     import ctypes as C
     from rich_text_to_image_amd.engine import load_library, _ptr
     lib = load_library()
