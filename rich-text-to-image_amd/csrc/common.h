@@ -138,6 +138,10 @@ struct GemmArgs {
     // (operands as bf16 pairs v = hi + lo).  Null: single pass.  The 3x3 convolution kernels run it as one launch with a three times
     // longer K loop (no fp32 read-modify-write of the output between passes); launch_gemm falls back to three launches elsewhere.
     const bf16_t* A_lo; const bf16_t* W_lo;
+    // EPI_F32 with pair_lo != null (precise VAE, 3x3 convolutions on the patch kernel only: gemm_pair_output_ok): the fp32 result leaves
+    // as the bf16 pair the NEXT contraction consumes - `out` = hi plane, `pair_lo` = lo plane, both bf16 [M, ldo] - instead of fp32
+    // that a cast kernel would read back and split (8 B of traffic per element saved; same bits: pack_bf16x2 / pack_bf16x2_lo)
+    bf16_t* pair_lo;
     // EPI_XATTN (launch_xattn_fused): A = LayerNorm'd tokens [B * xa_tokens, K], W = packed to_q [H * 64, K] (pre-scaled by
     // d^-1/2 log2 e), out = attention output O [M, ldo] bf16.  K / V^T: the per-prompt cross-attention cache (AttnArgs layout).
     const bf16_t* xa_k; const bf16_t* xa_vt;
@@ -152,6 +156,7 @@ struct GemmArgs {
 bool xattn_fused_supported(int C, int H, int DP, int tokens);
 void launch_xattn_fused(const GemmArgs& a, hipStream_t st);
 void launch_gemm(const GemmArgs& a, hipStream_t st);
+bool gemm_pair_output_ok(const GemmArgs& a);            // host-only: launch_gemm would run this problem on a kernel that can write GemmArgs.pair_lo
 size_t gemm_splitk_scratch_floats(const GemmArgs& a);   // fp32 partial sums launch_gemm needs for this problem (0: not split)
 void gemm_force_config(int cfg);   // -1: shape-based choice; 0..8: force a gemm.hip tile configuration (also keeps gemm16.hip out)
 void gemm_set_debug(int d);        // bit 0: eligible 3x3 convolutions through the implicit-GEMM kernels; bit 1: keep gemm16.hip out; bit 4: no fused cross-attention

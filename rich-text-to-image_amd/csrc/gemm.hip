@@ -156,6 +156,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
                 if constexpr (F32) {
                     float4 o = make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w));
                     if (p.res) { const float4 rv = *(const float4*)((const float*)p.res + (size_t)row * p.ldres + col); o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w; }
+                    if (PATCH && p.pair_lo) {                          // the bf16 (hi, lo) pair of the fp32 value instead of the value (workgroup-uniform)
+                        uint2 h, l;
+                        h.x = pack_bf16x2(o.x, o.y); h.y = pack_bf16x2(o.z, o.w);
+                        l.x = pack_bf16x2_lo(o.x, o.y); l.y = pack_bf16x2_lo(o.z, o.w);
+                        *(uint2*)((bf16_t*)p.out + (size_t)row * p.ldo + col) = h;
+                        *(uint2*)(p.pair_lo + (size_t)row * p.ldo + col) = l;
+                    } else
                     *(float4*)((float*)p.out + (size_t)row * p.ldo + col) = o;
                 } else {
                     *(uint4*)((bf16_t*)p.out + (size_t)row * p.ldo + col) = q;
@@ -1235,7 +1242,7 @@ void gemm_set_debug(int flags) {
     g_conv_patch = (flags & 1) ? 0 : 1; g_use16 = (flags & 2) ? 0 : 1; g_splitk = (flags & 4) ? 0 : 1; g_conv16 = (flags & 8) ? 0 : 1;
     g_xattn = (flags & 16) ? 0 : 1;
     g_pair = (flags & 8192) ? 0 : 1;                                  // bit 13: attn1's Q|K and V^T projections as two launches instead of one grouped launch
-    g_no_triple = ((flags & 128) ? 1 : 0) | ((flags & 256) ? 2 : 0) | ((flags & 512) ? 4 : 0);   // (bits 8 / 9: only the gemm16 / only the patch-kernel route)              // bit 7: the precise VAE's contractions as three launches (round 3) instead of one
+    g_no_triple = ((flags & 128) ? 1 : 0) | ((flags & 256) ? 2 : 0) | ((flags & 512) ? 4 : 0) | ((flags & 32768) ? 8 : 0);   // bit 15: dense hi / lo contractions as three launches   // (bits 8 / 9: only the gemm16 / only the patch-kernel route)              // bit 7: the precise VAE's contractions as three launches (round 3) instead of one
 }
 bool gemm_xattn_enabled() { return g_xattn != 0 && g_use16 != 0 && g_force_cfg < 0; }
 
@@ -1458,8 +1465,23 @@ static void check_gemm_args(const GemmArgs& a) {
     if (a.temb) RT_REQUIRE(a.temb_ld % 4 == 0 && ((uintptr_t)a.temb & 15) == 0, "gemm: temb must be 16-B aligned");
 }
 
+// pair output (GemmArgs.pair_lo) exists in the patch convolution's epilogue only: true when launch_gemm takes this problem there
+bool gemm_pair_output_ok(const GemmArgs& a) {
+    if (a.epi != EPI_F32 || !(a.mode == A_CONV3 || a.mode == A_CONV3_UP2) || g_force_cfg >= 0 || !conv_patch_eligible(a)) return false;
+    if ((g_splitk ? splitk_slices(a) : 1) != 1) return false;
+    if (a.A_lo || a.W_lo) {                                          // hi / lo contraction: only as ONE launch on the patch kernel
+        if (!(a.A_lo && a.W_lo) || (g_no_triple & 1) || (g_no_triple & 4)) return false;
+        int ws = 0;
+        if (a.mode == A_CONV3 && g_use16 && g_conv16 && g_conv_patch && !a.prefer_patch_conv && gemm16_pick(a, 0, &ws) >= 0) return false;
+        return true;
+    }
+    int ws = 0;
+    return !(a.mode == A_CONV3 && g_use16 && g_conv16 && g_conv_patch && !a.prefer_patch_conv && gemm16_pick(a, 0, &ws) >= 0);
+}
+
 void launch_gemm(const GemmArgs& a, hipStream_t st) {
     check_gemm_args(a);
+    if (a.pair_lo) RT_REQUIRE(gemm_pair_output_ok(a) && a.ldo % 4 == 0 && ((uintptr_t)a.pair_lo & 7) == 0, "gemm: pair output is only built into the patch convolution (gemm_pair_output_ok)");
     // In-place residual (out == res) is safe: every element is read and written by the same thread.
     // split-K is a function of the shape only (not of a forced tile configuration, not of stream capture): the same problem
     // always takes the same path.  Debug bit 2 (rt_op_gemm_debug(4)) switches it off for A/B tests.
@@ -1473,6 +1495,10 @@ void launch_gemm(const GemmArgs& a, hipStream_t st) {
             int ws = 0;
             const bool to16 = a.mode == A_CONV3 && g_use16 && g_conv16 && g_conv_patch && !a.prefer_patch_conv && gemm16_pick(a, 0, &ws) >= 0;
             fused = (to16 && !(g_no_triple & 2)) || (!to16 && conv_patch_eligible(a) && !(g_no_triple & 4));        // exactly the two routes below that take these problems
+        }
+        if (a.mode == A_DENSE && g_force_cfg < 0 && g_use16 && (g_splitk ? splitk_slices(a) : 1) == 1 && !(g_no_triple & 1) && !(g_no_triple & 8)) {
+            int ws = 0;
+            fused = gemm16_pick(a, a.weights_on_rows, &ws) >= 0;     // dense on the 16x16x32 family (round 4): the route at the bottom of this function
         }
         if (!fused) {
             GemmArgs b = a; b.A_lo = nullptr; b.W_lo = nullptr;

@@ -387,6 +387,7 @@ bool gemm16_supported(const GemmArgs& a) {
         return a.ldw % 8 == 0;
     }
     if (a.mode != A_DENSE || a.K % (2 * BK16) != 0 || a.K < 4 * BK16) return false;      // K % 128 (the K-split class runs pairs of K tiles), >= 4 tiles
+    if ((a.A_lo || a.W_lo) && !(a.A_lo && a.W_lo && a.epi == EPI_F32)) return false;     // hi / lo contraction: the fp32-output kernels run it as one K loop of three passes
     if (!(a.epi == EPI_BF16 || a.epi == EPI_F32 || a.epi == EPI_F16 || a.epi == EPI_GEGLU)) return false;
     if (a.lda % 8 || a.ldw % 8) return false;
     // the loaders build signed 32-bit BYTE offsets against a 2 GiB buffer descriptor: larger operands stay on gemm.hip (whose
@@ -524,6 +525,10 @@ int gemm16_pick(const GemmArgs& a, int weights_on_rows, int* wstat) {
     if (a.N % 160 == 0) {                                                             // class B
         if ((long)cdiv(a.M, 64) * (a.N / 160) <= 256) return 9;
         return cost(224, 160, 1.0) <= cost(128, 160, 1.2) ? 0 : 1;
+    }
+    if (a.N % 256 == 0) {                                                             // widths that are multiples of 256 only (VAE 256 / 512, CLIP 768 / 1024 / 3072): class A
+        const double c2 = cost(224, 256, 1.0), c3 = cost(256, 256, 1.0), c8 = cost(128, 256, 1.2);
+        return c2 <= c3 && c2 <= c8 ? 2 : (c3 <= c8 ? 3 : 8);
     }
     return -1;
 }

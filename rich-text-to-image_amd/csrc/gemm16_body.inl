@@ -82,8 +82,13 @@
         ldst[i] = (isA ? 0 : BM * 128) + gl * 1024;
     }
     // conv, precise VAE: three passes (A W, A_lo W, A W_lo) as one K loop of 3 x 9 x Cin / 64 tiles
-    const bool triple = MODE == A_CONV3 && p.A_lo != nullptr;
-    const int nk = (p.K / BK16) * (triple ? 3 : 1);                  // host guarantees K % 128 == 0 / conv: 9 * Cin / 64, nk >= S + 1
+    // ... and, round 4, the dense fp32-output kernels (the VAE's 512-wide projections, 1x1 shortcuts and attention products - the UNet's
+    // dense launches are bf16 / fp16 / GEGLU epilogues and do not carry this code): the pass is a scalar advanced with the issued tiles
+    constexpr bool TRIPLE_DENSE = MODE == A_DENSE && EPI == EPI_F32;
+    const bool triple = (MODE == A_CONV3 || TRIPLE_DENSE) && p.A_lo != nullptr;
+    const int nkp = p.K / BK16;                                      // K tiles of ONE pass
+    const int nk = nkp * (triple ? 3 : 1);                           // host guarantees K % 128 == 0 / conv: 9 * Cin / 64, nk >= S + 1
+    int d_kt = 0, d_pass = 0;                                        // dense triple: K tile inside the pass / pass of the NEXT tile to be issued
     // conv: (tap, chunk) of the NEXT K tile to be issued, carried as scalars (tiles are issued strictly in order)
     const int nch = MODE == A_CONV3 ? p.Cin / BK16 : 1;
     const unsigned a_range = MODE == A_CONV3 ? (unsigned)p.M * (unsigned)p.Cin * 2u : 0x7fffffffu;
@@ -98,8 +103,10 @@
         } else {
             // conv weights are packed [Cout][tap][Cin]: the K offset of tile (tap, chunk) is tap * Cin + chunk * 64 (= t * 64 in the
             // tap-major order)
-            const int wk = MODE == A_CONV3 ? (is_tap * p.Cin + is_chunk * BK16) * 2 : t * (BK16 * 2);
-            glds16_buf(pisA[i] ? (const void*)p.A : (const void*)(MODE == A_CONV3 && is_pass == 2 ? p.W_lo : p.W), voff[i], wk, smem + slot_off + ldst[i]);
+            const int wk = MODE == A_CONV3 ? (is_tap * p.Cin + is_chunk * BK16) * 2 : (TRIPLE_DENSE ? d_kt : t) * (BK16 * 2);
+            const void* base = pisA[i] ? (const void*)(TRIPLE_DENSE && d_pass == 1 ? p.A_lo : p.A)
+                                       : (const void*)(((MODE == A_CONV3 && is_pass == 2) || (TRIPLE_DENSE && d_pass == 2)) ? p.W_lo : p.W);
+            glds16_buf(base, voff[i], wk, smem + slot_off + ldst[i]);
         }
     };
     // K-tile order of the convolution.  Round 3 ran (tap, chunk): for each tap the whole channel range of the tile's pixels streams
@@ -109,6 +116,7 @@
     // and still in the vL1D / L2.  Same k order as the patch kernel of gemm.hip.  -DRT_G16_CONV_TAP_MAJOR builds the old order (A/B
     // timing: `make tapmajor` + RTDIFF_LIB_PATH).
     auto tile_issued = [&]() {                                       // every piece of a K tile went out: advance (tap, chunk)
+        if (TRIPLE_DENSE) { if (++d_kt == nkp) { d_kt = 0; ++d_pass; } }
         if (MODE == A_CONV3) {
 #ifdef RT_G16_CONV_TAP_MAJOR
             if (++is_chunk == nch) { is_chunk = 0; ++is_tap; if (++is_kx == 3) { is_kx = 0; ++is_ky; is_pix += p.Win - 2; } else ++is_pix;

@@ -188,12 +188,14 @@ struct rt_vae {
         g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldo = ldo; g.ldres = ldres;
         launch_gemm(g, stream);
     }
-    void conv1(const bf16_t* in, int mode, const bf16_t* W, const float* bias, int N, int K, int H, int Wd, int CinP, void* out, int epi, const float* res,
-               const bf16_t* in_lo = nullptr, const bf16_t* W_lo = nullptr) {
+    // pair_lo != null: try to get the fp32 result as the bf16 (hi, lo) pair straight from the kernel (out = hi plane); returns false -
+    // nothing launched - when the route launch_gemm takes for this problem cannot (the caller then asks for fp32 and splits)
+    bool conv1(const bf16_t* in, int mode, const bf16_t* W, const float* bias, int N, int K, int H, int Wd, int CinP, void* out, int epi, const float* res,
+               const bf16_t* in_lo = nullptr, const bf16_t* W_lo = nullptr, bf16_t* pair_lo = nullptr) {
         int Ho = H, Wo = Wd;
         if (mode == A_CONV3_UP2) { Ho = 2 * H; Wo = 2 * Wd; }
         GemmArgs g{}; g.A = in; g.W = W; g.bias = bias; g.out = out; g.res = res; g.zero = zero; g.mode = mode; g.epi = epi;
-        g.A_lo = in_lo; g.W_lo = W_lo;
+        g.A_lo = in_lo; g.W_lo = W_lo; g.pair_lo = pair_lo;
         g.M = Ho * Wo; g.N = N; g.K = K; g.ldw = K; g.ldo = N; g.ldres = N; g.rows_per_batch = Ho * Wo; g.Hin = H; g.Win = Wd; g.Cin = CinP;
         g.Hout = Ho; g.Wout = Wo;
         RT_REQUIRE(K == 9 * CinP, "vae conv: weight/input channel mismatch");
@@ -202,7 +204,9 @@ struct rt_vae {
         // ... and every hi / lo (precise) contraction: as ONE launch of three passes the patch kernel runs the 128-channel layers at 1.6 PF
         // where the GEMM-loop form of the 256-channel layers reaches 0.86 (profiles/r4_vae_precise_kernel_stats.csv)
         g.prefer_patch_conv = in_lo != nullptr || (long)g.M * N < 192L * 224 * 256;
+        if (pair_lo && !gemm_pair_output_ok(g)) return false;
         launch_gemm(g, stream);
+        return true;
     }
     void split(const float* x, BT o, size_t n) { if (!dry) launch_cast_f32_bf16(x, o.hi, n, stream, o.lo); }
     BT castb(const float* x, size_t n) { BT o = bt(n); split(x, o, n); return o; }
@@ -242,7 +246,13 @@ struct rt_vae {
     }
     BT conv_b(BT in, int mode, const MatW& W, int H, int Wd, int CinP, bool bias = true) {
         const size_t n = (size_t)H * Wd * W.N;                     // (only stride-1 same-size convolutions produce operands)
-        if (precise) { BT o = bt(n); Scratch sc(this); float* t = f32(n); conv_f32(in, mode, W, H, Wd, CinP, t, nullptr, bias); split(t, o, n); return o; }
+        if (precise) {
+            // the pair straight from the convolution's epilogue where the patch kernel takes the problem (every 3x3 layer of the SDXL
+            // decoder at 1024^2); the fp32 temporary + split kernel otherwise
+            BT o = bt(n);
+            if (!dry && conv1(in.hi, mode, W.w, bias ? W.b : nullptr, W.N, W.K, H, Wd, CinP, o.hi, EPI_F32, nullptr, in.lo, W.w_lo, o.lo)) return o;
+            Scratch sc(this); float* t = f32(n); conv_f32(in, mode, W, H, Wd, CinP, t, nullptr, bias); split(t, o, n); return o;
+        }
         BT o = bt(n);
         if (!dry) conv1(in.hi, mode, W.w, bias ? W.b : nullptr, W.N, W.K, H, Wd, CinP, o.hi, EPI_BF16, nullptr);
         return o;
@@ -298,17 +308,22 @@ struct rt_vae {
         if (sv) { sv->x = x; sv->part1 = p1; sv->h2 = h2; sv->h2_bf16 = !precise; sv->part2 = p2; sv->H = H; sv->W = W; }
         return out;
     }
-    float* res_bwd(const VRes& r, const ResSaved& sv, const float* dOut) {
+    // A gradient tensor as the backward pass hands it on: fp32 (the skip / residual additions read it) and, where the producing
+    // GroupNorm-backward kernel could write it in the same pass, the bf16 pair the next contraction consumes (b.hi == null: not yet split)
+    struct Grad { float* f = nullptr; BT b{}; };
+    BT pair_of(const Grad& g, size_t n) { return g.b.hi ? g.b : castb(g.f, n); }
+    Grad res_bwd(const VRes& r, const ResSaved& sv, const Grad& dOutG) {
         const int H = sv.H, W = sv.W; const size_t HW = (size_t)H * W;
-        BT dOb = castb(dOut, HW * r.cout);
+        const float* dOut = dOutG.f;
+        BT dOb = pair_of(dOutG, HW * r.cout);
         BT dH3 = conv_b(dOb, A_CONV3, r.c2.b, H, W, r.cout, false);
         BT dH2 = bt(HW * r.cout);
         gn_bwd(sv.h2, sv.h2_bf16, dH3, sv.part2, r.cout, (int)HW, r.n2, true, nullptr, nullptr, dH2);
         BT dH1 = conv_b(dH2, A_CONV3, r.c1.b, H, W, r.cout, false);
         const float* skip = dOut;
         if (r.has_sc) { float* s = f32(HW * r.cin); gemm_f32(dOb, r.cout, r.sc.b, (int)HW, s, r.cin, nullptr, 0, false); skip = s; }
-        float* dX = f32(HW * r.cin);
-        gn_bwd(sv.x, false, dH1, sv.part1, r.cin, (int)HW, r.n1, true, skip, dX, BT{});
+        Grad dX; dX.f = f32(HW * r.cin); dX.b = bt(HW * r.cin);
+        gn_bwd(sv.x, false, dH1, sv.part1, r.cin, (int)HW, r.n1, true, skip, dX.f, dX.b);
         return dX;
     }
     float* attn_fwd(const float* x, int N, AttnSaved* sv) {
@@ -327,9 +342,10 @@ struct rt_vae {
         if (sv) { sv->x = x; sv->part = part; sv->q = q; sv->k = k; sv->v = v; sv->P = P; sv->N = N; }
         return out;
     }
-    float* attn_bwd(const AttnSaved& sv, const float* dOut) {
+    Grad attn_bwd(const AttnSaved& sv, const Grad& dOutG) {
         const int C = attn.C, N = sv.N;
-        BT dOb = castb(dOut, (size_t)N * C);
+        const float* dOut = dOutG.f;
+        BT dOb = pair_of(dOutG, (size_t)N * C);
         BT dO = gemm_b(dOb, C, attn.o.b, N, false);
         // dV = P^T dO
         BT PT = transp(sv.P, N, N), dOT = transp(dO, N, C);
@@ -347,8 +363,8 @@ struct rt_vae {
         gemm_f32(dK, C, attn.k.b, N, dg, C, dg, C, false);
         gemm_f32(dV, C, attn.v.b, N, dg, C, dg, C, false);
         BT dgb = castb(dg, (size_t)N * C);
-        float* dX = f32((size_t)N * C);
-        gn_bwd(sv.x, false, dgb, sv.part, C, N, attn.gn, false, dOut, dX, BT{});
+        Grad dX; dX.f = f32((size_t)N * C); dX.b = bt((size_t)N * C);
+        gn_bwd(sv.x, false, dgb, sv.part, C, N, attn.gn, false, dOut, dX.f, dX.b);
         return dX;
     }
 
@@ -390,26 +406,26 @@ struct rt_vae {
         int H = tp.Hi, W = tp.Wi;
         const int C0 = cfg.block_out_channels[0];
         BT dHn = conv_b(dimg, A_CONV3, conv_out.b, H, W, 8, false);
-        float* dX = f32((size_t)H * W * C0);
-        gn_bwd(tp.last_x, false, dHn, tp.part_out, C0, H * W, norm_out, true, nullptr, dX, BT{});
+        Grad dX; dX.f = f32((size_t)H * W * C0); dX.b = bt((size_t)H * W * C0);
+        gn_bwd(tp.last_x, false, dHn, tp.part_out, C0, H * W, norm_out, true, nullptr, dX.f, dX.b);
         int ri = (int)tp.res.size() - 1;
         for (int i = (int)up_res.size() - 1; i >= 0; --i) {
             if (i + 1 < (int)up_res.size()) {
                 const int C = up_conv[i].cin;
-                BT dYb = castb(dX, (size_t)H * W * C);
+                BT dYb = pair_of(dX, (size_t)H * W * C);
                 float* dUp = f32((size_t)H * W * C);
                 conv_f32(dYb, A_CONV3, up_conv[i].b, H, W, C, dUp, nullptr, false);
                 H /= 2; W /= 2;
                 float* d = f32((size_t)H * W * C);
                 if (!dry) launch_sumpool2x2(dUp, d, 1, H, W, C, stream);
-                dX = d;
+                dX = Grad{}; dX.f = d;                                // (the pooled gradient exists as fp32 only: split by its consumer)
             }
             for (int j = (int)up_res[i].size() - 1; j >= 0; --j) dX = res_bwd(up_res[i][j], tp.res[ri--], dX);
         }
         dX = res_bwd(mid1, tp.res[ri--], dX);
         dX = attn_bwd(tp.attn, dX);
         dX = res_bwd(mid0, tp.res[ri--], dX);
-        BT dXb = castb(dX, (size_t)h * w * conv_in.cout);
+        BT dXb = pair_of(dX, (size_t)h * w * conv_in.cout);
         float* dz = f32((size_t)h * w * 4);
         conv_f32(dXb, A_CONV3, conv_in.b, h, w, conv_in.coutP, dz, nullptr, false);
         return dz;
