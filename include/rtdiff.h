@@ -218,7 +218,7 @@ int rt_op_gemm_force_config(int cfg);
  * bit 5 token-map accumulation on the round-1 two-pass kernel (csrc/attn_store.hip); bit 6 large maps on the one-pass kernel instead of
  * the statistics + key-split apply pair; bit 7 the precise VAE's hi / lo contractions as three launches instead of one;
  * bit 13 attn1's Q|K and V^T projections as two launches instead of one grouped launch; bit 14 no raised wave priority (s_setprio) in the
- * MFMA phases of the attention kernel */
+ * MFMA phases of the attention kernel; bit 15 the precise VAE's DENSE hi / lo contractions as three launches */
 int rt_op_gemm_debug(int flags);
 
 /* ---- VAE decoder: colour guidance (rd.py:151-168, xl.py:849-867) and plain decode (rd.py:227-236) ----
