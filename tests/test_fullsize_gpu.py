@@ -30,6 +30,7 @@ pytestmark = pytest.mark.gpu
 from oracle.region_loop import rich_loop_sd, rich_loop_xl  # noqa: E402
 from oracle.schedulers import OracleEuler, OraclePNDM  # noqa: E402
 from oracle.unet import INJECT_RESNET, SD15_CONFIG, SDXL_CONFIG, OracleUNet  # noqa: E402
+from oracle_cache import cached, weights_fingerprint  # noqa: E402
 
 DEV = "cuda:0"
 torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))     # the fp32 oracle is the clock here; more threads oversubscribe the host
@@ -59,7 +60,9 @@ def _build(cfg, hw, seed, max_streams, max_prompts):
         eng.synchronize()
         del t
     assert eng.weights_missing()[0] == 0
-    return eng, OracleUNet(cfg, sd)
+    o = OracleUNet(cfg, sd)
+    o.fingerprint = weights_fingerprint(sd)          # keys the committed oracle outputs (tests/oracle_cache.py)
+    return eng, o
 
 
 @pytest.fixture(scope="module")
@@ -87,15 +90,18 @@ def _stream_mode_forward(eng, o, cfg, hw, xl, t):
 
     def added(k):
         return {"text_embeds": pooled[k:k + 1], "time_ids": tid} if xl else None
-    with torch.no_grad():
-        r0 = o.forward(lat, t, emb[:1], added(0))
-        r1 = o.forward(lat, t, emb[2:3], added(2), ctl={"fontsize": {"word_pos": wp, "font_size": fs}})
-        cap = {}
-        r2 = o.forward(lat_ref, t, emb[2:3], added(2), ctl={"capture": cap})
-        inj = {k: v for k, v in cap.items() if k.endswith("attn1") or k == INJECT_RESNET}
-        assert INJECT_RESNET in inj and sum(k.endswith("attn1") for k in inj) == (70 if xl else 16)
-        r3 = o.forward(lat, t, emb[1:2], added(1), ctl={"inject": inj})
-        del cap, inj
+    def oracle_forwards():
+        with torch.no_grad():
+            r0 = o.forward(lat, t, emb[:1], added(0))
+            r1 = o.forward(lat, t, emb[2:3], added(2), ctl={"fontsize": {"word_pos": wp, "font_size": fs}})
+            cap = {}
+            r2 = o.forward(lat_ref, t, emb[2:3], added(2), ctl={"capture": cap})
+            inj = {k: v for k, v in cap.items() if k.endswith("attn1") or k == INJECT_RESNET}
+            assert INJECT_RESNET in inj and sum(k.endswith("attn1") for k in inj) == (70 if xl else 16)
+            r3 = o.forward(lat, t, emb[1:2], added(1), ctl={"inject": inj})
+        return r0, r1, r2, r3
+    (r0, r1, r2, r3), hit = cached(f"stream_modes_{'sdxl' if xl else 'sd15'}", o.fingerprint, [lat, lat_ref, emb, pooled, tid, wp, fs, float(t)], oracle_forwards)
+    print("oracle outputs:", "tests/golden/fullsize_oracle" if hit else "computed live")
     if xl:
         eng.set_prompts(emb.to(DEV), pooled.to(DEV), tid)
     else:
@@ -165,7 +171,9 @@ def test_sdxl_config3_rich_step_matches_oracle(sdxl):
         return {"text_embeds": pooled[k:k + 1], "time_ids": tid}
     t = sched.timesteps[0]
     lat_in = sched.scale_model_input(lat0, t)
-    eu, et, eur, etr = rich_step_forwards(o, lat_in, lat_in.clone(), t, emb, added_fn, masks, tfd, True, True)
+    (eu, et, eur, etr), hit = cached("config3_rich_step", o.fingerprint, [lat_in, emb, pooled, tid, m, tfd, float(t)],
+                                     lambda: rich_step_forwards(o, lat_in, lat_in.clone(), t, emb, added_fn, masks, tfd, True, True))
+    print("oracle outputs:", "tests/golden/fullsize_oracle" if hit else "computed live")
     out = sched.step(torch.cat([eu + gs * (et - eu), eur + gs * (etr - eur)]), t, torch.cat([lat0, lat0]))["prev_sample"]
     ref, ref_ref = torch.chunk(out, 2, dim=0)
     r, rr = rel_l2(got - lat0, ref - lat0), rel_l2(got_ref - lat0, ref_ref - lat0)
@@ -201,8 +209,9 @@ def test_sdxl_full_architecture_two_step_loop_with_background_blend(sdxl):
     for i in range(steps):
         eng.region_step(i, gs, isa, ibg, xl=True, elide=False)
     got = eng.read_latents(hw, hw).cpu()
-    trace = []
-    ref = rich_loop_xl(o, OracleEuler(), emb, pooled, tid, masks, lat0, steps, gs, tfd, isa, ibg, trace=trace)
+    ref, hit = cached("sdxl_two_step_loop_blend", o.fingerprint, [lat0, emb, pooled, tid, m, tfd, steps, gs, isa, ibg],
+                      lambda: rich_loop_xl(o, OracleEuler(), emb, pooled, tid, masks, lat0, steps, gs, tfd, isa, ibg))
+    print("oracle outputs:", "tests/golden/fullsize_oracle" if hit else "computed live")
     r = rel_l2(got - lat0, ref - lat0)
     bgm = (m[R - 1:R] > 0.5).expand_as(ref)            # mostly-background pixels: after the blend they hold the reference stream's latents
     rb = rel_l2((got - lat0)[bgm], (ref - lat0)[bgm])
@@ -229,7 +238,8 @@ def test_sd15_config1_rich_loop_matches_oracle(sd15):
     for i in range(len(sched.timesteps)):
         eng.region_step(i, gs, 0.0, 0.0, xl=False, elide=False)
     got = eng.read_latents(hw, hw).cpu()
-    ref = rich_loop_sd(o, OraclePNDM(), emb, masks, lat0, steps, gs, tfd, 0, 0)
+    ref, hit = cached("sd15_config1_loop", o.fingerprint, [lat0, emb, m, tfd, steps, gs], lambda: rich_loop_sd(o, OraclePNDM(), emb, masks, lat0, steps, gs, tfd, 0, 0))
+    print("oracle outputs:", "tests/golden/fullsize_oracle" if hit else "computed live")
     r = rel_l2(got, ref)
     print(f"SD-v1.5 config 1, {len(sched.timesteps)} PLMS iterations (R=2): final latents rel-L2 {r:.3e} (ref std {ref.std():.3f})")
     assert r < 3e-2
@@ -351,8 +361,11 @@ def test_sdxl_config5_guided_loop_through_the_facade(sdxl):
     sched = OracleEuler(); sched.set_timesteps(steps)
     guidance = {"vae": OracleVAEDecoder(SDXL_VAE_CONFIG, vsd), "scaling": SDXL_VAE_CONFIG["scaling_factor"]}
     t0 = time.perf_counter()
-    ref = rich_loop_xl(o, OracleEuler(), emb, pooled, tid, masks, lat * sched.init_noise_sigma, steps, gs, tfd, isa, ibg, use_guidance=True, guidance=guidance)
+    ref, hit = cached("sdxl_config5_guided_loop", o.fingerprint, [lat, emb, pooled, tid, m, tfd, vsd, steps, gs, isa, ibg],
+                      lambda: rich_loop_xl(o, OracleEuler(), emb, pooled, tid, masks, lat * sched.init_noise_sigma, steps, gs, tfd, isa, ibg, use_guidance=True,
+                                           guidance=guidance))
     t_ref = time.perf_counter() - t0
+    print("oracle outputs:", "tests/golden/fullsize_oracle" if hit else "computed live")
     vae = VaeDecoder(SDXL_VAE_CONFIG, hw, hw, device=0, state_dict=vsd, precise=True)
     mdl = RegionDiffusionXL(device=0, unet_state_dict="empty", config=SDXL_CONFIG, vae=vae, vae_scaling_factor=SDXL_VAE_CONFIG["scaling_factor"])
     mdl.unet._engines[(hw, hw)] = eng                                # the module's engine (same weights as the oracle): no second 5 GB arena
@@ -392,8 +405,10 @@ def test_sd15_config2_guided_loop_through_the_facade(sd15):
     vsd = random_vae_state_dict(SD_VAE_CONFIG, seed=12)
     guidance = {"vae": OracleVAEDecoder(SD_VAE_CONFIG, vsd), "scaling": SD_VAE_CONFIG["scaling_factor"]}
     t0 = time.perf_counter()
-    ref = rich_loop_sd(o, OraclePNDM(), emb, masks, lat, steps, gs, tfd, 0, 0, use_guidance=True, guidance=guidance)
+    ref, hit = cached("sd15_config2_guided_loop", o.fingerprint, [lat, emb, m, tfd, vsd, steps, gs],
+                      lambda: rich_loop_sd(o, OraclePNDM(), emb, masks, lat, steps, gs, tfd, 0, 0, use_guidance=True, guidance=guidance))
     t_ref = time.perf_counter() - t0
+    print("oracle outputs:", "tests/golden/fullsize_oracle" if hit else "computed live")
     vae = VaeDecoder(SD_VAE_CONFIG, hw, hw, device=0, state_dict=vsd)
     mdl = RegionDiffusion(0, unet_state_dict="empty", config=SD15_CONFIG, vae=vae)
     mdl.unet._engines[(hw, hw)] = eng
