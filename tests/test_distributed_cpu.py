@@ -34,7 +34,8 @@ def _worker(rank, world, port, q):
 def test_seed_parallel_launcher_world2_gloo():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
+    from rich_text_to_image_amd import launcher
+    port = launcher.free_port()                                    # (a pid-derived port collided once with a socket still in TIME_WAIT)
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
