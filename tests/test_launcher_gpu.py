@@ -45,7 +45,8 @@ print("LAUNCHER_GPU_OK")
 
 def test_arena_view_and_rccl_broadcast_single_rank():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    port = 29600 + os.getpid() % 300
+    from rich_text_to_image_amd import launcher
+    port = launcher.free_port()
     r = subprocess.run([sys.executable, "-c", _SCRIPT % (ROOT, port)], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0 and "LAUNCHER_GPU_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
