@@ -1501,6 +1501,7 @@ void launch_gemm(const GemmArgs& a, hipStream_t st) {
             fused = gemm16_pick(a, a.weights_on_rows, &ws) >= 0;     // dense on the 16x16x32 family (round 4): the route at the bottom of this function
         }
         if (!fused) {
+            RT_REQUIRE(!a.pair_lo, "gemm: pair output on a route without it");      // (unreachable: gemm_pair_output_ok mirrors this routing; kept as a guard)
             GemmArgs b = a; b.A_lo = nullptr; b.W_lo = nullptr;
             launch_gemm(b, st);
             b.bias = nullptr; b.res = a.out; b.ldres = a.ldo;
@@ -1516,9 +1517,12 @@ void launch_gemm(const GemmArgs& a, hipStream_t st) {
         // stride-1 3x3 convolutions with Cin % 64 == 0: implicit GEMM on the 16x16x32 family's main loop (gemm16.hip, MODE = A_CONV3)
         int wstat = 0;
         const int v = gemm16_pick(a, 0, &wstat);
-        if (v >= 0) { launch_gemm16_variant(a, v, 0, st); return; }
+        if (v >= 0) { RT_REQUIRE(!a.pair_lo, "gemm: pair output on a route without it"); launch_gemm16_variant(a, v, 0, st); return; }
     }
-    if (conv_patch_eligible(a) && !patch_underfilled) {
+    // only the patch kernel's epilogue writes GemmArgs.pair_lo: every other route below and above would store fp32 into the bf16 hi plane
+    const bool to_patch = conv_patch_eligible(a) && !patch_underfilled;
+    if (a.pair_lo && !to_patch) throw rt_error(RT_E_INVALID, "gemm: pair output on a route without it");
+    if (to_patch) {
         if (a.mode == A_CONV3_UP2) { if (a.epi == EPI_F16) launch_conv3p<EPI_F16, true>(a, st); else launch_conv3p<EPI_F32, true>(a, st); }
         else switch (a.epi) {
             case EPI_BF16: launch_conv3p<EPI_BF16, false>(a, st); break;
