@@ -6,6 +6,7 @@ The numerical steps follow attention_utils.py:233-341 line by line: 32x32 self-a
 SpectralClustering(n_init=100, kmeans) -> clusters labelled by min-max-normalised cross-attention score against
 `segment_threshold` -> bicubic(antialias) resize, clamp, normalise.  The clustering itself stays on the CPU
 (scikit-learn, seeded like the reference: `seed_everything(seed)` before `fit_predict`)."""
+import os
 import random
 
 import numpy as np
@@ -66,7 +67,17 @@ def _segment(selfattn_maps, crossattn_maps, seed, num_segments, resolution):
     affinity = torch.cat(maps32).mean(0).cpu().numpy()
     seed_everything(seed)
     sc = SpectralClustering(num_segments, affinity='precomputed', n_init=100, assign_labels='kmeans')
-    clusters = sc.fit_predict(affinity).reshape(resolution, resolution)
+    # 100 k-means restarts on 1024 points x num_segments coordinates: every OpenMP / BLAS region is far too small for the host's
+    # thread pool (256 hardware threads on the GPU boxes) and pays its fork / join instead - one thread is the fastest setting
+    # (0.98 -> 0.59 s on 8 cores).  Same seed, same labels (tests/test_token_maps.py); RTDIFF_CLUSTER_THREADS=0 leaves the pools alone.
+    nthr = int(os.environ.get("RTDIFF_CLUSTER_THREADS", "1"))
+    if nthr > 0:
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=nthr):
+            clusters = sc.fit_predict(affinity)
+    else:
+        clusters = sc.fit_predict(affinity)
+    clusters = clusters.reshape(resolution, resolution)
 
     cross = []
     for attn_map in crossattn_maps.values():

@@ -55,6 +55,21 @@ def test_segmentation_cache_gives_the_uncached_masks_and_clusters_once(monkeypat
     assert len(calls) == 2
 
 
+def test_single_threaded_clustering_gives_the_default_pools_labels(monkeypatch):
+    """get_token_maps runs sklearn's SpectralClustering under threadpool_limits(1) (100 tiny k-means restarts pay the fork / join of a
+    256-thread host pool): the masks must be the ones the untouched pools give - and the golden test above already holds the limited
+    run against the REFERENCE function's output."""
+    from rich_text_to_image_amd.attention_utils import get_token_maps
+    selfm, crossm = synthetic_attention_maps(1)
+    toks = [torch.tensor([2, 3]), torch.tensor([6])]
+    out = {}
+    for thr in ("1", "0"):
+        monkeypatch.setenv("RTDIFF_CLUSTER_THREADS", thr)
+        out[thr] = get_token_maps(selfm, crossm, {}, None, 64, 64, toks, seed=4, segment_threshold=0.3, num_segments=5, device="cpu")
+    for a, b in zip(out["1"], out["0"]):
+        assert torch.equal(a, b)
+
+
 def test_same_size_bicubic_antialias_resize_is_the_identity():
     """The port drops the reference's resize of the 32 x 32 self-attention maps to 32 x 32 (attention_utils.py:246-251): it must be
     the identity, bit for bit, in this torch build - including the reference's permute / reshape round trip around it."""
