@@ -1,0 +1,148 @@
+"""TEST INFRASTRUCTURE: full-SCHEDULE trajectories of the fp32 CPU oracle at the architectures BASELINE.json names.
+
+    python -m oracle.make_fullsize_golden config1 config3 config5 [config3_50]      # in the build container (CPU time is free there)
+
+writes tests/golden/fullschedule/<case>.pt = latents at a list of loop iterations + the final image (uint8, decoded by the
+oracle VAE as the reference decodes it: rd.py:227-236,267-271 / xl.py:916-944).  tests/test_fullschedule_gpu.py runs the HIP
+engine over the SAME schedules and compares per checkpoint and in pixels.
+
+What is followed (file:line under /root/reference):
+  * config 1 = RegionDiffusion.produce_latents, models/region_diffusion.py:86-174: SD-v1.5 @ 64x64 latent, R = 2, 20 requested
+    steps = 21 PLMS iterations, CFG 8.5, one font-size token
+  * config 3 = RegionDiffusionXL.sample rich branch, models/region_diffusion_sdxl.py:779-878: SDXL-base @ 128x128, R = 4,
+    inject_selfattn = 0.5, CFG 5, two font-size tokens; 10 Euler steps (t > 500 for iterations 0..4: the injection boundary
+    falls between checkpoints 5 and 6) and, as `config3_50`, the full 50 steps
+  * config 5 = the same loop with use_guidance (xl.py:849-867, precise fp32 SDXL VAE), inject_background = 0.5, CFG 7.5,
+    4 Euler steps @ 128x128 (blend at iteration 2, xl.py:870)
+
+Nothing large is committed: the UNet / VAE weights are `oracle.unet.random_state_dict(cfg, seed)` /
+`oracle.vae.random_vae_state_dict(cfg, seed)` - drawn by torch's CPU generator from a seed, regenerated bit-identically on the
+GPU box (same image, same torch) and checked there against the fingerprint stored in the file.  The inputs are functions of a
+seed too (`case_inputs`).  The loops are oracle.region_loop's, pinned against the unmodified reference loops by
+tests/test_oracle_vs_reference.py.
+"""
+import os
+import sys
+import time
+
+import torch
+
+from .region_loop import rich_loop_sd, rich_loop_xl
+from .schedulers import OracleEuler, OraclePNDM
+from .unet import SD15_CONFIG, SDXL_CONFIG, OracleUNet, random_state_dict
+from .vae import SD_VAE_CONFIG, SDXL_VAE_CONFIG, OracleVAEDecoder, random_vae_state_dict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "golden", "fullschedule")
+
+CASES = {
+    # name: model, latent size, regions, requested steps, CFG, inject_selfattn, inject_background, guided, checkpoints (1-based loop iterations)
+    "config1": dict(model="sd15", hw=64, R=2, steps=20, gs=8.5, isa=0.0, ibg=0.0, guided=False, unet_seed=101, vae_seed=201, seed=301,
+                    word_pos=[2], font_size=[3.0], checkpoints=[1, 2, 3, 6, 11, 16, 21]),
+    "config3": dict(model="sdxl", hw=128, R=4, steps=10, gs=5.0, isa=0.5, ibg=0.0, guided=False, unet_seed=103, vae_seed=203, seed=303,
+                    word_pos=[5, 6], font_size=[20.0, 20.0], checkpoints=[1, 2, 5, 6, 10]),
+    "config3_50": dict(model="sdxl", hw=128, R=4, steps=50, gs=5.0, isa=0.5, ibg=0.0, guided=False, unet_seed=103, vae_seed=203, seed=303,
+                       word_pos=[5, 6], font_size=[20.0, 20.0], checkpoints=[1, 2, 5, 10, 15, 20, 25, 26, 30, 35, 40, 45, 50]),
+    "config5": dict(model="sdxl", hw=128, R=4, steps=4, gs=7.5, isa=0.0, ibg=0.5, guided=True, unet_seed=103, vae_seed=203, seed=305,
+                    word_pos=[4], font_size=[8.0], n_color=1, color_weight=20.0, checkpoints=[1, 2, 3, 4]),
+}
+
+
+def smooth_masks(R, hw, g):
+    """R soft region masks that sum to 1 (attention_utils.py:325-329 normalises the same way), 4 identical channels."""
+    m = torch.softmax(torch.randn(R, 1, hw // 4, hw // 4, generator=g) * 4, dim=0)
+    m = torch.nn.functional.interpolate(m, size=(hw, hw), mode="bilinear", align_corners=False)
+    return (m / (m.sum(0, keepdim=True) + 1e-8)).repeat(1, 4, 1, 1)
+
+
+def case_inputs(name):
+    """Every input of a case from its seed (CPU generator): identical here and on the GPU box."""
+    c = CASES[name]
+    xl = c["model"] == "sdxl"
+    hw, R = c["hw"], c["R"]
+    g = torch.Generator().manual_seed(c["seed"])
+    d = {"emb": torch.randn(R + 1, 77, 2048 if xl else 768, generator=g)}
+    if xl:
+        d["pooled"] = torch.randn(R + 1, 1280, generator=g)
+        d["time_ids"] = torch.tensor([[8.0 * hw, 8.0 * hw, 0, 0, 8.0 * hw, 8.0 * hw]])
+    d["masks"] = smooth_masks(R, hw, g)
+    d["latents"] = torch.randn(1, 4, hw, hw, generator=g)                 # unscaled: prepare_latents multiplies by init_noise_sigma (xl.py:533-536)
+    tfd = {"word_pos": torch.tensor(c["word_pos"]), "font_size": torch.tensor(c["font_size"])}
+    if c["guided"]:
+        n = c["n_color"]
+        tfd.update({"target_RGB": [torch.rand(1, 3, 1, 1, generator=g) for _ in range(n)], "guidance_start_step": 999,
+                    "color_guidance_weight": c["color_weight"],
+                    "color_obj_atten": [(torch.rand(1, 1, 8 * hw, 8 * hw, generator=g) ** 2).repeat(1, 4, 1, 1) for _ in range(n + 1)],
+                    "color_obj_atten_all": torch.rand(1, 4, hw, hw, generator=g)})
+    d["tfd"] = tfd
+    return d
+
+
+def unet_weights(name):
+    c = CASES[name]
+    return random_state_dict(SDXL_CONFIG if c["model"] == "sdxl" else SD15_CONFIG, seed=c["unet_seed"])
+
+
+def vae_weights(name):
+    c = CASES[name]
+    return random_vae_state_dict(SDXL_VAE_CONFIG if c["model"] == "sdxl" else SD_VAE_CONFIG, seed=c["vae_seed"])
+
+
+def to_uint8(img):
+    """[1,3,H,W] decoder output in [-1,1] -> uint8 [H,W,3] (rd.py:234,267-271; VaeImageProcessor.postprocess for xl.py:943)."""
+    return ((img / 2 + 0.5).clamp(0, 1)[0].permute(1, 2, 0) * 255).round().to(torch.uint8)
+
+
+def weights_fingerprint(sd):
+    """Same digest as tests/oracle_cache.py (kept local: oracle/ does not import tests/)."""
+    import hashlib
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        t = sd[k].double()
+        h.update(f"{k}|{tuple(t.shape)}|{float(t.sum()):.17g}|{float((t * t).sum()):.17g};".encode())
+    return h.hexdigest()
+
+
+def run_case(name):
+    c = CASES[name]
+    xl = c["model"] == "sdxl"
+    t0 = time.perf_counter()
+    usd, vsd = unet_weights(name), vae_weights(name)
+    inp = case_inputs(name)
+    unet = OracleUNet(SDXL_CONFIG if xl else SD15_CONFIG, usd)
+    vcfg = SDXL_VAE_CONFIG if xl else SD_VAE_CONFIG
+    vae = OracleVAEDecoder(vcfg, vsd)
+    print(f"[{name}] weights + inputs drawn in {time.perf_counter() - t0:.0f} s", flush=True)
+    m = inp["masks"]
+    masks = [m[r:r + 1] for r in range(c["R"])]
+    guidance = {"vae": vae, "scaling": vcfg["scaling_factor"]} if c["guided"] else None
+
+    class Progress(list):                                                  # the loops append one latent per iteration
+        def append(self, x):
+            super().append(x)
+            print(f"[{name}] iteration {len(self)} done at {time.perf_counter() - t0:.0f} s, latent std {x.std():.4f}", flush=True)
+    trace = Progress()
+    if xl:
+        sched = OracleEuler(); sched.set_timesteps(c["steps"])
+        lat0 = inp["latents"] * sched.init_noise_sigma
+        final = rich_loop_xl(unet, OracleEuler(), inp["emb"], inp["pooled"], inp["time_ids"], masks, lat0, c["steps"], c["gs"], inp["tfd"],
+                             c["isa"], c["ibg"], use_guidance=c["guided"], guidance=guidance, trace=trace)
+    else:
+        lat0 = inp["latents"]
+        final = rich_loop_sd(unet, OraclePNDM(), inp["emb"], masks, lat0, c["steps"], c["gs"], inp["tfd"], c["isa"], c["ibg"],
+                             use_guidance=c["guided"], guidance=guidance, trace=trace)
+    assert torch.equal(final, trace[-1]) and len(trace) == c["checkpoints"][-1], (len(trace), c["checkpoints"])
+    with torch.no_grad():
+        image = to_uint8(vae.decode(final / vcfg["scaling_factor"]))
+    out = {"case": dict(c), "unet_fingerprint": weights_fingerprint(usd), "vae_fingerprint": weights_fingerprint(vsd),
+           "lat0": lat0, "checkpoints": {k: trace[k - 1].clone() for k in c["checkpoints"]}, "image_u8": image,
+           "torch": torch.__version__, "oracle_seconds": time.perf_counter() - t0}
+    os.makedirs(OUT, exist_ok=True)
+    torch.save(out, os.path.join(OUT, name + ".pt"))
+    print(f"[{name}] written; {time.perf_counter() - t0:.0f} s; final latent std {final.std():.4f}; image mean {image.float().mean():.1f}", flush=True)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(int(os.environ.get("ORACLE_THREADS", os.cpu_count() or 1)))
+    for n in sys.argv[1:] or ["config1", "config3", "config5"]:
+        run_case(n)

@@ -392,7 +392,8 @@ void launch_attn_store(const AttnStoreArgs& a, hipStream_t st) {
         switch (a.DP) {
             case 32: hipLaunchKernelGGL(attn_store_stats_kernel<32>, gs, blk, 0, st, a); hipLaunchKernelGGL(attn_store_apply_kernel<32>, ga, blk, 0, st, a); break;
             case 64: hipLaunchKernelGGL(attn_store_stats_kernel<64>, gs, blk, 0, st, a); hipLaunchKernelGGL(attn_store_apply_kernel<64>, ga, blk, 0, st, a); break;
-            default: hipLaunchKernelGGL(attn_store_stats_kernel<96>, gs, blk, 0, st, a); hipLaunchKernelGGL(attn_store_apply_kernel<96>, ga, blk, 0, st, a); break;
+            case 96: hipLaunchKernelGGL(attn_store_stats_kernel<96>, gs, blk, 0, st, a); hipLaunchKernelGGL(attn_store_apply_kernel<96>, ga, blk, 0, st, a); break;
+            default: throw rt_error(RT_E_UNSUPPORTED, "attn_store: unsupported padded head dim");
         }
         HIP_CHECK(hipGetLastError());
         return;

@@ -48,7 +48,9 @@ def self_launch(script, argv, nproc, require_gpus=True, module=None):
         if have < nproc:
             return f"need {nproc} GPUs on this node for --gpus {nproc}, found {have}"
     env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes fails without it on this driver
+    # dmabuf IPC: the image's documentation says RCCL / cross-process device-memory sharing needs it on this host driver.  NOT validated
+    # here: every GPU lease of rounds 1-5 had ONE device, the 2-rank RCCL path has never executed.
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "8")
     # module: `python -m pkg.mod` programs (sample.py uses relative imports) are launched as torchrun's --module form
     target = ["--module", module] if module else [script]
@@ -97,14 +99,15 @@ def broadcast_tensor(t, src=0, chunk_bytes=None):
     if flat.is_cuda and dist.get_backend() == "gloo":
         # gloo carries host memory: stage device arenas through pinned-size host chunks (tests that run two ranks on ONE GPU; the
         # product backend is RCCL, which takes the device tensor as it is)
-        step = 1 << 28
+        step, n, is_src = 1 << 28, 0, dist.get_rank() == src
         for off in range(0, flat.numel(), step):
             piece = flat[off:off + step]
-            host = piece.cpu()
+            host = piece.cpu() if is_src else torch.empty(piece.shape, dtype=piece.dtype)     # receivers: no device -> host copy
             dist.broadcast(host, src=src)
-            if dist.get_rank() != src:
+            n += 1
+            if not is_src:
                 piece.copy_(host)
-        return 1
+        return n
     if chunk_bytes is None:
         if flat.dtype == torch.uint8 and flat.numel() % 8 == 0 and flat.data_ptr() % 8 == 0:
             flat = flat.view(torch.int64)

@@ -34,9 +34,16 @@ class HipUNet2DConditionModel:
             self.max_streams, grow = min(16, max(streams, 2 * self.max_streams)), True
         if prompts and prompts > self.max_prompts:
             self.max_prompts, grow = max(prompts, 2 * self.max_prompts), True
+        donor = None
         if grow:
+            # A model built "empty" (ranks != 0 of a seed-parallel launch) holds weights that exist nowhere else on this rank: the
+            # packed arena it received by launcher.broadcast_weights.  Its layout is a function of the config alone (not of the
+            # stream / prompt capacity), so the rebuilt engine takes it over device to device.
+            if isinstance(self._state_dict, str) and self._state_dict == "empty":
+                donor = next((e for e in self._engines.values() if e.weights_missing()[0] == 0), None)
             for e in self._engines.values():
-                e.close()
+                if e is not donor:
+                    e.close()
             self._engines = {}
         key = (h, w)
         if key not in self._engines:
@@ -45,7 +52,16 @@ class HipUNet2DConditionModel:
             if self._state_dict is None:
                 raise RuntimeError("HipUNet2DConditionModel: no weights loaded (call load_state_dict)")
             if isinstance(self._state_dict, str) and self._state_dict == "empty":
-                pass                                                            # the packed arena arrives by launcher.broadcast_weights
+                if donor is not None:                                           # grown engine of a broadcast-fed rank
+                    from .launcher import arena_tensor
+                    src, dst = arena_tensor(donor), arena_tensor(e)
+                    if src.numel() != dst.numel():
+                        raise RuntimeError(f"weight arena layout changed with the engine capacity ({src.numel()} vs {dst.numel()} bytes)")
+                    dst.copy_(src)
+                    torch.cuda.synchronize(self.device_index)
+                    e.arena_mark_bound()
+                    donor.close()
+                # otherwise the packed arena arrives by launcher.broadcast_weights
             elif isinstance(self._state_dict, str) and self._state_dict.startswith("random"):
                 e.init_random_weights(seed=int(self._state_dict[6:] or 0))      # "random<seed>": benchmarks without checkpoints
             else:

@@ -1,0 +1,168 @@
+"""FULL-SCHEDULE parity at the architectures BASELINE.json names, in latents per checkpoint AND in final pixels.
+
+tests/golden/fullschedule/<case>.pt holds trajectories of the fp32 CPU oracle (oracle/region_loop.py, pinned to the unmodified
+reference loops by tests/test_oracle_vs_reference.py), generated in the build container by `python -m oracle.make_fullsize_golden`:
+
+  * config1     RegionDiffusion.produce_latents      rd.py:86-174,227-236    SD-v1.5 @ 512x512, R = 2, 20 steps = 21 PLMS iterations
+  * config3     RegionDiffusionXL.sample(rich)       xl.py:779-878,916-944   SDXL @ 1024x1024, R = 4, inject_selfattn 0.5, 10 Euler steps
+  * config3_50  the same, the full 50-step schedule (the benched workload end to end)
+  * config5     the same loop + colour guidance (xl.py:849-867) + background blend, CFG 7.5, 4 Euler steps @ 1024x1024
+
+The weights are not committed: `oracle.unet.random_state_dict(cfg, seed)` draws them with torch's CPU generator, bit-identically
+here and in the build container (checked against the fingerprint in the file).  The HIP engine runs the same schedule through the
+facade classes; after the iterations the file lists, the relative L2 error of the latents is asserted (the growth curve is printed and
+written to gpurun_out/fullschedule_parity.json), and the final image is compared in uint8 pixels with the oracle's image (decoded by
+the oracle VAE the way the reference decodes: /2 + 0.5, clamp, x255, round): PSNR, mean and max absolute difference, fraction of
+pixels within 1 / 2 / 8 levels.  `decoder only` = the ORACLE's final latents through the engine's decoder: what the decoder alone
+contributes.
+
+Stated tolerances (measured values in DESIGN.md section 5): see TOL below.
+"""
+import json
+import math
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import make_fullsize_golden as mg  # noqa: E402
+from oracle.unet import SD15_CONFIG, SDXL_CONFIG  # noqa: E402
+from oracle.vae import SD_VAE_CONFIG, SDXL_VAE_CONFIG  # noqa: E402
+
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden", "fullschedule")
+
+# case: (max rel-L2 of the latents at ANY checkpoint, min PSNR [dB] of the final uint8 image, max mean-abs pixel difference)
+TOL = {
+    "config1": (6e-2, 26.0, 8.0),
+    "config3": (6e-2, 26.0, 8.0),
+    "config3_50": (1e-1, 22.0, 12.0),
+    "config5": (6e-2, 26.0, 8.0),
+}
+RESULTS = {}
+
+
+def rel_l2(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).pow(2).sum() / b.pow(2).sum()).sqrt().item()
+
+
+def pixel_stats(got_u8, ref_u8):
+    d = (got_u8.to(torch.int16) - ref_u8.to(torch.int16)).abs().float()
+    mse = (d * d).mean().item()
+    return {"psnr_db": 10 * math.log10(255.0 ** 2 / max(mse, 1e-12)), "mean_abs": d.mean().item(), "max_abs": int(d.max()),
+            "within_1": (d <= 1).float().mean().item(), "within_2": (d <= 2).float().mean().item(), "within_8": (d <= 8).float().mean().item()}
+
+
+def load_golden(name):
+    path = os.path.join(GOLD, name + ".pt")
+    if not os.path.exists(path):
+        pytest.skip(f"{path} not generated (python -m oracle.make_fullsize_golden {name})")
+    return torch.load(path)
+
+
+def _report(name, curve, pix, pix_dec, gold):
+    RESULTS[name] = {"latent_rel_l2_by_iteration": curve, "pixels_vs_oracle_image": pix, "decoder_only": pix_dec,
+                     "oracle_seconds": gold["oracle_seconds"], "case": {k: v for k, v in gold["case"].items() if k != "checkpoints"}}
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "fullschedule_parity.json"), "w") as f:
+        json.dump(RESULTS, f, indent=1)
+    print(f"{name}: latent rel-L2 by loop iteration: " + ", ".join(f"{k}: {v:.3e}" for k, v in curve.items()))
+    print(f"{name}: final image vs the oracle's image: PSNR {pix['psnr_db']:.2f} dB, mean |d| {pix['mean_abs']:.3f} / 255, max |d| {pix['max_abs']}, "
+          f"within 1 / 2 / 8 levels {pix['within_1']:.4f} / {pix['within_2']:.4f} / {pix['within_8']:.4f}")
+    print(f"{name}: decoder only (oracle latents through the engine's decoder): PSNR {pix_dec['psnr_db']:.2f} dB, mean |d| {pix_dec['mean_abs']:.4f}, max |d| {pix_dec['max_abs']}")
+    t_lat, t_psnr, t_mean = TOL[name]
+    assert max(curve.values()) < t_lat, curve
+    assert pix["psnr_db"] > t_psnr and pix["mean_abs"] < t_mean, pix
+    assert pix_dec["psnr_db"] > 40.0, pix_dec
+
+
+@pytest.fixture(scope="module")
+def sdxl_model():
+    """RegionDiffusionXL on the seed-103 SDXL-base weights + the seed-203 SDXL VAE in the precise (fp32-class) mode the reference
+    decodes and guides in (xl.py:856,916-938)."""
+    from rich_text_to_image_amd.engine import VaeDecoder
+    from rich_text_to_image_amd.region_diffusion_sdxl import RegionDiffusionXL
+    usd, vsd = mg.unet_weights("config3"), mg.vae_weights("config3")
+    fp = (mg.weights_fingerprint(usd), mg.weights_fingerprint(vsd))
+    vae = VaeDecoder(SDXL_VAE_CONFIG, 128, 128, device=0, state_dict=vsd, precise=True)
+    mdl = RegionDiffusionXL(device=0, unet_state_dict=usd, config=SDXL_CONFIG, vae=vae, vae_scaling_factor=SDXL_VAE_CONFIG["scaling_factor"])
+    mdl.unet.engine(128, 128)                # packs the arena now ...
+    mdl.unet._state_dict = "empty"           # ... and lets go of 10 GB of fp32 host tensors
+    del usd
+    yield mdl, fp
+    for e in mdl.unet._engines.values():
+        e.close()
+    vae.close()
+
+
+def _run_xl(name, mdl, fp):
+    gold = load_golden(name)
+    c = gold["case"]
+    assert (gold["unet_fingerprint"], gold["vae_fingerprint"]) == fp, "regenerated weights differ from the ones the golden file was made with"
+    inp = mg.case_inputs(name)
+    m = inp["masks"]
+    mdl.masks = [m[r:r + 1] for r in range(c["R"])]
+    got = {}
+    emb, pooled = inp["emb"], inp["pooled"]
+    out = mdl.sample(prompt=None, height=8 * c["hw"], width=8 * c["hw"], num_inference_steps=c["steps"], guidance_scale=c["gs"],
+                     latents=inp["latents"].clone(), prompt_embeds=emb[1:], negative_prompt_embeds=emb[:1], pooled_prompt_embeds=pooled[1:],
+                     negative_pooled_prompt_embeds=pooled[:1], output_type="np", run_rich_text=True, text_format_dict=inp["tfd"],
+                     use_guidance=c["guided"], inject_selfattn=c["isa"], inject_background=c["ibg"],
+                     callback=lambda i, t, lat: got.__setitem__(i + 1, lat.cpu()) if (i + 1) in gold["checkpoints"] else None)
+    image = torch.from_numpy(out.images[0])
+    curve = {k: rel_l2(got[k], v) for k, v in gold["checkpoints"].items()}
+    last = c["checkpoints"][-1]
+    dec = mdl.vae.decode(gold["checkpoints"][last].to(DEV) / SDXL_VAE_CONFIG["scaling_factor"])
+    _report(name, curve, pixel_stats(image, gold["image_u8"]), pixel_stats(mg.to_uint8(dec.float().cpu()), gold["image_u8"]), gold)
+
+
+def test_config3_ten_step_schedule_latents_and_pixels(sdxl_model):
+    _run_xl("config3", *sdxl_model)
+
+
+def test_config3_full_fifty_step_schedule_latents_and_pixels(sdxl_model):
+    _run_xl("config3_50", *sdxl_model)
+
+
+def test_config5_guided_schedule_latents_and_pixels(sdxl_model):
+    _run_xl("config5", *sdxl_model)
+
+
+def test_config1_full_plms_schedule_latents_and_pixels():
+    """BASELINE config 1 in full: the engine is driven exactly as RegionDiffusion.produce_latents drives it (region_diffusion.py of
+    this package), with the latents read back after the listed iterations; the final latents go through RegionDiffusion.latents_to_uint8."""
+    from rich_text_to_image_amd.engine import VaeDecoder
+    from rich_text_to_image_amd.region_diffusion import RegionDiffusion
+    name = "config1"
+    gold = load_golden(name)
+    c = gold["case"]
+    usd, vsd = mg.unet_weights(name), mg.vae_weights(name)
+    assert gold["unet_fingerprint"] == mg.weights_fingerprint(usd) and gold["vae_fingerprint"] == mg.weights_fingerprint(vsd)
+    inp = mg.case_inputs(name)
+    hw = c["hw"]
+    vae = VaeDecoder(SD_VAE_CONFIG, hw, hw, device=0, state_dict=vsd)        # single bf16 pass: rd.py:232 decodes in the checkpoint dtype under autocast
+    mdl = RegionDiffusion(0, unet_state_dict=usd, config=SD15_CONFIG, vae=vae)
+    m = inp["masks"]
+    mdl.masks = [m[r:r + 1] for r in range(c["R"])]
+    final = mdl.produce_latents(inp["emb"], num_inference_steps=c["steps"], guidance_scale=c["gs"], latents=inp["latents"].clone(), text_format_dict=inp["tfd"])
+    # the same loop once more, stopping at the checkpoints (produce_latents has no callback: rd.py:86 has none either)
+    eng = mdl.unet.engine(hw, hw)
+    eng.set_latents(inp["latents"].to(DEV))
+    got = {}
+    for i in range(len(mdl.scheduler.timesteps)):
+        eng.region_step(i, c["gs"], 0.0, 0.0, xl=False, elide=False)
+        if i + 1 in gold["checkpoints"]:
+            got[i + 1] = eng.read_latents(hw, hw).cpu()
+    assert torch.equal(got[c["checkpoints"][-1]], final.cpu())              # the run is deterministic
+    curve = {k: rel_l2(got[k], v) for k, v in gold["checkpoints"].items()}
+    image = torch.from_numpy(mdl.latents_to_uint8(final)[0])
+    dec = torch.from_numpy(mdl.latents_to_uint8(gold["checkpoints"][c["checkpoints"][-1]].to(DEV))[0])
+    for e in mdl.unet._engines.values():
+        e.close()
+    vae.close()
+    _report(name, curve, pixel_stats(image, gold["image_u8"]), pixel_stats(dec, gold["image_u8"]), gold)
