@@ -161,9 +161,18 @@ def cross_attention_block(dev, F=7):
         flops = F * (4.0 * N * Cc * H * DP + 4.0 * H * N * 77 * 64)
         out[name] = dict(ms=ms, tflops=flops / (ms * 1e-3) / 1e12, frac=flops / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
                          three_launch_ms=ms3, three_launch_frac=flops / (ms3 * 1e-3) / 1e12 / PEAK_BF16_TFLOPS)
+        if Cc == 640:                                 # the one-launch register-chained form (xblock.hip; opt-in, NOT the engine's path: slower)
+            lib.rt_op_gemm_debug(flags | 65536)
+            try:
+                ms1 = timed()
+            finally:
+                lib.rt_op_gemm_debug(flags)
+            out[name].update(one_launch_xblock_ms=ms1, one_launch_xblock_frac=flops / (ms1 * 1e-3) / 1e12 / PEAK_BF16_TFLOPS)
     out["note"] = ("rt_op_cross_attn_block: to_q + attention(77 keys, cached K/V, font-size softmax) + to_out(+bias, + fp16 trunk residual) "
-                   "for the 7 streams of a step, exactly the launches the engine issues - round 4: to_q and the attention are one kernel "
-                   "(gemm16.hip EPI_XATTN, the Q tile stays in LDS) + the to_out GEMM; three_launch_* = the same operator as three launches; executed FLOPs")
+                   "for the 7 streams of a step, exactly the launches the engine issues - to_q and the attention as one kernel where the tiling "
+                   "allows it (gemm16.hip EPI_XATTN, the Q tile stays in LDS: shape B) + the to_out GEMM; one_launch_xblock_* (shape A) = the whole "
+                   "block as ONE launch with Q / P / O in registers (xblock.hip, round 5): built, parity-tested, slower, not the engine's path; "
+                   "three_launch_* = the same operator as three launches; executed FLOPs")
     return out
 
 

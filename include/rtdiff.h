@@ -120,7 +120,8 @@ int rt_attn_module_info(rt_engine* e, int idx, char* name, int name_cap, int* ma
  * head dims / keys are not counted). */
 enum { RT_PROF_GEMM_DENSE = 0, RT_PROF_GEMM_CONV = 1, RT_PROF_ATTN_SELF = 2, RT_PROF_ATTN_CROSS = 3,
        RT_PROF_ATTN_STORE = 4 /* head-averaged map accumulation of the plain pass (attn_store_kernel, HBM-side accumulators) */,
-       RT_PROF_XATTN_FUSED = 5 /* to_q + 77-key cross-attention as one launch (gemm16 EPI_XATTN): FLOPs = 2*M*HD*C + 4*B*H*N*77*d */ };
+       RT_PROF_XATTN_FUSED = 5 /* to_q + 77-key cross-attention as one launch (gemm16 EPI_XATTN): FLOPs = 2*M*HD*C + 4*B*H*N*77*d */,
+       RT_PROF_XBLOCK = 6 /* the whole cross-attention block as one launch (xblock.hip): FLOPs = 4*M*HD*C + 4*B*H*N*77*d */ };
 int rt_profile_enable(rt_engine* e, int on);     /* on: start recording (clears old records); off: stop */
 int rt_profile_read(rt_engine* e, int kernel_class, int* count, double* total_ms, double* total_flops);
 /* as rt_profile_read, plus the ALGORITHMIC HBM bytes of the launches (attention store: the fp32 accumulator read + written once and the

@@ -99,7 +99,7 @@ def weights_fingerprint(sd):
     h = hashlib.sha256()
     for k in sorted(sd):
         t = sd[k].double()
-        h.update(f"{k}|{tuple(t.shape)}|{float(t.sum()):.17g}|{float((t * t).sum()):.17g};".encode())
+        h.update(f"{k}|{tuple(t.shape)}|{float(t.sum()):.10g}|{float((t * t).sum()):.10g};".encode())
     return h.hexdigest()
 
 

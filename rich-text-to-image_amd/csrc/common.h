@@ -155,11 +155,26 @@ struct GemmArgs {
 // tokens % 128 == 0, C % 64 == 0, C >= 192.
 bool xattn_fused_supported(int C, int H, int DP, int tokens);
 void launch_xattn_fused(const GemmArgs& a, hipStream_t st);
+// xblock.hip: the whole cross-attention block of the 640-channel level (to_q -> 77-key attention -> to_out + bias + fp16 residual) as ONE
+// launch with Q, P and O in registers.  x = LayerNorm'd tokens (bf16), wq = packed to_q [H * 64, C] pre-scaled by d^-1/2 log2 e,
+// wo = packed to_out [C, H * 64], K / V^T = the per-prompt cache (AttnArgs layout), res / out = the fp16 trunk.
+struct XBlockArgs {
+    const bf16_t* x; const bf16_t* wq; const bf16_t* wo; const float* bo;
+    const bf16_t* kc; const bf16_t* vt;
+    const f16_t* res; f16_t* out;
+    const float* wabs; const float* wsgn;            // [nsets, 96] font-size multipliers (attention_processor.py:386-401)
+    int ldk, ldvt, ldres, ldo;
+    int M, tokens, nk_valid, C, H;                   // M = streams * tokens; keys >= nk_valid of the 96 cached rows are masked
+    int prompt[RT_MAXB], wset[RT_MAXB];              // per stream: prompt index into the cache, multiplier set (-1: plain softmax)
+};
+bool xblock_supported(int C, int H, int DP, int tokens);
+void launch_xblock(const XBlockArgs& a, hipStream_t st);
 void launch_gemm(const GemmArgs& a, hipStream_t st);
 bool gemm_pair_output_ok(const GemmArgs& a);            // host-only: launch_gemm would run this problem on a kernel that can write GemmArgs.pair_lo
 size_t gemm_splitk_scratch_floats(const GemmArgs& a);   // fp32 partial sums launch_gemm needs for this problem (0: not split)
 void gemm_force_config(int cfg);   // -1: shape-based choice; 0..8: force a gemm.hip tile configuration (also keeps gemm16.hip out)
 void gemm_set_debug(int d);        // bit 0: eligible 3x3 convolutions through the implicit-GEMM kernels; bit 1: keep gemm16.hip out; bit 4: no fused cross-attention
+bool gemm_xblock_enabled();       // the one-launch cross-attention block (xblock.hip) is switched on (debug bit 16 SET - opt-in; gemm16 on, no forced configuration)
 bool gemm_xattn_enabled();         // the fused to_q + cross-attention kernel is allowed (debug bit 4 clear, gemm16 on, no forced configuration)
 // gemm16.hip: 16x16x32-MFMA family (224-row tiles, intra-tile K split); dense problems with K % 64 == 0 only
 #define RT_G16_NVAR 13

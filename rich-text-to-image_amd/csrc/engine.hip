@@ -569,6 +569,20 @@ struct rt_engine {
                 // keeps the two-launch form for the layers it records
                 const bool capture2 = in.store_stream >= 0 && k.store_mode[1];
                 const bool fused2 = gemm_xattn_enabled() && xattn_fused_supported(C, t.heads, t.DP, HW) && !capture2;
+                // the 640-channel level: to_q, attention AND to_out + residual as one launch with Q / P / O in registers (xblock.hip)
+                const bool block2 = gemm_xblock_enabled() && xblock_supported(C, t.heads, t.DP, HW) && t.d == 64 && !capture2;
+                if (block2) {
+                    if (!dry()) {
+                        XBlockArgs xa{}; xa.x = n; xa.wq = k.q2.w; xa.wo = k.out2.w; xa.bo = k.out2.b; xa.kc = k.kcache; xa.vt = k.vtcache;
+                        xa.res = hcur; xa.out = hcur; xa.wabs = wabs; xa.wsgn = wsgn; xa.ldk = HD; xa.ldvt = cfg.max_prompts * 96; xa.ldres = C; xa.ldo = C;
+                        xa.M = M; xa.tokens = HW; xa.nk_valid = 77; xa.C = C; xa.H = t.heads;
+                        for (int b = 0; b < B; ++b) { xa.prompt[b] = in.prompt[b]; xa.wset[b] = in.fontsize[b] ? 1 : -1; }
+                        RT_REQUIRE(k.q2.K == C && k.out2.K == HD && HD == C, "xblock: packed projection widths");
+                        prof_begin(RT_PROF_XBLOCK, 4.0 * M * HD * C + 4.0 * B * t.heads * (double)HW * 77 * t.d);
+                        launch_xblock(xa, stream);
+                        prof_end();
+                    }
+                } else {
                 if (fused2) {
                     if (!dry()) {
                         GemmArgs g{}; g.A = n; g.W = k.q2.w; g.out = o; g.zero = zero; g.mode = A_DENSE; g.epi = EPI_XATTN;
@@ -605,6 +619,7 @@ struct rt_engine {
                 }
                 }
                 gemm(o, HD, k.out2, M, hcur, C, EPI_F16, hcur, C);
+                }
                 // --- GEGLU feed-forward (attention.py:209-304)
                 layernorm(hcur, k.ln3, n, M);
                 bf16_t* gg = ws.b16((size_t)M * 4 * C);
@@ -1255,6 +1270,15 @@ int rt_op_cross_attn_block(const void* x, const void* wq, const void* wo, const 
         RT_REQUIRE(B >= 1 && B <= RT_MAXB && N > 0 && C % 8 == 0 && H > 0 && DP % 32 == 0, "rt_op_cross_attn_block: shape");
         hipStream_t st = (hipStream_t)stream;
         const int M = B * N, HD = H * DP;
+        if (gemm_xblock_enabled() && xblock_supported(C, H, DP, N)) {
+            // the engine's path for the 640-channel level: the whole block in one launch (neither scratch buffer is written)
+            XBlockArgs xa{}; xa.x = (const bf16_t*)x; xa.wq = (const bf16_t*)wq; xa.wo = (const bf16_t*)wo; xa.bo = bo; xa.kc = (const bf16_t*)kcache;
+            xa.vt = (const bf16_t*)vtcache; xa.res = (const f16_t*)trunk_in; xa.out = (f16_t*)trunk_out; xa.wabs = wabs; xa.wsgn = wsgn;
+            xa.ldk = HD; xa.ldvt = ldvt; xa.ldres = C; xa.ldo = C; xa.M = M; xa.tokens = N; xa.nk_valid = 77; xa.C = C; xa.H = H;
+            for (int b = 0; b < B; ++b) { xa.prompt[b] = prompt_host ? prompt_host[b] : 0; xa.wset[b] = wset_host ? wset_host[b] : 0; }
+            launch_xblock(xa, st);
+            return RT_OK;
+        }
         if (gemm_xattn_enabled() && xattn_fused_supported(C, H, DP, N)) {
             // the engine's path for these shapes: to_q + attention in one launch (Q stays in LDS; q_scratch is not written)
             GemmArgs g{}; g.A = (const bf16_t*)x; g.W = (const bf16_t*)wq; g.out = o_scratch; g.zero = op_zero_page(); g.mode = A_DENSE; g.epi = EPI_XATTN;

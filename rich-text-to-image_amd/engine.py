@@ -313,7 +313,7 @@ class Engine:
 
     # ---- profiling (HIP events around every MFMA kernel launch on the engine stream)
     PROF_CLASSES = {0: "gemm_kernel<A_DENSE>", 1: "gemm_kernel<A_CONV3*>", 2: "attn_kernel<self>", 3: "attn_kernel<cross>",
-                    5: "gemm16_kernel<EPI_XATTN> (to_q + cross-attention)"}
+                    5: "gemm16_kernel<EPI_XATTN> (to_q + cross-attention)", 6: "xblock_kernel (to_q + cross-attention + to_out)"}
     PROF_STORE = 4          # attn_store_kernel (plain pass, token-map capture): priced in algorithmic HBM bytes
 
     def profile_read_store(self):
