@@ -136,13 +136,28 @@ def run_case(name):
         image = to_uint8(vae.decode(final / vcfg["scaling_factor"]))
     out = {"case": dict(c), "unet_fingerprint": weights_fingerprint(usd), "vae_fingerprint": weights_fingerprint(vsd),
            "lat0": lat0, "checkpoints": {k: trace[k - 1].clone() for k in c["checkpoints"]}, "image_u8": image,
-           "torch": torch.__version__, "oracle_seconds": time.perf_counter() - t0}
+           "torch": str(torch.__version__), "oracle_seconds": time.perf_counter() - t0}
     os.makedirs(OUT, exist_ok=True)
     torch.save(out, os.path.join(OUT, name + ".pt"))
     print(f"[{name}] written; {time.perf_counter() - t0:.0f} s; final latent std {final.std():.4f}; image mean {image.float().mean():.1f}", flush=True)
 
 
+def refingerprint(name):
+    """Rewrites the weight fingerprints of an existing file (after a change of the digest's format) - the trajectories stay."""
+    path = os.path.join(OUT, name + ".pt")
+    d = torch.load(path, weights_only=False)
+    d["unet_fingerprint"], d["vae_fingerprint"] = weights_fingerprint(unet_weights(name)), weights_fingerprint(vae_weights(name))
+    d["torch"] = str(d["torch"])
+    torch.save(d, path)
+    print(f"[{name}] fingerprints rewritten")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(int(os.environ.get("ORACLE_THREADS", os.cpu_count() or 1)))
-    for n in sys.argv[1:] or ["config1", "config3", "config5"]:
-        run_case(n)
+    args = sys.argv[1:]
+    if args and args[0] == "--refingerprint":
+        for n in args[1:]:
+            refingerprint(n)
+    else:
+        for n in args or ["config1", "config3", "config5"]:
+            run_case(n)

@@ -16,7 +16,7 @@ the oracle VAE the way the reference decodes: /2 + 0.5, clamp, x255, round): PSN
 pixels within 1 / 2 / 8 levels.  `decoder only` = the ORACLE's final latents through the engine's decoder: what the decoder alone
 contributes.
 
-Stated tolerances (measured values in DESIGN.md section 5): see TOL below.
+Stated tolerances: TOL below (latents: relative L2 at every checkpoint; pixels: PSNR, mean and max absolute difference in uint8 levels).
 """
 import json
 import math
@@ -35,12 +35,14 @@ DEV = "cuda:0"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden", "fullschedule")
 
-# case: (max rel-L2 of the latents at ANY checkpoint, min PSNR [dB] of the final uint8 image, max mean-abs pixel difference)
+# case: (max rel-L2 of the latents at ANY checkpoint, min PSNR [dB] of the final uint8 image, max mean-abs pixel difference, max-abs)
+# Measured on MI355X (profiles/r5_fullschedule_parity.json): config1 4.9e-3 / 53.3 dB / 0.30 / 3; config3 4.1e-3 / 56.2 dB / 0.16 / 2;
+# config5 8.2e-3 / 52.8 dB / 0.33 / 4 - the error of one forward (7e-3 at CFG 1) does not compound over the schedule.
 TOL = {
-    "config1": (6e-2, 26.0, 8.0),
-    "config3": (6e-2, 26.0, 8.0),
-    "config3_50": (1e-1, 22.0, 12.0),
-    "config5": (6e-2, 26.0, 8.0),
+    "config1": (1.5e-2, 46.0, 1.0, 8),
+    "config3": (1.5e-2, 46.0, 1.0, 8),
+    "config3_50": (2.5e-2, 44.0, 1.5, 12),
+    "config5": (2.5e-2, 46.0, 1.0, 8),
 }
 RESULTS = {}
 
@@ -75,9 +77,9 @@ def _report(name, curve, pix, pix_dec, gold):
     print(f"{name}: final image vs the oracle's image: PSNR {pix['psnr_db']:.2f} dB, mean |d| {pix['mean_abs']:.3f} / 255, max |d| {pix['max_abs']}, "
           f"within 1 / 2 / 8 levels {pix['within_1']:.4f} / {pix['within_2']:.4f} / {pix['within_8']:.4f}")
     print(f"{name}: decoder only (oracle latents through the engine's decoder): PSNR {pix_dec['psnr_db']:.2f} dB, mean |d| {pix_dec['mean_abs']:.4f}, max |d| {pix_dec['max_abs']}")
-    t_lat, t_psnr, t_mean = TOL[name]
+    t_lat, t_psnr, t_mean, t_max = TOL[name]
     assert max(curve.values()) < t_lat, curve
-    assert pix["psnr_db"] > t_psnr and pix["mean_abs"] < t_mean, pix
+    assert pix["psnr_db"] > t_psnr and pix["mean_abs"] < t_mean and pix["max_abs"] <= t_max, pix
     assert pix_dec["psnr_db"] > 40.0, pix_dec
 
 
