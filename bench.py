@@ -68,24 +68,45 @@ def cpu_model_name():
     return "unknown"
 
 
-def cpu_baseline(sd_cpu, threads, x, ctx, pooled, tid, t, full_step=False, all_ctx=None, all_pooled=None):
+def pick_cpu_threads(threads_max):
+    """Thread count for the fp32 oracle on this host: the fastest of {16, 32, 64, 128, all physical cores} on the operators one ResNet
+    block + one transformer block of the SDXL UNet are made of, at their 1280-channel / 32x32 shapes (3x3 convolution 1280 -> 1280,
+    the GEGLU and projection matmuls, 20-head self-attention over 1024 tokens, GroupNorm / LayerNorm): oversubscribed NUMA hosts are
+    slower with every hardware thread than with a subset, and a conv-heavy forward need not prefer what one big matmul prefers."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(0)
+    xc, wc = torch.randn(1, 1280, 32, 32, generator=g), torch.randn(1280, 1280, 3, 3, generator=g) * 0.01
+    xt, w1, w2, wq = torch.randn(1024, 1280, generator=g), torch.randn(10240, 1280, generator=g) * 0.02, torch.randn(1280, 5120, generator=g) * 0.02, torch.randn(1280, 1280, generator=g) * 0.02
+    def block():
+        h = F.conv2d(F.silu(F.group_norm(xc, 32)), wc, padding=1)
+        h = F.conv2d(F.silu(F.group_norm(h, 32)), wc, padding=1)
+        y = F.layer_norm(xt, (1280,))
+        q = (y @ wq.t()).reshape(1024, 20, 64).transpose(0, 1)
+        a = torch.softmax(q @ q.transpose(1, 2) * 0.125, -1) @ q
+        y = y + a.transpose(0, 1).reshape(1024, 1280) @ wq.t()
+        u = F.layer_norm(y, (1280,)) @ w1.t()
+        y = y + (u[:, :5120] * F.gelu(u[:, 5120:])) @ w2.t()
+        return h.sum() + y.sum()
+    cand = sorted({t for t in (16, 32, 64, 128, threads_max) if t <= threads_max})
+    probe = {}
+    with torch.no_grad():
+        for nt in cand:
+            torch.set_num_threads(nt)
+            block()
+            t0 = time.perf_counter(); block(); block()
+            probe[nt] = (time.perf_counter() - t0) / 2
+    best = min(probe, key=probe.get)
+    return best, cand, {str(k): round(v, 4) for k, v in probe.items()}
+
+
+def cpu_baseline(sd_cpu, threads, x, ctx, pooled, tid, t, full_step=True, all_ctx=None, all_pooled=None):
     """Reference-equivalent CPU path: the fp32 oracle restatement of the reference UNet (oracle/unet.py, pinned
     against the unmodified reference) timed on the host cores of this box.  Bounded sample: ONE batch-1 SDXL
     UNet forward at 128x128 (the step is 7 such forwards + negligible elementwise work), on the SAME latents /
     prompt / timestep as one stream of the engine, so its output doubles as the full-architecture parity check."""
     from oracle.unet import SDXL_CONFIG, OracleUNet
-    # pick the thread count on a cheap proxy (one GEGLU-sized fp32 matmul): oversubscribed NUMA boxes are
-    # slower with every hardware thread than with a subset
     threads_max = threads
-    a, b = torch.randn(4096, 1280), torch.randn(1280, 10240)
-    best = (1e9, threads)
-    cand = sorted({t for t in (16, 32, 64, 96, 128, threads) if t <= threads})
-    for nt in cand:
-        torch.set_num_threads(nt)
-        a @ b
-        t0 = time.perf_counter(); a @ b; a @ b
-        best = min(best, (time.perf_counter() - t0, nt))
-    threads = best[1]
+    threads, cand, probe = pick_cpu_threads(threads)
     torch.set_num_threads(threads)
     o = OracleUNet(SDXL_CONFIG, sd_cpu)
     added = {"text_embeds": pooled, "time_ids": tid}
@@ -94,7 +115,7 @@ def cpu_baseline(sd_cpu, threads, x, ctx, pooled, tid, t, full_step=False, all_c
         ref = o.forward(x, t, ctx, added)
         dt = time.perf_counter() - t0
         if full_step:
-            # `--steps >= 50` (the default run): ONE FULL STEP = the 7 batch-1 forwards of a config-3 iteration (uncond, base, uncond_ref,
+            # ONE FULL STEP (whatever --steps says) = the 7 batch-1 forwards of a config-3 iteration (uncond, base, uncond_ref,
             # text_ref, 3 regions: prompts 0, R, 0, R, 1, 2, 3), timed as a whole instead of one forward x 7
             prompts = [0, all_ctx.shape[0] - 1, 0, all_ctx.shape[0] - 1, 1, 2, 3]
             t1 = time.perf_counter()
@@ -102,15 +123,94 @@ def cpu_baseline(sd_cpu, threads, x, ctx, pooled, tid, t, full_step=False, all_c
                 o.forward(x, t, all_ctx[pi:pi + 1], {"text_embeds": all_pooled[pi:pi + 1], "time_ids": tid})
             step_s = time.perf_counter() - t1
             return dict(value=1.0 / step_s, unit="steps/s", cores=threads, cores_physical=threads_max,
-                        cores_note=f"{threads} of {threads_max} physical cores (thread count picked by a matmul probe over {cand}: the fastest, so the baseline is not handicapped by oversubscription)",
+                        cores_note=f"{threads} of {threads_max} physical cores: the fastest of {cand} on one ResNet block + one transformer block of the oracle's operators (seconds per probe: {probe})",
                         kind="port", cpu=cpu_model_name(),
                         sample=f"1 full config-3 step = 7 batch-1 SDXL UNet forwards (fp32 oracle, {step_s:.1f} s; hooks / mask combine / Euler update are negligible beside them)",
                         forward_seconds=dt, step_seconds=step_s), ref
     return dict(value=1.0 / (7 * dt), unit="steps/s", cores=threads, cores_physical=threads_max,
-                cores_note=f"{threads} of {threads_max} physical cores (thread count picked by a matmul probe over {cand}: the fastest, so the baseline is not handicapped by oversubscription)",
+                cores_note=f"{threads} of {threads_max} physical cores: the fastest of {cand} on one ResNet block + one transformer block of the oracle's operators (seconds per probe: {probe})",
                 kind="port", cpu=cpu_model_name(),
                 sample=f"1 batch-1 SDXL UNet forward (fp32 oracle, {dt:.2f} s) x 7 forwards/step extrapolated",
                 forward_seconds=dt), ref
+
+
+def physical_cores():
+    threads = max(1, min(os.cpu_count() or 1, 256))
+    try:
+        phys = len({l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("core id")}) * \
+            len({l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("physical id")})
+        if phys > 0:
+            threads = min(threads, phys)
+    except Exception:
+        pass
+    return threads
+
+
+PIXEL_TOL = {"config1": (1.5e-2, 46.0, 8), "config2": (2.5e-2, 44.0, 12), "config3": (1.5e-2, 46.0, 8), "config5": (2.5e-2, 46.0, 8)}     # tests/test_fullschedule_gpu.py
+
+
+def pixel_parity(case):
+    """The engine over a FULL schedule against the committed trajectory of the fp32 CPU oracle (tests/golden/fullschedule/<case>.pt,
+    oracle/make_fullsize_golden.py): seeded weights regenerated here, the facade classes run the schedule, latents per recorded loop
+    iteration and the final uint8 image are compared (tools/fullschedule_check.py).  A checker leg, outside every timed region."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fullschedule_check as fc
+    if fc.load_golden(case) is None:
+        return {"error": f"tests/golden/fullschedule/{case}.pt missing"}
+    mdl, fp = fc.build_model(case)
+    try:
+        r = fc.compare(case, mdl, fp)
+    finally:
+        fc.close_model(mdl)
+    t_lat, t_psnr, t_max = PIXEL_TOL[case]
+    curve, pix = r["latent_rel_l2_by_iteration"], r["pixels_vs_oracle_image"]
+    c = r["case"]
+    return dict(case=case, schedule=f"{c['model']} latent {c['hw']}x{c['hw']}, R={c['R']}, {c['steps']} scheduler steps = {max(curve)} loop iterations, CFG {c['gs']}, "
+                                     f"inject_selfattn {c['isa']}, inject_background {c['ibg']}, colour guidance {c['guided']}",
+                latent_rel_l2_by_iteration={str(k): v for k, v in curve.items()}, latent_rel_l2_final=curve[max(curve)],
+                psnr_db=pix["psnr_db"], mean_abs_u8=pix["mean_abs"], max_abs_u8=pix["max_abs"], within_1_level=pix["within_1"],
+                decoder_only_psnr_db=r["decoder_only"]["psnr_db"],
+                tol=dict(latent_rel_l2=t_lat, psnr_db=t_psnr, max_abs_u8=t_max),
+                ok=bool(max(curve.values()) < t_lat and pix["psnr_db"] > t_psnr and pix["max_abs"] <= t_max),
+                reference="fp32 CPU oracle trajectory + oracle VAE decode (oracle/region_loop.py, pinned to the unmodified reference loops)")
+
+
+def cpu_baseline_other(config):
+    """One loop iteration of BASELINE configs 1 / 2 / 5 on the host cores through the fp32 oracle (bounded sample, stated)."""
+    from oracle.unet import SD15_CONFIG, SDXL_CONFIG, OracleUNet, random_state_dict
+    from oracle.vae import SD_VAE_CONFIG, SDXL_VAE_CONFIG, OracleVAEDecoder, color_guidance_update, random_vae_state_dict
+    threads_max = physical_cores()
+    threads, cand, probe = pick_cpu_threads(threads_max)
+    torch.set_num_threads(threads)
+    xl = config == 5
+    cfg, hw, F = (SDXL_CONFIG, 128, 7) if xl else (SD15_CONFIG, 64, 3 if config == 1 else 5)
+    o = OracleUNet(cfg, random_state_dict(cfg, seed=1))
+    g = torch.Generator().manual_seed(2)
+    x, ctx = torch.randn(1, 4, hw, hw, generator=g), torch.randn(1, 77, cfg["cross_attention_dim"], generator=g)
+    added = {"text_embeds": torch.randn(1, 1280, generator=g), "time_ids": torch.tensor([[8.0 * hw, 8.0 * hw, 0, 0, 8.0 * hw, 8.0 * hw]])} if xl else None
+    with torch.no_grad():
+        n_fwd = 1 if xl else F
+        t0 = time.perf_counter()
+        for _ in range(n_fwd):
+            o.forward(x, 501.0, ctx, added)
+        fwd_s = (time.perf_counter() - t0) / n_fwd
+    step_s, sample = F * fwd_s, f"{n_fwd} batch-1 UNet forward(s) of the fp32 oracle ({fwd_s:.2f} s each) x {F} forwards per iteration"
+    if config in (2, 5):
+        vcfg = SDXL_VAE_CONFIG if xl else SD_VAE_CONFIG
+        vh = 64                                                    # the guidance gradient is timed on a 64x64 latent (512x512 image) ...
+        vae = OracleVAEDecoder(vcfg, random_vae_state_dict(vcfg, seed=3))
+        lat, eps = torch.randn(1, 4, vh, vh, generator=g), torch.randn(1, 4, vh, vh, generator=g)
+        masks = [(torch.rand(1, 1, 8 * vh, 8 * vh, generator=g) ** 2).repeat(1, 4, 1, 1) for _ in range(2)]
+        rgb = [torch.rand(1, 3, 1, 1, generator=g)]
+        t0 = time.perf_counter()
+        color_guidance_update(vae, lat, eps, 0.37, vcfg["scaling_factor"], masks, rgb, 0.5, torch.rand(1, 4, vh, vh, generator=g))
+        vs = time.perf_counter() - t0
+        scale = (hw / vh) ** 2                                      # ... and scaled by the image area for the 1024x1024 case
+        step_s += vs * scale
+        sample += f" + 1 VAE decode + autograd gradient at {8 * vh}x{8 * vh} ({vs:.1f} s)" + (f" x {scale:.0f} (area) for {8 * hw}x{8 * hw}" if scale != 1 else "")
+    return dict(value=1.0 / step_s, unit="steps/s", cores=threads, cores_physical=threads_max, kind="port", cpu=cpu_model_name(),
+                cores_note=f"the fastest of {cand} on one ResNet block + one transformer block of the oracle's operators (seconds per probe: {probe})",
+                sample=sample, step_seconds=step_s)
 
 
 def cross_attention_block(dev, F=7):
@@ -194,9 +294,9 @@ def other_config(args):
             "finite": r["finite"],
             "roofline": {"bound": "mfma", "kernel": "whole step (UNet forwards + VAE guidance where configured)", "achieved": tf,
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_BF16_TFLOPS, "traffic": None},
-            "cpu_baseline": None,
-            # numerics of these workloads are pinned by the GPU tests, not inside this (timing-only) line
-            "parity": None,
+            "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline_other(args.config),
+            # the full schedule of the committed oracle trajectory of this configuration, latents and pixels (tests/test_fullschedule_gpu.py asserts the same)
+            "parity": None if args.no_cpu_baseline else pixel_parity({1: "config1", 2: "config2", 5: "config5"}[args.config]),
             "parity_tests": {1: "tests/test_fullsize_gpu.py::test_sd15_config1_rich_loop_matches_oracle (SD-v1.5 full architecture, PLMS loop vs the fp32 oracle)",
                              2: "tests/test_fullsize_gpu.py::test_sd15_full_architecture_stream_modes_match_oracle + test_full_width_vae_decode_and_guidance_gradient_match_oracle",
                              5: "tests/test_fullsize_gpu.py::test_sdxl_config3_rich_step_matches_oracle + test_full_width_vae_decode_and_guidance_gradient_match_oracle"}[args.config]}
@@ -414,24 +514,25 @@ def main():
     cpu = None
     parity = None
     if rank == 0 and not args.no_cpu_baseline and not args.roofline_only and sd_cpu is not None:
-        threads = max(1, min(os.cpu_count() or 1, 256))
-        try:
-            phys = len({l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("core id")}) * \
-                len({l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("physical id")})
-            if phys > 0:
-                threads = min(threads, phys)
-        except Exception:
-            pass
+        threads = physical_cores()
         # one engine stream on the oracle's inputs: prompt 0 (negative), t = 801, unscaled latents
         gp = torch.Generator().manual_seed(4242)
         px = torch.randn(1, 4, hw, hw, generator=gp)
         eng.set_fontsize(None, None)
         got = eng.unet_forward(px.to(dev), 801.0, [0]).cpu()
         cpu, ref = cpu_baseline(sd_cpu, threads, px, inp["emb"][:1].cpu(), inp["pooled"][:1].cpu(), inp["tid"], 801.0,
-                                full_step=args.steps >= 50, all_ctx=inp["emb"].cpu(), all_pooled=inp["pooled"].cpu())
+                                full_step=True, all_ctx=inp["emb"].cpu(), all_pooled=inp["pooled"].cpu())
         rel = float(((got - ref).pow(2).sum() / ref.pow(2).sum()).sqrt())
         parity = dict(rel_l2=rel, tol=PARITY_TOL, ok=bool(rel <= PARITY_TOL),
                       config="SDXL-base full architecture, 1 UNet forward (latent 128x128, t=801, negative-prompt stream) vs the fp32 CPU oracle")
+
+    # ---- the full schedule against the committed oracle trajectory, in latents and in pixels (config 3, 10 Euler steps)
+    pixels = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.roofline_only:
+        try:
+            pixels = pixel_parity("config3")
+        except Exception as ex:          # the headline line must still print
+            pixels = {"error": repr(ex)}
 
     # ---- the other half of an image and the secondary modes (N = 1, rank 0, outside every timed region; tools/end_to_end.py).
     # They re-program the engine (prompts, schedule, capture), so they come after everything that reads the headline state.
@@ -494,13 +595,15 @@ def main():
             "whole_step_mfma_frac": None if args.roofline_only else step_tflop / (dt / args.steps) / PEAK_BF16_TFLOPS,
             "executed_flops_per_step": step_flops, "nominal_tflop_per_step": 7 * SDXL_FWD_GFLOP / 1e3,
             "weight_broadcast_s": bcast_s, "weight_broadcast_calls": launcher.LAST_BROADCAST_CALLS, "finite": finite,
-            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "cross_attention_block": xblock, "elide_dead_forwards_timing": elided,
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "pixel_parity": pixels, "cross_attention_block": xblock, "elide_dead_forwards_timing": elided,
             "timed_schedule_indices": [sched_index(i, args.steps) for i in range(min(args.steps, nsched))],
         }
         line.update(extras)
         print(json.dumps(line), flush=True)
         if parity is not None and not parity["ok"]:
             sys.exit(f"bench: full-architecture parity FAILED: rel-L2 {parity['rel_l2']:.3e} > {PARITY_TOL}")
+        if pixels is not None and pixels.get("ok") is False:
+            sys.exit(f"bench: full-schedule pixel parity FAILED: {pixels}")
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE: full-SCHEDULE trajectories of the fp32 CPU oracle at the architectures BASELINE.json names.
 
-    python -m oracle.make_fullsize_golden config1 config3 config5 [config3_50]      # in the build container (CPU time is free there)
+    python -m oracle.make_fullsize_golden config1 config2 config3 config5 [config3_50]      # in the build container (CPU time is free there)
 
 writes tests/golden/fullschedule/<case>.pt = latents at a list of loop iterations + the final image (uint8, decoded by the
 oracle VAE as the reference decodes it: rd.py:227-236,267-271 / xl.py:916-944).  tests/test_fullschedule_gpu.py runs the HIP
@@ -39,6 +39,8 @@ CASES = {
     # name: model, latent size, regions, requested steps, CFG, inject_selfattn, inject_background, guided, checkpoints (1-based loop iterations)
     "config1": dict(model="sd15", hw=64, R=2, steps=20, gs=8.5, isa=0.0, ibg=0.0, guided=False, unet_seed=101, vae_seed=201, seed=301,
                     word_pos=[2], font_size=[3.0], checkpoints=[1, 2, 3, 6, 11, 16, 21]),
+    "config2": dict(model="sd15", hw=64, R=4, steps=10, gs=7.5, isa=0.0, ibg=0.0, guided=True, unet_seed=101, vae_seed=201, seed=302,
+                    word_pos=[2], font_size=[3.0], n_color=2, color_weight=20.0, checkpoints=[1, 2, 3, 6, 11]),
     "config3": dict(model="sdxl", hw=128, R=4, steps=10, gs=5.0, isa=0.5, ibg=0.0, guided=False, unet_seed=103, vae_seed=203, seed=303,
                     word_pos=[5, 6], font_size=[20.0, 20.0], checkpoints=[1, 2, 5, 6, 10]),
     "config3_50": dict(model="sdxl", hw=128, R=4, steps=50, gs=5.0, isa=0.5, ibg=0.0, guided=False, unet_seed=103, vae_seed=203, seed=303,

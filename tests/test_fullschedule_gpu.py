@@ -4,6 +4,7 @@ tests/golden/fullschedule/<case>.pt holds trajectories of the fp32 CPU oracle (o
 reference loops by tests/test_oracle_vs_reference.py), generated in the build container by `python -m oracle.make_fullsize_golden`:
 
   * config1     RegionDiffusion.produce_latents      rd.py:86-174,227-236    SD-v1.5 @ 512x512, R = 2, 20 steps = 21 PLMS iterations
+  * config2     the same loop + colour guidance        rd.py:151-168           SD-v1.5 @ 512x512, R = 4, 2 colour regions, 11 PLMS iterations
   * config3     RegionDiffusionXL.sample(rich)       xl.py:779-878,916-944   SDXL @ 1024x1024, R = 4, inject_selfattn 0.5, 10 Euler steps
   * config3_50  the same, the full 50-step schedule (the benched workload end to end)
   * config5     the same loop + colour guidance (xl.py:849-867) + background blend, CFG 7.5, 4 Euler steps @ 1024x1024
@@ -19,27 +20,24 @@ contributes.
 Stated tolerances: TOL below (latents: relative L2 at every checkpoint; pixels: PSNR, mean and max absolute difference in uint8 levels).
 """
 import json
-import math
 import os
+import sys
 
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 
-from oracle import make_fullsize_golden as mg  # noqa: E402
-from oracle.unet import SD15_CONFIG, SDXL_CONFIG  # noqa: E402
-from oracle.vae import SD_VAE_CONFIG, SDXL_VAE_CONFIG  # noqa: E402
-
-DEV = "cuda:0"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-GOLD = os.path.join(ROOT, "tests", "golden", "fullschedule")
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import fullschedule_check as fc  # noqa: E402
 
 # case: (max rel-L2 of the latents at ANY checkpoint, min PSNR [dB] of the final uint8 image, max mean-abs pixel difference, max-abs)
 # Measured on MI355X (profiles/r5_fullschedule_parity.json): config1 4.9e-3 / 53.3 dB / 0.30 / 3; config3 4.1e-3 / 56.2 dB / 0.16 / 2;
 # config5 8.2e-3 / 52.8 dB / 0.33 / 4 - the error of one forward (7e-3 at CFG 1) does not compound over the schedule.
 TOL = {
     "config1": (1.5e-2, 46.0, 1.0, 8),
+    "config2": (2.5e-2, 44.0, 1.5, 12),
     "config3": (1.5e-2, 46.0, 1.0, 8),
     "config3_50": (2.5e-2, 44.0, 1.5, 12),
     "config5": (2.5e-2, 46.0, 1.0, 8),
@@ -47,32 +45,16 @@ TOL = {
 RESULTS = {}
 
 
-def rel_l2(a, b):
-    a, b = a.float().cpu(), b.float().cpu()
-    return ((a - b).pow(2).sum() / b.pow(2).sum()).sqrt().item()
-
-
-def pixel_stats(got_u8, ref_u8):
-    d = (got_u8.to(torch.int16) - ref_u8.to(torch.int16)).abs().float()
-    mse = (d * d).mean().item()
-    return {"psnr_db": 10 * math.log10(255.0 ** 2 / max(mse, 1e-12)), "mean_abs": d.mean().item(), "max_abs": int(d.max()),
-            "within_1": (d <= 1).float().mean().item(), "within_2": (d <= 2).float().mean().item(), "within_8": (d <= 8).float().mean().item()}
-
-
-def load_golden(name):
-    path = os.path.join(GOLD, name + ".pt")
-    if not os.path.exists(path):
-        pytest.skip(f"{path} not generated (python -m oracle.make_fullsize_golden {name})")
-    return torch.load(path)
-
-
-def _report(name, curve, pix, pix_dec, gold):
-    RESULTS[name] = {"latent_rel_l2_by_iteration": curve, "pixels_vs_oracle_image": pix, "decoder_only": pix_dec,
-                     "oracle_seconds": gold["oracle_seconds"], "case": {k: v for k, v in gold["case"].items() if k != "checkpoints"}}
+def _check(name, mdl, fp):
+    if fc.load_golden(name) is None:
+        pytest.skip(f"tests/golden/fullschedule/{name}.pt not generated (python -m oracle.make_fullsize_golden {name})")
+    r = fc.compare(name, mdl, fp)
+    RESULTS[name] = r
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, "fullschedule_parity.json"), "w") as f:
         json.dump(RESULTS, f, indent=1)
+    curve, pix, pix_dec = r["latent_rel_l2_by_iteration"], r["pixels_vs_oracle_image"], r["decoder_only"]
     print(f"{name}: latent rel-L2 by loop iteration: " + ", ".join(f"{k}: {v:.3e}" for k, v in curve.items()))
     print(f"{name}: final image vs the oracle's image: PSNR {pix['psnr_db']:.2f} dB, mean |d| {pix['mean_abs']:.3f} / 255, max |d| {pix['max_abs']}, "
           f"within 1 / 2 / 8 levels {pix['within_1']:.4f} / {pix['within_2']:.4f} / {pix['within_8']:.4f}")
@@ -85,86 +67,33 @@ def _report(name, curve, pix, pix_dec, gold):
 
 @pytest.fixture(scope="module")
 def sdxl_model():
-    """RegionDiffusionXL on the seed-103 SDXL-base weights + the seed-203 SDXL VAE in the precise (fp32-class) mode the reference
-    decodes and guides in (xl.py:856,916-938)."""
-    from rich_text_to_image_amd.engine import VaeDecoder
-    from rich_text_to_image_amd.region_diffusion_sdxl import RegionDiffusionXL
-    usd, vsd = mg.unet_weights("config3"), mg.vae_weights("config3")
-    fp = (mg.weights_fingerprint(usd), mg.weights_fingerprint(vsd))
-    vae = VaeDecoder(SDXL_VAE_CONFIG, 128, 128, device=0, state_dict=vsd, precise=True)
-    mdl = RegionDiffusionXL(device=0, unet_state_dict=usd, config=SDXL_CONFIG, vae=vae, vae_scaling_factor=SDXL_VAE_CONFIG["scaling_factor"])
-    mdl.unet.engine(128, 128)                # packs the arena now ...
-    mdl.unet._state_dict = "empty"           # ... and lets go of 10 GB of fp32 host tensors
-    del usd
+    mdl, fp = fc.build_model("config3")
     yield mdl, fp
-    for e in mdl.unet._engines.values():
-        e.close()
-    vae.close()
+    fc.close_model(mdl)
 
 
-def _run_xl(name, mdl, fp):
-    gold = load_golden(name)
-    c = gold["case"]
-    assert (gold["unet_fingerprint"], gold["vae_fingerprint"]) == fp, "regenerated weights differ from the ones the golden file was made with"
-    inp = mg.case_inputs(name)
-    m = inp["masks"]
-    mdl.masks = [m[r:r + 1] for r in range(c["R"])]
-    got = {}
-    emb, pooled = inp["emb"], inp["pooled"]
-    out = mdl.sample(prompt=None, height=8 * c["hw"], width=8 * c["hw"], num_inference_steps=c["steps"], guidance_scale=c["gs"],
-                     latents=inp["latents"].clone(), prompt_embeds=emb[1:], negative_prompt_embeds=emb[:1], pooled_prompt_embeds=pooled[1:],
-                     negative_pooled_prompt_embeds=pooled[:1], output_type="np", run_rich_text=True, text_format_dict=inp["tfd"],
-                     use_guidance=c["guided"], inject_selfattn=c["isa"], inject_background=c["ibg"],
-                     callback=lambda i, t, lat: got.__setitem__(i + 1, lat.cpu()) if (i + 1) in gold["checkpoints"] else None)
-    image = torch.from_numpy(out.images[0])
-    curve = {k: rel_l2(got[k], v) for k, v in gold["checkpoints"].items()}
-    last = c["checkpoints"][-1]
-    dec = mdl.vae.decode(gold["checkpoints"][last].to(DEV) / SDXL_VAE_CONFIG["scaling_factor"])
-    _report(name, curve, pixel_stats(image, gold["image_u8"]), pixel_stats(mg.to_uint8(dec.float().cpu()), gold["image_u8"]), gold)
+@pytest.fixture(scope="module")
+def sd_model():
+    mdl, fp = fc.build_model("config1")
+    yield mdl, fp
+    fc.close_model(mdl)
 
 
 def test_config3_ten_step_schedule_latents_and_pixels(sdxl_model):
-    _run_xl("config3", *sdxl_model)
+    _check("config3", *sdxl_model)
 
 
 def test_config3_full_fifty_step_schedule_latents_and_pixels(sdxl_model):
-    _run_xl("config3_50", *sdxl_model)
+    _check("config3_50", *sdxl_model)
 
 
 def test_config5_guided_schedule_latents_and_pixels(sdxl_model):
-    _run_xl("config5", *sdxl_model)
+    _check("config5", *sdxl_model)
 
 
-def test_config1_full_plms_schedule_latents_and_pixels():
-    """BASELINE config 1 in full: the engine is driven exactly as RegionDiffusion.produce_latents drives it (region_diffusion.py of
-    this package), with the latents read back after the listed iterations; the final latents go through RegionDiffusion.latents_to_uint8."""
-    from rich_text_to_image_amd.engine import VaeDecoder
-    from rich_text_to_image_amd.region_diffusion import RegionDiffusion
-    name = "config1"
-    gold = load_golden(name)
-    c = gold["case"]
-    usd, vsd = mg.unet_weights(name), mg.vae_weights(name)
-    assert gold["unet_fingerprint"] == mg.weights_fingerprint(usd) and gold["vae_fingerprint"] == mg.weights_fingerprint(vsd)
-    inp = mg.case_inputs(name)
-    hw = c["hw"]
-    vae = VaeDecoder(SD_VAE_CONFIG, hw, hw, device=0, state_dict=vsd)        # single bf16 pass: rd.py:232 decodes in the checkpoint dtype under autocast
-    mdl = RegionDiffusion(0, unet_state_dict=usd, config=SD15_CONFIG, vae=vae)
-    m = inp["masks"]
-    mdl.masks = [m[r:r + 1] for r in range(c["R"])]
-    final = mdl.produce_latents(inp["emb"], num_inference_steps=c["steps"], guidance_scale=c["gs"], latents=inp["latents"].clone(), text_format_dict=inp["tfd"])
-    # the same loop once more, stopping at the checkpoints (produce_latents has no callback: rd.py:86 has none either)
-    eng = mdl.unet.engine(hw, hw)
-    eng.set_latents(inp["latents"].to(DEV))
-    got = {}
-    for i in range(len(mdl.scheduler.timesteps)):
-        eng.region_step(i, c["gs"], 0.0, 0.0, xl=False, elide=False)
-        if i + 1 in gold["checkpoints"]:
-            got[i + 1] = eng.read_latents(hw, hw).cpu()
-    assert torch.equal(got[c["checkpoints"][-1]], final.cpu())              # the run is deterministic
-    curve = {k: rel_l2(got[k], v) for k, v in gold["checkpoints"].items()}
-    image = torch.from_numpy(mdl.latents_to_uint8(final)[0])
-    dec = torch.from_numpy(mdl.latents_to_uint8(gold["checkpoints"][c["checkpoints"][-1]].to(DEV))[0])
-    for e in mdl.unet._engines.values():
-        e.close()
-    vae.close()
-    _report(name, curve, pixel_stats(image, gold["image_u8"]), pixel_stats(dec, gold["image_u8"]), gold)
+def test_config1_full_plms_schedule_latents_and_pixels(sd_model):
+    _check("config1", *sd_model)
+
+
+def test_config2_guided_plms_schedule_latents_and_pixels(sd_model):
+    _check("config2", *sd_model)
