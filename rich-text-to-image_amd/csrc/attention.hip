@@ -273,6 +273,11 @@ __global__ __launch_bounds__(NW * 64, (CROSS && DP <= 64) ? 3 : 1) void attn_ker
 
     l += __shfl_xor(l, 32);
     const float inv = 1.f / l;
+    if constexpr (!CROSS) {
+        // token-map capture (plain pass): P(q, k) = exp2(s - m) / l for every key of this head - the deferred rescale keeps m and l consistent
+        if (p.stats != nullptr && b == p.stats_b && hi == 0 && q < p.N)
+            ((float2*)p.stats)[(size_t)h * p.N + q] = make_float2(m, inv / (float)p.H);
+    }
     // Epilogue through LDS: in the accumulator layout a lane owns ONE query row and 4-element runs of d, so direct stores touch
     // 32 rows with 8 B each per instruction (store-issue-bound tail, guide T21).  Every wave transposes its 32 x DP tile in its
     // own slab of the (now idle) K/V buffers - the loop ended with a barrier - and writes whole 16-B chunks, 8 lanes per row.

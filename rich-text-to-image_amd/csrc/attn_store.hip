@@ -383,6 +383,9 @@ __global__ __launch_bounds__(256) void attn_store_apply_kernel(AttnStoreArgs p) 
     }
 }
 
+int g_store_own_stats = 0;    // debug bit 17: the store computes the statistics itself although the attention launch could leave them
+// would launch_attn_store run the statistics + apply pair for this map?  (the caller may then let the self-attention launch write the statistics)
+bool attn_store_takes_stats(int N, int NK, int DP);
 int g_store_legacy = 0;      // A/B timing (rt_op_gemm_debug): bit 0 (debug bit 5) the round-1 two-pass single-wave kernel for every shape; bit 1 (debug bit 6) no statistics + apply pair
 void launch_attn_store(const AttnStoreArgs& a, hipStream_t st) {
     RT_REQUIRE(a.NKpad % 32 == 0 && a.NK >= 1 && a.NK <= a.NKpad && a.NKrows >= 1 && a.H >= 1 && a.H <= 32, "attn_store: keys are padded to a multiple of 32; at most 32 heads");
@@ -390,9 +393,10 @@ void launch_attn_store(const AttnStoreArgs& a, hipStream_t st) {
         // large maps: statistics pass + key-split accumulation (see above)
         dim3 gs(cdiv(a.N, 64), a.H), ga(cdiv(a.N, 16), cdiv(a.NKpad, 128)), blk(256);
         switch (a.DP) {
-            case 32: hipLaunchKernelGGL(attn_store_stats_kernel<32>, gs, blk, 0, st, a); hipLaunchKernelGGL(attn_store_apply_kernel<32>, ga, blk, 0, st, a); break;
-            case 64: hipLaunchKernelGGL(attn_store_stats_kernel<64>, gs, blk, 0, st, a); hipLaunchKernelGGL(attn_store_apply_kernel<64>, ga, blk, 0, st, a); break;
-            case 96: hipLaunchKernelGGL(attn_store_stats_kernel<96>, gs, blk, 0, st, a); hipLaunchKernelGGL(attn_store_apply_kernel<96>, ga, blk, 0, st, a); break;
+            // stats_ready: the self-attention launch of this layer left the statistics (AttnArgs.stats): the statistics pass is skipped
+            case 32: if (!a.stats_ready) hipLaunchKernelGGL(attn_store_stats_kernel<32>, gs, blk, 0, st, a); hipLaunchKernelGGL(attn_store_apply_kernel<32>, ga, blk, 0, st, a); break;
+            case 64: if (!a.stats_ready) hipLaunchKernelGGL(attn_store_stats_kernel<64>, gs, blk, 0, st, a); hipLaunchKernelGGL(attn_store_apply_kernel<64>, ga, blk, 0, st, a); break;
+            case 96: if (!a.stats_ready) hipLaunchKernelGGL(attn_store_stats_kernel<96>, gs, blk, 0, st, a); hipLaunchKernelGGL(attn_store_apply_kernel<96>, ga, blk, 0, st, a); break;
             default: throw rt_error(RT_E_UNSUPPORTED, "attn_store: unsupported padded head dim");
         }
         HIP_CHECK(hipGetLastError());
@@ -430,4 +434,9 @@ void launch_attn_store(const AttnStoreArgs& a, hipStream_t st) {
     }
 #undef LAUNCH
     HIP_CHECK(hipGetLastError());
+}
+
+bool attn_store_takes_stats(int N, int NK, int DP) {
+    (void)N;
+    return !g_store_own_stats && NK >= 256 && NK <= 1024 && NK % 32 == 0 && (DP == 32 || DP == 64 || DP == 96) && !(g_store_legacy & 3);
 }

@@ -201,6 +201,10 @@ struct AttnArgs {
     int DP;                      // padded head dim (multiple of 32)
     int cross;
     int nqb;                     // set by launch_attention: 128-query blocks per (batch entry, head)
+    // self-attention only: when non-null, the kernel also leaves the softmax statistics of batch entry stats_b - (running reference m,
+    // 1 / (H * sum)) per (head, query), [H][N][2] fp32 - which is exactly what attn_store_apply_kernel needs to rebuild the
+    // head-averaged probabilities of that stream: the token-map capture of the plain pass then skips its own statistics pass
+    float* stats; int stats_b;
 };
 void launch_attention(const AttnArgs& a, hipStream_t st);
 void attention_set_prio(int on);   // s_setprio around the MFMA phases of attn_kernel (default on; rt_op_gemm_debug bit 14 clears it)
@@ -214,8 +218,11 @@ struct AttnStoreArgs {
     int overwrite;                             // 1: out = avg(P); 0: out += avg(P)
     float* stats;                              // optional scratch [H][N][2] fp32 (softmax max, 1 / (H sum) per (head, query)): enables the
                                                // statistics + key-split apply pair for maps of >= 256 keys; null: one-pass kernel
+    int stats_ready;                           // 1: `stats` already holds the statistics of this stream (written by the attention
+                                               // launch itself, AttnArgs.stats): only the apply kernel runs
 };
 void launch_attn_store(const AttnStoreArgs& a, hipStream_t st);
+bool attn_store_takes_stats(int N, int NK, int DP);   // the statistics + apply pair would run for this map: the self-attention launch may leave the statistics
 
 // ---------------------------------------------------------------- norms / elementwise
 struct GroupNormArgs {

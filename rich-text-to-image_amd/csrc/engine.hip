@@ -546,15 +546,20 @@ struct rt_engine {
                     AttnArgs a{}; a.Q = qk; a.ldq = 2 * HD; a.K = qk + HD; a.ldk = 2 * HD; a.VT = vt; a.ldvt = M; a.O = o; a.ldo = HD;
                     for (int b = 0; b < B; ++b) { a.q_src[b] = in.qk_src[b]; a.k_src[b] = in.qk_src[b]; a.v_src[b] = b; a.wset[b] = 0; }
                     a.B = B; a.H = t.heads; a.N = HW; a.NK = HW; a.nk_valid = HW; a.DP = t.DP; a.cross = 0;
+                    // a layer whose map is recorded in this call: the attention launch leaves the softmax statistics of the recorded stream,
+                    // so the store runs its apply kernel only (debug bit 17: the store computes them itself, round 4's two launches)
+                    const bool will_store = in.store_stream >= 0 && k.store_mode[0] && k.store_calls[0] + 1 > 10;      // n_maps[name] > 10 (rd.py:422, xl.py:988)
+                    const bool stats_from_attn = will_store && attn_store_takes_stats(HW, HW, t.DP) && in.qk_src[in.store_stream] == in.store_stream;
+                    if (stats_from_attn) { a.stats = store_stats; a.stats_b = in.store_stream; }
                     prof_begin(RT_PROF_ATTN_SELF, 4.0 * B * t.heads * (double)HW * HW * t.d);
                     launch_attention(a, stream);
                     prof_end();
-                    if (in.store_stream >= 0 && k.store_mode[0] && ++k.store_calls[0] > 10) {      // n_maps[name] > 10 (rd.py:422, xl.py:988)
+                    if (in.store_stream >= 0 && k.store_mode[0] && ++k.store_calls[0] > 10) {
                         RT_REQUIRE((size_t)HW * HW <= k.store_cap[0], "attention store: map larger than the enabled buffer");
                         AttnStoreArgs sa{}; sa.Q = qk; sa.ldq = 2 * HD; sa.q_row0 = (long)in.store_stream * HW;
                         sa.K = qk + HD; sa.ldk = 2 * HD; sa.k_row0 = (long)in.store_stream * HW;
                         sa.out = k.store[0]; sa.H = t.heads; sa.N = HW; sa.NK = HW; sa.NKpad = HW; sa.NKrows = HW; sa.DP = t.DP;
-                        sa.overwrite = k.store_mode[0] == 2; sa.stats = store_stats;
+                        sa.overwrite = k.store_mode[0] == 2; sa.stats = store_stats; sa.stats_ready = stats_from_attn ? 1 : 0;
                         prof_begin(RT_PROF_ATTN_STORE, 2.0 * 2.0 * t.heads * (double)HW * HW * t.d, 8.0 * HW * HW + 2.0 * 2.0 * HW * HD);
                         launch_attn_store(sa, stream);
                         prof_end();
@@ -1168,7 +1173,8 @@ static float* op_store_stats(size_t floats, hipStream_t st) {
 
 const char* rt_op_last_error(void) { return g_op_error.c_str(); }
 extern int g_store_legacy;
-int rt_op_gemm_debug(int d) { gemm_set_debug(d); g_store_legacy = ((d & 32) ? 1 : 0) | ((d & 64) ? 2 : 0); attention_set_prio(((d >> 14) & 1) ^ 1); return RT_OK; }
+extern int g_store_own_stats;
+int rt_op_gemm_debug(int d) { gemm_set_debug(d); g_store_own_stats = (d >> 17) & 1; g_store_legacy = ((d & 32) ? 1 : 0) | ((d & 64) ? 2 : 0); attention_set_prio(((d >> 14) & 1) ^ 1); return RT_OK; }
 int rt_op_gemm_force_config(int cfg) {
     if (cfg < -1 || cfg > 8) return RT_E_INVALID;
     gemm_force_config(cfg);
