@@ -9,6 +9,7 @@
 // probabilities), averages over heads in an LDS tile and adds the tile to an fp32 accumulator in HBM.
 // One wavefront owns 32 query rows: no atomics, deterministic.
 #include "common.h"
+#include <type_traits>
 #include <math.h>
 
 // Keys are processed in chunks of at most 1024 (the LDS tile is [32][chunk+1] fp32): pass 0 computes the softmax statistics
@@ -383,6 +384,96 @@ __global__ __launch_bounds__(256) void attn_store_apply_kernel(AttnStoreArgs p) 
     }
 }
 
+// ---------------------------------------------------------------------------------------------- round 5: apply kernel, K through LDS
+// attn_store_apply_kernel fetches every MFMA operand from global memory row-per-lane (a 16-query workgroup pulls 128 keys x H heads
+// through its vector L1: 25 us per 32x32 map, latency bound).  Here a workgroup owns 64 queries x 32 keys and walks the heads: the
+// head's K tile (32 keys x 64 d = 4 KB) arrives in LDS by ONE coalesced LDS-DMA piece per wave, two heads ahead (3 buffers, one
+// barrier per head); wave w owns queries 16 w .. + 15 for ALL heads, so the head sum stays in its registers (no cross-wave
+// reduction) and the order of the sum is h = 0, 1, 2, ... for every element.  d = 64 (DP = 64) only; other head dims keep the
+// round-4 kernel.
+#define AS2_MT 2                      // 16-key tiles per workgroup
+__global__ __launch_bounds__(256) void attn_store_apply2_kernel(AttnStoreArgs p) {
+    constexpr int DP = 64, MT = AS2_MT;
+    typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+    __shared__ __attribute__((aligned(16))) char kbuf[3][MT * 16 * 128];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, q4 = lane >> 4;
+    const int q0 = blockIdx.x * 64 + wave * 16, t0 = blockIdx.y * MT;
+    const int qrow = q0 + l15 < p.N ? q0 + l15 : p.N - 1;
+    const bf16_t* qbase = p.Q + ((size_t)p.q_row0 + qrow) * p.ldq + q4 * 8;
+    const float2* stat = (const float2*)p.stats + qrow;
+    // this wave's LDS-DMA piece of a head's K tile: rows 8 wave .. + 7 (MT * 16 = 32 rows = 4 pieces), 16-B slots XOR-swizzled
+    const int prow = wave * 8 + (lane >> 3), pslot = lane & 7;
+    int krow = t0 * 16 + prow; if (krow > p.NKrows - 1) krow = p.NKrows - 1;
+    const int kvoff = (int)(((size_t)krow * p.ldk + ((pslot ^ ((prow >> 1) & 7)) << 3)) * 2);
+    const bf16_t* kbase = p.K + (size_t)p.k_row0 * p.ldk;
+    bf16x8 qf[3][2];
+    float2 ms[3];
+    auto fetch = [&](int h, int slot) {
+        static_assert(MT == 2, "32 rows = one 8-row piece per wave");
+        glds16_buf(kbase, kvoff, h * DP * 2, kbuf[slot] + wave * 1024);
+        qf[slot][0] = *(const bf16x8*)(qbase + h * DP); qf[slot][1] = *(const bf16x8*)(qbase + h * DP + 32);
+        ms[slot] = stat[(size_t)h * p.N];
+    };
+    f32x4_t acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    fetch(0, 0);
+    if (p.H > 1) fetch(1, 1); else fetch(0, 1);
+    const int key = (l15 >> 1) & 7;
+    const int c0 = l15 * 128 + ((q4 ^ key) << 4), c1 = l15 * 128 + (((4 + q4) ^ key) << 4);
+    // three heads per trip: static buffer / register indices
+    auto head = [&](int h, auto slot_c) {
+        constexpr int SL = decltype(slot_c)::value;
+        // loads issued behind head h's: head h + 1's piece, 2 Q fragments and statistics pair
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                               // head h's tile landed; every wave left head h - 1's buffer ...
+        fetch(h + 2 < p.H ? h + 2 : p.H - 1, (SL + 2) % 3);        // ... which head h + 2 takes (beyond the last head: a harmless re-fetch keeps the cadence)
+        f32x4_t s[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            s[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(kbuf[SL] + i * 2048 + c0), qf[SL][0], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            s[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(kbuf[SL] + i * 2048 + c1), qf[SL][1], s[i], 0, 0, 0);
+        }
+        const float m = ms[SL].x, sc = ms[SL].y;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kk = (t0 + i) * 16 + 4 * q4 + r;
+                acc[i][r] += kk < p.NK ? __builtin_amdgcn_exp2f(s[i][r] - m) * sc : 0.f;
+            }
+    };
+    int h = 0;
+    for (; h + 3 <= p.H; h += 3) {
+        head(h, std::integral_constant<int, 0>{}); head(h + 1, std::integral_constant<int, 1>{}); head(h + 2, std::integral_constant<int, 2>{});
+    }
+    if (h < p.H) { head(h, std::integral_constant<int, 0>{}); ++h; }
+    if (h < p.H) { head(h, std::integral_constant<int, 1>{}); ++h; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the tail re-fetches: nothing may land in LDS after the workgroup left
+    if (q0 + l15 < p.N) {
+        float* orow = p.out + (size_t)(q0 + l15) * p.NK;
+        const bool vec = (p.NK & 3) == 0 && (((uintptr_t)p.out) & 15) == 0;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int kk = (t0 + i) * 16 + 4 * q4;
+            if (vec && kk + 4 <= p.NK) {
+                float4* d = (float4*)(orow + kk);
+                float4 o = p.overwrite ? make_float4(0.f, 0.f, 0.f, 0.f) : *d;
+                o.x += acc[i][0]; o.y += acc[i][1]; o.z += acc[i][2]; o.w += acc[i][3];
+                *d = o;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kk + r < p.NK) orow[kk + r] = p.overwrite ? acc[i][r] : orow[kk + r] + acc[i][r];
+            }
+        }
+    }
+}
+
+int g_store_apply_v1 = 0;     // debug bit 18: round 4's apply kernel for every head dim
 int g_store_own_stats = 0;    // debug bit 17: the store computes the statistics itself although the attention launch could leave them
 // would launch_attn_store run the statistics + apply pair for this map?  (the caller may then let the self-attention launch write the statistics)
 bool attn_store_takes_stats(int N, int NK, int DP);
@@ -395,7 +486,11 @@ void launch_attn_store(const AttnStoreArgs& a, hipStream_t st) {
         switch (a.DP) {
             // stats_ready: the self-attention launch of this layer left the statistics (AttnArgs.stats): the statistics pass is skipped
             case 32: if (!a.stats_ready) hipLaunchKernelGGL(attn_store_stats_kernel<32>, gs, blk, 0, st, a); hipLaunchKernelGGL(attn_store_apply_kernel<32>, ga, blk, 0, st, a); break;
-            case 64: if (!a.stats_ready) hipLaunchKernelGGL(attn_store_stats_kernel<64>, gs, blk, 0, st, a); hipLaunchKernelGGL(attn_store_apply_kernel<64>, ga, blk, 0, st, a); break;
+            case 64:
+                if (!a.stats_ready) hipLaunchKernelGGL(attn_store_stats_kernel<64>, gs, blk, 0, st, a);
+                if (!g_store_apply_v1 && (long)a.NKrows * a.ldk * 2 < 0x7fffffffL) hipLaunchKernelGGL(attn_store_apply2_kernel, dim3(cdiv(a.N, 64), cdiv(a.NKpad, 16 * AS2_MT)), blk, 0, st, a);
+                else hipLaunchKernelGGL(attn_store_apply_kernel<64>, ga, blk, 0, st, a);
+                break;
             case 96: if (!a.stats_ready) hipLaunchKernelGGL(attn_store_stats_kernel<96>, gs, blk, 0, st, a); hipLaunchKernelGGL(attn_store_apply_kernel<96>, ga, blk, 0, st, a); break;
             default: throw rt_error(RT_E_UNSUPPORTED, "attn_store: unsupported padded head dim");
         }
