@@ -253,14 +253,20 @@ def cross_attention_block(dev, F=7):
             return e0.elapsed_time(e1) / 20
         flags = int(os.environ.get("RTDIFF_DEBUG_FLAGS", "0"))
         ms = timed()                                  # the engine's form for this shape
-        lib.rt_op_gemm_debug(flags | 16)              # same operator as to_q GEMM -> attention launch -> to_out GEMM (round 3's form)
+        lib.rt_op_gemm_debug(flags | 16 | 524288)     # same operator as to_q GEMM -> attn_kernel<CROSS> launch -> to_out GEMM (round 3's form)
         try:
             ms3 = timed()
         finally:
             lib.rt_op_gemm_debug(flags)
+        lib.rt_op_gemm_debug(flags | 524288)          # round 4's form: to_q + attention fused (gemm16 EPI_XATTN) where the tiling allowed it
+        try:
+            ms4 = timed()
+        finally:
+            lib.rt_op_gemm_debug(flags)
         flops = F * (4.0 * N * Cc * H * DP + 4.0 * H * N * 77 * 64)
         out[name] = dict(ms=ms, tflops=flops / (ms * 1e-3) / 1e12, frac=flops / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
-                         three_launch_ms=ms3, three_launch_frac=flops / (ms3 * 1e-3) / 1e12 / PEAK_BF16_TFLOPS)
+                         three_launch_ms=ms3, three_launch_frac=flops / (ms3 * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+                         round4_form_ms=ms4, round4_form_frac=flops / (ms4 * 1e-3) / 1e12 / PEAK_BF16_TFLOPS)
         if Cc == 640:                                 # the one-launch register-chained form (xblock.hip; opt-in, NOT the engine's path: slower)
             lib.rt_op_gemm_debug(flags | 65536)
             try:
@@ -269,10 +275,11 @@ def cross_attention_block(dev, F=7):
                 lib.rt_op_gemm_debug(flags)
             out[name].update(one_launch_xblock_ms=ms1, one_launch_xblock_frac=flops / (ms1 * 1e-3) / 1e12 / PEAK_BF16_TFLOPS)
     out["note"] = ("rt_op_cross_attn_block: to_q + attention(77 keys, cached K/V, font-size softmax) + to_out(+bias, + fp16 trunk residual) "
-                   "for the 7 streams of a step, exactly the launches the engine issues - to_q and the attention as one kernel where the tiling "
-                   "allows it (gemm16.hip EPI_XATTN, the Q tile stays in LDS: shape B) + the to_out GEMM; one_launch_xblock_* (shape A) = the whole "
+                   "for the 7 streams of a step, exactly the launches the engine issues - round 5: to_q GEMM, cross77_kernel (xblock.hip: the 77-key "
+                   "attention with K / V^T in LDS, 64 queries x 2 heads per workgroup), to_out GEMM; round4_form_* = to_q and the attention as one "
+                   "kernel where the tiling allowed it (gemm16.hip EPI_XATTN, shape B); one_launch_xblock_* (shape A) = the whole "
                    "block as ONE launch with Q / P / O in registers (xblock.hip, round 5): built, parity-tested, slower, not the engine's path; "
-                   "three_launch_* = the same operator as three launches; executed FLOPs")
+                   "three_launch_* = to_q GEMM, the generic attn_kernel<CROSS>, to_out GEMM (round 3); executed FLOPs")
     return out
 
 

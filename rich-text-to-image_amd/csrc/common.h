@@ -207,6 +207,10 @@ struct AttnArgs {
     float* stats; int stats_b;
 };
 void launch_attention(const AttnArgs& a, hipStream_t st);
+// xblock.hip: the 77-key cross-attention as its own kernel (d = 64, cached K / V^T): 64 queries x 2 heads per workgroup, K / V^T in LDS
+bool cross77_supported(int H, int DP, int tokens, int NK, int nk_valid);
+void launch_cross77(const AttnArgs& a, hipStream_t st);
+bool gemm_cross77_enabled();      // debug bit 19 clear
 void attention_set_prio(int on);   // s_setprio around the MFMA phases of attn_kernel (default on; rt_op_gemm_debug bit 14 clears it)
 
 // head-averaged probabilities of one stream, accumulated over calls (token-map producer)

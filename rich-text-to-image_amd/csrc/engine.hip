@@ -573,7 +573,10 @@ struct rt_engine {
                 // allows it - a pure function of the layer's shape; the token-map capture of the plain pass reads Q from HBM and
                 // keeps the two-launch form for the layers it records
                 const bool capture2 = in.store_stream >= 0 && k.store_mode[1];
-                const bool fused2 = gemm_xattn_enabled() && xattn_fused_supported(C, t.heads, t.DP, HW) && !capture2;
+                // round 5: the 77-key attention on its own kernel (cross77_kernel, xblock.hip: 64 queries x 2 heads per workgroup, K / V^T in
+                // LDS) behind the plain to_q GEMM is faster than the fused launch of round 4 and serves the capturing layers too (Q is in HBM)
+                const bool c77 = gemm_cross77_enabled() && cross77_supported(t.heads, t.DP, HW, 96, 77) && t.d == 64;
+                const bool fused2 = !c77 && gemm_xattn_enabled() && xattn_fused_supported(C, t.heads, t.DP, HW) && !capture2;
                 // the 640-channel level: to_q, attention AND to_out + residual as one launch with Q / P / O in registers (xblock.hip)
                 const bool block2 = gemm_xblock_enabled() && xblock_supported(C, t.heads, t.DP, HW) && t.d == 64 && !capture2;
                 if (block2) {
@@ -608,7 +611,7 @@ struct rt_engine {
                     a.wabs = wabs; a.wsgn = wsgn;
                     a.B = B; a.H = t.heads; a.N = HW; a.NK = 96; a.nk_valid = 77; a.DP = t.DP; a.cross = 1;
                     prof_begin(RT_PROF_ATTN_CROSS, 4.0 * B * t.heads * (double)HW * 77 * t.d);
-                    launch_attention(a, stream);
+                    if (c77) launch_cross77(a, stream); else launch_attention(a, stream);
                     prof_end();
                     if (in.store_stream >= 0 && k.store_mode[1] && ++k.store_calls[1] > 10) {
                         RT_REQUIRE((size_t)HW * 77 <= k.store_cap[1], "attention store: map larger than the enabled buffer");
@@ -1202,7 +1205,10 @@ int rt_op_attention(const void* Q, int ldq, const void* K, int ldk, const void* 
         a.O = (bf16_t*)O; a.ldo = ldo; a.wabs = wabs; a.wsgn = wsgn;
         for (int b = 0; b < B; ++b) { a.q_src[b] = q_src ? q_src[b] : b; a.k_src[b] = k_src ? k_src[b] : b; a.v_src[b] = v_src ? v_src[b] : b; a.wset[b] = wset ? wset[b] : 0; }
         a.B = B; a.H = H; a.N = N; a.NK = NK; a.nk_valid = nk_valid; a.DP = DP; a.cross = cross;
-        launch_attention(a, (hipStream_t)stream);
+        bool same_kv = true;
+        for (int b = 0; b < B; ++b) same_kv = same_kv && a.k_src[b] == a.v_src[b];
+        if (cross && same_kv && gemm_cross77_enabled() && cross77_supported(H, DP, N, NK, nk_valid)) launch_cross77(a, (hipStream_t)stream);     // the engine's kernel for these shapes
+        else launch_attention(a, (hipStream_t)stream);
     })
 }
 // The shape rule of csrc/gemm16.hip as a host-only query (no device needed): which tile variant a problem takes (-1: stays on gemm.hip /
@@ -1286,8 +1292,9 @@ int rt_op_cross_attn_block(const void* x, const void* wq, const void* wo, const 
             launch_xblock(xa, st);
             return RT_OK;
         }
-        if (gemm_xattn_enabled() && xattn_fused_supported(C, H, DP, N)) {
-            // the engine's path for these shapes: to_q + attention in one launch (Q stays in LDS; q_scratch is not written)
+        const bool c77 = gemm_cross77_enabled() && cross77_supported(H, DP, N, 96, 77);
+        if (!c77 && gemm_xattn_enabled() && xattn_fused_supported(C, H, DP, N)) {
+            // round 4's path for these shapes: to_q + attention in one launch (Q stays in LDS; q_scratch is not written)
             GemmArgs g{}; g.A = (const bf16_t*)x; g.W = (const bf16_t*)wq; g.out = o_scratch; g.zero = op_zero_page(); g.mode = A_DENSE; g.epi = EPI_XATTN;
             g.M = M; g.N = HD; g.K = C; g.lda = C; g.ldw = C; g.ldo = HD; g.rows_per_stream = N;
             g.xa_k = (const bf16_t*)kcache; g.xa_vt = (const bf16_t*)vtcache; g.xa_ldk = HD; g.xa_ldvt = ldvt; g.xa_tokens = N; g.xa_nk_valid = 77;
@@ -1302,7 +1309,7 @@ int rt_op_cross_attn_block(const void* x, const void* wq, const void* wo, const 
         a.O = (bf16_t*)o_scratch; a.ldo = HD; a.wabs = wabs; a.wsgn = wsgn;
         for (int b = 0; b < B; ++b) { a.q_src[b] = b; a.k_src[b] = prompt_host ? prompt_host[b] : 0; a.v_src[b] = a.k_src[b]; a.wset[b] = wset_host ? wset_host[b] : 0; }
         a.B = B; a.H = H; a.N = N; a.NK = 96; a.nk_valid = 77; a.DP = DP; a.cross = 1;
-        launch_attention(a, st);
+        if (c77) launch_cross77(a, st); else launch_attention(a, st);
         }
         GemmArgs o{}; o.A = (const bf16_t*)o_scratch; o.W = (const bf16_t*)wo; o.bias = bo; o.out = trunk_out; o.res = trunk_in; o.zero = op_zero_page();
         o.mode = A_DENSE; o.epi = EPI_F16; o.M = M; o.N = C; o.K = HD; o.lda = HD; o.ldw = HD; o.ldo = C; o.ldres = C; o.rows_per_stream = N;

@@ -1232,6 +1232,7 @@ static int g_conv16 = 1;
 static int g_xattn = 1;
 static int g_no_triple = 0;
 static int g_pair = 1;
+static int g_cross77 = 1;
 static int g_xblock = 0;      // measured slower than the separate launches (LABNOTES R5.2): opt-in
 #ifdef RT_PROBE
 int g_conv3p_tn = 0;          // probe override of the patch kernel's column-tile count
@@ -1243,9 +1244,11 @@ void gemm_set_debug(int flags) {
     g_conv_patch = (flags & 1) ? 0 : 1; g_use16 = (flags & 2) ? 0 : 1; g_splitk = (flags & 4) ? 0 : 1; g_conv16 = (flags & 8) ? 0 : 1;
     g_xattn = (flags & 16) ? 0 : 1;
     g_xblock = (flags & 65536) ? 1 : 0;                               // bit 16: the 640-channel cross-attention block as xblock.hip's ONE launch (opt-in: measured slower, LABNOTES R5.2)
+    g_cross77 = (flags & 524288) ? 0 : 1;                             // bit 19: cross-attention on the round-4 kernels (EPI_XATTN / attn_kernel<CROSS>) instead of cross77_kernel
     g_pair = (flags & 8192) ? 0 : 1;                                  // bit 13: attn1's Q|K and V^T projections as two launches instead of one grouped launch
     g_no_triple = ((flags & 128) ? 1 : 0) | ((flags & 256) ? 2 : 0) | ((flags & 512) ? 4 : 0) | ((flags & 32768) ? 8 : 0);   // bit 15: dense hi / lo contractions as three launches   // (bits 8 / 9: only the gemm16 / only the patch-kernel route)              // bit 7: the precise VAE's contractions as three launches (round 3) instead of one
 }
+bool gemm_cross77_enabled() { return g_cross77 != 0; }
 bool gemm_xblock_enabled() { return g_xblock != 0 && g_use16 != 0 && g_force_cfg < 0; }
 bool gemm_xattn_enabled() { return g_xattn != 0 && g_use16 != 0 && g_force_cfg < 0; }
 

@@ -62,10 +62,14 @@ static __device__ __forceinline__ bf16x8 xb_pack8(const f32x4& a0, const f32x4& 
     return pk.v;
 }
 
-// v_max without the canonicalising self-max that fmaxf's NaN semantics drag in (scores are finite or -inf); row reductions over the
-// four 16-lane groups by gfx950's v_permlane16_swap / v_permlane32_swap (VALU) instead of two ds_bpermute round trips
-static __device__ __forceinline__ float xb_max(float a, float b) { float d; asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-static __device__ __forceinline__ float xb_max3(float a, float b, float c) { float d; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+// Row reductions over the four 16-lane groups by gfx950's v_permlane16_swap / v_permlane32_swap (VALU) instead of two ds_bpermute
+// round trips.  The maxima are plain fmaxf: this file is compiled with -fno-honor-nans (scores are finite or -inf), which drops the
+// canonicalising self-max fmaxf's NaN semantics drag in.  (An inline-asm v_max3_f32 is NOT an option: hipcc's hazard recogniser does not
+// see the registers an asm statement reads, so the wait states between an MFMA and a VALU read of its result were missing and the
+// maxima were taken over stale registers - harmless for the mathematics, any reference works, but the last bits differed from run to
+// run, which the determinism tests caught.)
+static __device__ __forceinline__ float xb_max(float a, float b) { return fmaxf(a, b); }
+static __device__ __forceinline__ float xb_max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 static __device__ __forceinline__ float xb_rowmax(float v) {
     const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     v = xb_max(__uint_as_float(r[0]), __uint_as_float(r[1]));
@@ -373,6 +377,136 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     XB_T(7)
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------- cross77_kernel: stand-alone 77-key cross-attention
+// O = softmax_fs(Q K[prompt]^T) V[prompt] for the cached cross-attention keys (models/attention_processor.py:476-545, font-size softmax
+// :386-401) - the attention unit of xblock_kernel above with Q read from and O written to HBM.  The generic attn_kernel (attention.hip)
+// runs this shape as a one-tile flash loop: 19.6 us for 7 x 1024 tokens x 20 heads, 28 us at 4096 tokens x 10 heads - 2.6 TB/s of its
+// Q + O bytes.  Here a workgroup owns 64 queries x 2 heads; K / V^T of the two heads (80 staged keys, 44 KB) arrive in LDS by
+// coalesced LDS-DMA once, three workgroups share a CU (12 waves hide each other's fragment and softmax latency), every wave runs its 16
+// queries against both heads: S^T = K Q^T (Q rows straight from HBM as the B operand), masked / font-size-biased scores, P^T from the
+// accumulators, O^T = V^T P^T with the V^T rows staged in the pi order, so a lane ends with 8 CONSECUTIVE d of its query per pair of
+// accumulator tiles = one 16-B store.
+#define C77_LDS (2 * XB_KVH + 768)
+__global__ __launch_bounds__(256, 3) void cross77_kernel(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, q4 = lane >> 4;
+    const int nhg = p.H >> 1;                                        // head pairs
+    // (head pair, stream, query block) order, contiguous per XCD: the query blocks of one (stream, head pair) share K / V^T in one L2
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, qq = nwg >> 3, rr = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+    }
+    const int nqb = p.N >> 6;
+    const int qb = bid % nqb; bid /= nqb;
+    const int b = bid % p.B, hg = bid / p.B;
+    const int prompt = p.k_src[b], wset = p.wset[b];
+    const bool fs = wset >= 0;
+    float tw = 1.f, tsg = 1.f;
+    if (fs && tid < 96) { tw = p.wabs[wset * p.NK + tid]; tsg = p.wsgn[wset * p.NK + tid]; }
+    // ---- K / V^T of heads 2 hg, 2 hg + 1: 44 pieces of 1 KB, 11 per wave (layout of xblock_kernel's K / V^T tiles)
+    const int lrow = lane >> 3, pslot = lane & 7;
+    const int voff_v = xb_pi(lane) * p.ldvt * 2;
+#pragma unroll
+    for (int i = 0; i < 11; ++i) {
+        const int pidx = i * 4 + wave;
+        const int h2 = pidx >= 22 ? 1 : 0, pp = pidx - 22 * h2;
+        const int head = hg * 2 + h2;
+        char* dst = smem + h2 * XB_KVH + pp * 1024;
+        if (pp < 10) {
+            const int rho = pp * 8 + lrow, j = rho >> 4, i16 = rho & 15;
+            const int key = j < 4 ? 32 * (j >> 1) + 8 * (i16 >> 2) + 4 * (j & 1) + (i16 & 3) : 64 + i16;
+            glds16_buf(p.K, (key * p.ldk + ((pslot ^ ((rho >> 1) & 7)) << 3)) * 2, (prompt * p.NK * p.ldk + head * 64) * 2, dst);
+        } else {
+            const int cc = pp - 10, keyoff = cc < 8 ? 8 * cc : 64 + 4 * (cc - 8);
+            glds16_buf(p.VT, voff_v, (head * 64 * p.ldvt + prompt * p.NK + keyoff) * 2, dst);
+        }
+    }
+    // ---- Q fragments of this wave's 16 queries, both heads: d = 32 ks + 8 q4 .. + 7
+    const size_t qrow = (size_t)p.q_src[b] * p.N + qb * 64 + wave * 16 + l15;
+    const bf16_t* qp = p.Q + qrow * p.ldq + hg * 128 + 8 * q4;
+    bf16x8 qf[2][2];
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) { qf[h2][0] = *(const bf16x8*)(qp + h2 * 64); qf[h2][1] = *(const bf16x8*)(qp + h2 * 64 + 32); }
+    float* tabw = (float*)(smem + 2 * XB_KVH);
+    if (tid < 96) {
+        tabw[tid] = tid < p.nk_valid ? __builtin_amdgcn_logf(tw) : -INFINITY;          // v_log_f32 = log2; log2(0) = -inf
+        tabw[96 + tid] = tsg;
+    }
+    // hipcc's waitcnt pass orders LDS *stores* behind a pending LDS-DMA, not LDS reads, and __syncthreads() does not wait for VMEM loads:
+    // every wave must see its own pieces landed BEFORE the barrier (without this wait the kernel raced: 5e-3 run-to-run differences)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const float* tab = tabw;
+    const int key = (l15 >> 1) & 7;
+    const int c0 = ((q4 ^ key) << 4), c1 = (((4 + q4) ^ key) << 4);
+    bf16_t* orow = p.O + ((size_t)b * p.N + qb * 64 + wave * 16 + l15) * p.ldo + hg * 128 + 8 * q4;
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+        const char* kp = smem + h2 * XB_KVH + l15 * 128;
+        const char* vp = smem + h2 * XB_KVH + 10240 + (q4 * 64 + l15) * 16;
+        f32x4 s[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const f32x4 bias = *(const f32x4*)(tab + (j < 4 ? 32 * (j >> 1) + 8 * q4 + 4 * (j & 1) : 64 + 4 * q4));
+            s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(kp + j * 2048 + c0), qf[h2][0], bias, 0, 0, 0);
+            s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(kp + j * 2048 + c1), qf[h2][1], s[j], 0, 0, 0);
+        }
+        float mx = xb_max3(s[0][0], s[0][1], s[0][2]);
+        mx = xb_max3(mx, s[0][3], s[1][0]);
+        mx = xb_max3(mx, s[1][1], s[1][2]);
+#pragma unroll
+        for (int j = 2; j < 5; ++j) { mx = xb_max3(mx, s[j - 1][3], s[j][0]); mx = xb_max3(mx, s[j][1], s[j][2]); }
+        mx = xb_rowmax(xb_max(mx, s[4][3]));
+        f32x2 sum2 = {0.f, 0.f};
+        const f32x2 nmx = {-mx, -mx};
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const f32x2 d0 = f32x2{s[j][0], s[j][1]} + nmx, d1 = f32x2{s[j][2], s[j][3]} + nmx;          // Q carries d^-1/2 log2 e
+            s[j][0] = __builtin_amdgcn_exp2f(d0.x); s[j][1] = __builtin_amdgcn_exp2f(d0.y);
+            s[j][2] = __builtin_amdgcn_exp2f(d1.x); s[j][3] = __builtin_amdgcn_exp2f(d1.y);
+            sum2 += f32x2{s[j][0], s[j][1]} + f32x2{s[j][2], s[j][3]};
+        }
+        const float inv = 1.f / xb_rowsum(sum2.x + sum2.y);
+        if (fs) {                                                    // sign of a negative font size on the normalised probability
+#pragma unroll
+            for (int j = 0; j < 5; ++j) s[j] = s[j] * *(const f32x4*)(tab + 96 + (j < 4 ? 32 * (j >> 1) + 8 * q4 + 4 * (j & 1) : 64 + 4 * q4));
+        }
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < 3; ++st) {
+            const bf16x8 pf = xb_pack8(s[2 * st], st < 2 ? s[2 * st + 1] : zero4);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(vp + st * 4096 + dt * 256), pf, o[dt], 0, 0, 0);
+        }
+        // accumulator tiles (2 s2, 2 s2 + 1) of lane (l15, q4): d = 32 s2 + 8 q4 + [0, 8) of query l15
+        *(bf16x8*)(orow + h2 * 64) = xb_pack8(o[0] * inv, o[1] * inv);
+        *(bf16x8*)(orow + h2 * 64 + 32) = xb_pack8(o[2] * inv, o[3] * inv);
+    }
+}
+
+bool cross77_supported(int H, int DP, int tokens, int NK, int nk_valid) {
+    return DP == 64 && H % 2 == 0 && tokens % 64 == 0 && NK == 96 && nk_valid >= 1 && nk_valid <= 80;
+}
+
+void launch_cross77(const AttnArgs& a, hipStream_t st) {
+    RT_REQUIRE(a.cross && cross77_supported(a.H, a.DP, a.N, a.NK, a.nk_valid), "cross77: shape");
+    RT_REQUIRE(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldvt % 8 == 0 && a.ldo % 8 == 0, "cross77: leading dimensions");
+    RT_REQUIRE((long)RT_MAXB * a.NK * a.ldk * 2 < 0x7fffffffL && (long)a.H * 64 * a.ldvt * 2 < 0x7fffffffL, "cross77: K / V^T cache beyond the 2 GiB descriptor range");
+    for (int b = 0; b < a.B; ++b) RT_REQUIRE(a.wset[b] < 0 || (a.wabs && a.wsgn), "cross77: multiplier tables");
+    for (int b = 0; b < a.B; ++b) RT_REQUIRE(a.k_src[b] == a.v_src[b], "cross77: K and V of one prompt");
+    static bool attr = false;
+    if (!attr) { HIP_CHECK(hipFuncSetAttribute((const void*)cross77_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C77_LDS)); attr = true; }
+    hipLaunchKernelGGL(cross77_kernel, dim3((a.N / 64) * a.B * (a.H / 2)), dim3(256), C77_LDS, st, a);
+    HIP_CHECK(hipGetLastError());
 }
 
 bool xblock_supported(int C, int H, int DP, int tokens) {

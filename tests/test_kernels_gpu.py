@@ -502,6 +502,47 @@ def test_cross_attention_fontsize(use_fs):
         report(f"cross_attn stream {b} fs={wset[b]}", out.float().reshape(B, N, -1)[b], ref[0], atol=1.5e-2, rtol=1.5e-2)
 
 
+@pytest.mark.parametrize("B,H,N", [(3, 4, 256), (7, 20, 1024), (2, 10, 4096)])
+def test_cross77_kernel_against_reference_arithmetic_and_the_generic_kernel(B, H, N):
+    """cross77_kernel (csrc/xblock.hip: what the engine runs for attn2 at d = 64 - 64 queries x 2 heads per workgroup, K / V^T of the
+    cached 77 keys in LDS, key mask and |font size| as an additive log2 bias on the scores) through rt_op_attention: against the
+    reference processor's arithmetic in fp32 (attention_processor.py:476-545, font-size softmax :386-401) with a NEGATIVE size, a ZERO
+    size, the last valid key (76) and junk in the padded V rows, streams mixing prompts and plain / font-size softmax - and against
+    the generic attn_kernel<CROSS> on the same inputs (debug bit 19)."""
+    from rich_text_to_image_amd.engine import load_library
+    lib = load_library()
+    d = DP = 64
+    P = 3
+    q = rnd(B, N, H * d, seed=60) * 3.0                                       # scores of a few units: a peaked softmax
+    kc, vc = rnd(P, 77, H * d, seed=61), rnd(P, 77, H * d, seed=62)
+    qs = d ** -0.5 * math.log2(math.e)
+    Q = _pack_heads(q.reshape(B * N, -1), H, d, DP, qs)
+    Kp = torch.zeros(P, 96, H * d); Kp[:, :77] = kc
+    Vp = torch.full((P, 96, H * d), 7.0); Vp[:, :77] = vc                      # padded keys carry junk values: they must be masked, not multiplied by ~0
+    K = _pack_heads(Kp.reshape(P * 96, -1), H, d, DP)
+    V = _pack_heads(Vp.reshape(P * 96, -1), H, d, DP)
+    wp, fs = torch.tensor([2, 9, 30, 64, 70, 76]), torch.tensor([3.0, -1.5, 0.25, 0.0, -2.0, 20.0])
+    wabs = torch.zeros(2, 96); wabs[:, :77] = 1.0
+    wsgn = torch.ones(2, 96)
+    wabs[1, wp] = fs.abs(); wsgn[1, wp] = fs.sign()
+    prompt = [(2 * b + 1) % P for b in range(B)]
+    wset = [1 if b % 3 == 1 else -1 for b in range(B)]
+    kw = dict(q_src=list(range(B)), k_src=prompt, v_src=prompt, cross=True, wabs=wabs.to(DEV), wsgn=wsgn.to(DEV), wset=wset, nk_valid=77)
+    out = attention(Q, K, V.t().contiguous(), B, H, N, 96, DP, **kw)
+    lib.rt_op_gemm_debug(524288)
+    try:
+        generic = attention(Q, K, V.t().contiguous(), B, H, N, 96, DP, **kw)
+    finally:
+        lib.rt_op_gemm_debug(0)
+    assert torch.isfinite(out.float()).all()
+    qr = Q.float().reshape(B, N, -1) / qs
+    kr, vr = K.float().reshape(P, 96, -1)[:, :77], V.float().reshape(P, 96, -1)[:, :77]
+    for b in range(min(B, 4)):
+        ref, _ = _ref_attention(qr[b:b + 1], kr[prompt[b]][None], vr[prompt[b]][None], H, (wp, fs) if wset[b] >= 0 else None)
+        report(f"cross77 B{B} H{H} N{N} stream {b} fs={wset[b]}", out.float().reshape(B, N, -1)[b], ref[0], atol=2e-2, rtol=2e-2)
+    report("cross77 vs attn_kernel<CROSS>", out.float(), generic.float(), atol=2e-2, rtol=2e-2)
+
+
 def test_cross_attention_plain_path_equals_the_tables_of_ones():
     """wset[b] < 0 selects plain softmax over the nk_valid keys without multiplier tables (attention.hip: what the engine passes for
     every stream without a font-size entry).  It must agree BIT FOR BIT with wset = 0 on tables of ones / zeros for the padded keys:
@@ -605,8 +646,9 @@ def test_cross_attn_block_op_against_reference_module_golden():
 
 @pytest.mark.parametrize("B,N,Cc,H", [(3, 256, 320, 5), (7, 1024, 1280, 20), (2, 384, 640, 10), (3, 1024, 640, 10)])
 def test_cross_attn_block_fused_kernel_against_reference_arithmetic(B, N, Cc, H):
-    """The fused to_q + 77-key attention kernel (csrc/gemm16.hip, EPI_XATTN; what the engine runs at the 1280-channel level of SDXL)
-    inside rt_op_cross_attn_block, on shapes that take it (d = 64, H % 5 == 0, N % 128 == 0): against the reference processor's
+    """rt_op_cross_attn_block in all of its forms - the engine's (to_q GEMM -> cross77_kernel -> to_out GEMM, round 5), round 4's fused
+    to_q + 77-key attention kernel (csrc/gemm16.hip, EPI_XATTN; debug bit 19), the generic three launches (bits 4 + 19) and, at 640
+    channels, the one-launch xblock kernel (bit 16) - on shapes that take them (d = 64, H % 5 == 0, N % 128 == 0): against the reference processor's
     arithmetic in fp32 (attention_processor.py:476-545, font-size softmax :386-401 incl. a NEGATIVE size; attention.py:169-189 adds
     the residual) on identical bf16-rounded operands, and against the three-launch form of the same operator (debug bit 4).
     Streams mix prompts and plain / font-size softmax, so a tile's K / V^T and multiplier set follow ITS stream."""
@@ -652,9 +694,17 @@ def test_cross_attn_block_fused_kernel_against_reference_arithmetic(B, N, Cc, H)
         finally:
             lib.rt_op_gemm_debug(0)
         assert float(q_block.float().abs().max()) == 0.0 and float(o_block.float().abs().max()) == 0.0, "xblock must write neither Q nor O"
-    fused, o_fused, q_fused = run()
+    # the engine's form (round 5): to_q GEMM -> cross77_kernel -> to_out GEMM
+    engine_form, o_engine, q_engine = run()
+    if H % 2 == 0 and N % 64 == 0:                                         # cross77's shapes (an odd head count keeps round 4's forms)
+        assert float(q_engine.float().abs().max()) > 0.0
+    lib.rt_op_gemm_debug(524288)                                           # bit 19: round 4's forms - EPI_XATTN where the tiling allows it
+    try:
+        fused, o_fused, q_fused = run()
+    finally:
+        lib.rt_op_gemm_debug(0)
     assert float(q_fused.float().abs().max()) == 0.0, "the fused path must not write Q to HBM"
-    lib.rt_op_gemm_debug(16)
+    lib.rt_op_gemm_debug(16 | 524288)                                      # to_q GEMM -> attn_kernel<CROSS> -> to_out GEMM
     try:
         three, o_three, q_three = run()
     finally:
@@ -671,6 +721,8 @@ def test_cross_attn_block_fused_kernel_against_reference_arithmetic(B, N, Cc, H)
     report(f"rt_op_cross_attn_block fused B{B} N{N} C{Cc}", fused, ref, atol=3e-2, rtol=2e-2)
     report("fused vs three-launch form", fused, three, atol=3e-2, rtol=2e-2)
     report("fused O vs three-launch O", o_fused, o_three, atol=2e-2, rtol=2e-2)
+    report(f"engine form (to_q -> cross77 -> to_out) O B{B} N{N} C{Cc}", o_engine, ref_o.reshape(B * N, -1), atol=2e-2, rtol=2e-2)
+    report(f"rt_op_cross_attn_block engine form B{B} N{N} C{Cc}", engine_form, ref, atol=3e-2, rtol=2e-2)
     if is_xblock:
         report(f"xblock (one launch) B{B} N{N} C{Cc}", block, ref, atol=3e-2, rtol=2e-2)
         report("xblock vs three-launch form", block, three, atol=3e-2, rtol=2e-2)
