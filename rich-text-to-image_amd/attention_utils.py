@@ -1,7 +1,9 @@
 """Token-map producer: drop-in for `utils/attention_utils.py:get_token_maps`.
 
-Same arguments and return value as the reference (list of [1,4,h,w] region masks on the GPU); the seaborn /
-matplotlib figures the reference writes on every call (attention_utils.py:266-270,334-335) are not produced.
+Same arguments and return value as the reference (list of [1,4,h,w] region masks on the GPU).  The figures the reference writes
+to `save_dir` on EVERY call (attention_utils.py:266-270,334-335) are produced only when `return_vis=True` asks for them: the call then
+returns the reference's triple (masks, segments_vis, token_maps_vis) - uint8 RGB renderings of the cluster map and of the per-span
+maps (matplotlib only; seaborn, which the reference uses for the heat maps, is not a dependency).
 The numerical steps follow attention_utils.py:233-341 line by line: 32x32 self-attention affinity ->
 SpectralClustering(n_init=100, kmeans) -> clusters labelled by min-max-normalised cross-attention score against
 `segment_threshold` -> bicubic(antialias) resize, clamp, normalise.  The clustering itself stays on the CPU
@@ -132,4 +134,65 @@ def get_token_maps(selfattn_maps, crossattn_maps, n_maps, save_dir, width, heigh
     resized = resized / (resized.sum(0, True) + 1e-8)
     dev = device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu")
     dtype = next(iter(crossattn_maps.values())).dtype
-    return [m.unsqueeze(0).unsqueeze(1).repeat([1, 4, 1, 1]).to(dtype).to(dev) for m in resized]
+    maps = [m.unsqueeze(0).unsqueeze(1).repeat([1, 4, 1, 1]).to(dtype).to(dev) for m in resized]
+    if not return_vis:
+        return maps
+    # attention_utils.py:263-277,334-339: the Gradio apps show these two pictures next to the image
+    segments_vis = _render_clusters(clusters, save_dir, num_segments, seed)
+    token_maps_vis = _render_token_maps([[m[None] for m in foreground], [m[None] for m in resized.numpy()]], obj_tokens, save_dir, seed, tokens_vis)
+    return maps, segments_vis, token_maps_vis
+
+
+def _canvas_rgb(fig):
+    fig.canvas.draw()
+    w, h = fig.canvas.get_width_height()
+    return np.asarray(fig.canvas.buffer_rgba(), dtype=np.uint8).reshape(h, w, 4)[:, :, :3].copy()
+
+
+def _render_clusters(clusters, save_dir, num_segments, seed):
+    """attention_utils.py:266-275: imshow of the 32 x 32 label map, axes off; uint8 RGB [H, W, 3]."""
+    import matplotlib
+    matplotlib.use("Agg", force=False)
+    import matplotlib.pyplot as plt
+    fig = plt.figure()
+    plt.imshow(clusters)
+    plt.axis('off')
+    if save_dir:
+        plt.savefig(os.path.join(save_dir, 'segmentation_k%d_seed%d.jpg' % (num_segments, seed)), bbox_inches='tight', pad_inches=0)
+    vis = _canvas_rgb(fig)
+    plt.close(fig)
+    return vis
+
+
+def _render_token_maps(atten_map_list, obj_tokens, save_dir, seed, tokens_vis=None):
+    """attention_utils.py:96-146 (plot_attention_maps): one row of heat maps per list entry - the cluster-level span maps and the
+    resized, normalised region masks - 'OrRd' colour map on a common scale, span tokens as titles, the last map titled 'other tokens';
+    like the reference, returns the rendering of the LAST row (uint8 RGB [H, W, 3]) and writes average_seed<seed>_attn<i>.png."""
+    import matplotlib
+    matplotlib.use("Agg", force=False)
+    import matplotlib as mpl
+    import matplotlib.pyplot as plt
+    img = None
+    for i, attn_map in enumerate(atten_map_list):
+        n_obj = len(attn_map)
+        fig, axs = plt.subplots(ncols=n_obj + 1, gridspec_kw=dict(width_ratios=[1] * n_obj + [0.1]))
+        fig.set_figheight(3)
+        fig.set_figwidth(3 * n_obj + 0.1)
+        cmap = plt.get_cmap('OrRd')
+        vmax = max([0.0] + [float(np.asarray(m).max()) for m in attn_map])
+        vmin = min([1.0] + [float(np.asarray(m).min()) for m in attn_map])
+        for tid in range(n_obj):
+            axs[tid].imshow(np.asarray(attn_map[tid][0]), cmap=cmap, vmin=vmin, vmax=vmax, aspect='auto', interpolation='nearest')
+            axs[tid].set_axis_off()
+            if tokens_vis is not None:
+                if tid == n_obj - 1:
+                    label = 'other tokens'
+                else:
+                    label = ''.join(' ' + tokens_vis[int(t) - 1][:-len('</w>')] for t in obj_tokens[tid])
+                axs[tid].set_title(label)
+        fig.colorbar(mpl.cm.ScalarMappable(norm=mpl.colors.Normalize(vmin=vmin, vmax=vmax), cmap=cmap), cax=axs[-1])
+        if save_dir:
+            fig.savefig(os.path.join(save_dir, 'average_seed%d_attn%d.png' % (seed, i)), dpi=100)
+        img = _canvas_rgb(fig)
+        plt.close(fig)
+    return img

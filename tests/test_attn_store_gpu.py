@@ -62,3 +62,22 @@ def test_xl_plain_pass_attention_store_matches_reference_hooks():
                    run_rich_text=False, original_size=(1024, 1024), target_size=(1024, 1024)).images
     assert rel_l2(out, g["final_latents"]) < 3e-2
     _check(m, g)
+
+
+def test_get_token_maps_on_gpu_resident_maps_matches_reference_function_golden():
+    """The PRODUCTION hand-over: the facades give get_token_maps CUDA tensors, which are averaged on the GPU (another fp32 reduction
+    order than the reference's CPU mean) before the seeded clustering on the host.  Same synthetic maps as tests/test_token_maps.py,
+    as CUDA tensors, against the outputs of the REFERENCE function (tests/golden/token_maps_port.pt): the cluster labels must not flip."""
+    import os
+    from oracle.synth import synthetic_attention_maps
+    from rich_text_to_image_amd.attention_utils import get_token_maps
+    port = torch.load(os.path.join(os.path.dirname(__file__), "golden", "token_maps_port.pt"))
+    for (seed, nseg, thr), ref in port.items():
+        selfm, crossm = synthetic_attention_maps(seed)
+        selfm = {k: v.to("cuda:0") for k, v in selfm.items()}
+        crossm = {k: v.to("cuda:0") for k, v in crossm.items()}
+        masks = get_token_maps(selfm, crossm, {}, None, 64, 64, [torch.tensor([2, 3]), torch.tensor([6])], seed=4,
+                               segment_threshold=thr, num_segments=nseg, device="cuda:0")
+        got = torch.cat(masks)[:, 0].cpu()
+        assert masks[0].is_cuda and got.shape == ref.shape
+        assert torch.allclose(got, ref, atol=1e-5), (got - ref).abs().max()

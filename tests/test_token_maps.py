@@ -88,3 +88,22 @@ def test_layer_lists_match_the_reference_names():
         names = {n for n, _, _ in e.attn_modules()}
         assert set(lists) <= names
         e.close()
+
+
+def test_return_vis_gives_the_reference_triple(tmp_path):
+    """get_token_maps(..., return_vis=True) -> (masks, segments_vis, token_maps_vis) (attention_utils.py:271-277,338-339): the same masks
+    as the plain call, two uint8 RGB pictures, and the files the reference writes next to them."""
+    import numpy as np
+    from oracle.synth import synthetic_attention_maps
+    from rich_text_to_image_amd.attention_utils import get_token_maps
+    selfm, crossm = synthetic_attention_maps(seed=3)
+    obj = [torch.tensor([2]), torch.tensor([3, 6])]
+    toks = [f"w{i}</w>" for i in range(77)]
+    kw = dict(width=64, height=64, obj_tokens=obj, seed=1, tokens_vis=toks, segment_threshold=0.3, num_segments=5, device="cpu")
+    plain = get_token_maps(selfm, crossm, None, str(tmp_path), **kw)
+    maps, seg_vis, tok_vis = get_token_maps(selfm, crossm, None, str(tmp_path), return_vis=True, **kw)
+    assert len(maps) == len(plain) == 3 and all(torch.equal(a, b) for a, b in zip(maps, plain))
+    for v in (seg_vis, tok_vis):
+        assert isinstance(v, np.ndarray) and v.dtype == np.uint8 and v.ndim == 3 and v.shape[2] == 3 and v.shape[0] > 50
+    assert len(np.unique(seg_vis.reshape(-1, 3), axis=0)) >= 5            # five clusters, five colours (+ the white margin)
+    assert (tmp_path / "segmentation_k5_seed1.jpg").exists() and (tmp_path / "average_seed1_attn1.png").exists()
