@@ -389,19 +389,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // accumulators, O^T = V^T P^T with the V^T rows staged in the pi order, so a lane ends with 8 CONSECUTIVE d of its query per pair of
 // accumulator tiles = one 16-B store.
 #define C77_LDS (2 * XB_KVH + 768)
+template <int T>                                                      // 16-query tiles per wave: a workgroup owns 64 T queries x 2 heads
 __global__ __launch_bounds__(256, 3) void cross77_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, q4 = lane >> 4;
-    const int nhg = p.H >> 1;                                        // head pairs
     // (head pair, stream, query block) order, contiguous per XCD: the query blocks of one (stream, head pair) share K / V^T in one L2
     int bid = blockIdx.x;
     {
         const int nwg = gridDim.x, qq = nwg >> 3, rr = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
     }
-    const int nqb = p.N >> 6;
+    const int nqb = p.N / (64 * T);
     const int qb = bid % nqb; bid /= nqb;
     const int b = bid % p.B, hg = bid / p.B;
     const int prompt = p.k_src[b], wset = p.wset[b];
@@ -426,73 +426,97 @@ __global__ __launch_bounds__(256, 3) void cross77_kernel(AttnArgs p) {
             glds16_buf(p.VT, voff_v, (head * 64 * p.ldvt + prompt * p.NK + keyoff) * 2, dst);
         }
     }
-    // ---- Q fragments of this wave's 16 queries, both heads: d = 32 ks + 8 q4 .. + 7
-    const size_t qrow = (size_t)p.q_src[b] * p.N + qb * 64 + wave * 16 + l15;
-    const bf16_t* qp = p.Q + qrow * p.ldq + hg * 128 + 8 * q4;
-    bf16x8 qf[2][2];
+    // ---- Q fragments of this wave's 16 T queries, both heads: d = 32 ks + 8 q4 .. + 7
+    const int q0 = qb * 64 * T + wave * 16 * T + l15;
+    const bf16_t* qp = p.Q + ((size_t)p.q_src[b] * p.N + q0) * p.ldq + hg * 128 + 8 * q4;
+    bf16x8 qf[T][2][2];
 #pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2) { qf[h2][0] = *(const bf16x8*)(qp + h2 * 64); qf[h2][1] = *(const bf16x8*)(qp + h2 * 64 + 32); }
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            qf[t][h2][0] = *(const bf16x8*)(qp + (size_t)t * 16 * p.ldq + h2 * 64);
+            qf[t][h2][1] = *(const bf16x8*)(qp + (size_t)t * 16 * p.ldq + h2 * 64 + 32);
+        }
     float* tabw = (float*)(smem + 2 * XB_KVH);
     if (tid < 96) {
         tabw[tid] = tid < p.nk_valid ? __builtin_amdgcn_logf(tw) : -INFINITY;          // v_log_f32 = log2; log2(0) = -inf
         tabw[96 + tid] = tsg;
     }
     // hipcc's waitcnt pass orders LDS *stores* behind a pending LDS-DMA, not LDS reads, and __syncthreads() does not wait for VMEM loads:
-    // every wave must see its own pieces landed BEFORE the barrier (without this wait the kernel raced: 5e-3 run-to-run differences)
+    // every wave must see its own pieces landed BEFORE the barrier (without this wait the kernel raced)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const float* tab = tabw;
     const int key = (l15 >> 1) & 7;
     const int c0 = ((q4 ^ key) << 4), c1 = (((4 + q4) ^ key) << 4);
-    bf16_t* orow = p.O + ((size_t)b * p.N + qb * 64 + wave * 16 + l15) * p.ldo + hg * 128 + 8 * q4;
+    bf16_t* orow = p.O + ((size_t)b * p.N + q0) * p.ldo + hg * 128 + 8 * q4;
 #pragma unroll
     for (int h2 = 0; h2 < 2; ++h2) {
         const char* kp = smem + h2 * XB_KVH + l15 * 128;
         const char* vp = smem + h2 * XB_KVH + 10240 + (q4 * 64 + l15) * 16;
-        f32x4 s[5];
+        f32x4 s[T][5];
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
             const f32x4 bias = *(const f32x4*)(tab + (j < 4 ? 32 * (j >> 1) + 8 * q4 + 4 * (j & 1) : 64 + 4 * q4));
-            s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(kp + j * 2048 + c0), qf[h2][0], bias, 0, 0, 0);
-            s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(kp + j * 2048 + c1), qf[h2][1], s[j], 0, 0, 0);
+            const bf16x8 k0 = *(const bf16x8*)(kp + j * 2048 + c0), k1 = *(const bf16x8*)(kp + j * 2048 + c1);
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                s[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[t][h2][0], bias, 0, 0, 0);
+                s[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[t][h2][1], s[t][j], 0, 0, 0);
+            }
         }
-        float mx = xb_max3(s[0][0], s[0][1], s[0][2]);
-        mx = xb_max3(mx, s[0][3], s[1][0]);
-        mx = xb_max3(mx, s[1][1], s[1][2]);
+        float inv[T];
 #pragma unroll
-        for (int j = 2; j < 5; ++j) { mx = xb_max3(mx, s[j - 1][3], s[j][0]); mx = xb_max3(mx, s[j][1], s[j][2]); }
-        mx = xb_rowmax(xb_max(mx, s[4][3]));
-        f32x2 sum2 = {0.f, 0.f};
-        const f32x2 nmx = {-mx, -mx};
+        for (int t = 0; t < T; ++t) {
+            float mx = xb_max3(s[t][0][0], s[t][0][1], s[t][0][2]);
+            mx = xb_max3(mx, s[t][0][3], s[t][1][0]);
+            mx = xb_max3(mx, s[t][1][1], s[t][1][2]);
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const f32x2 d0 = f32x2{s[j][0], s[j][1]} + nmx, d1 = f32x2{s[j][2], s[j][3]} + nmx;          // Q carries d^-1/2 log2 e
-            s[j][0] = __builtin_amdgcn_exp2f(d0.x); s[j][1] = __builtin_amdgcn_exp2f(d0.y);
-            s[j][2] = __builtin_amdgcn_exp2f(d1.x); s[j][3] = __builtin_amdgcn_exp2f(d1.y);
-            sum2 += f32x2{s[j][0], s[j][1]} + f32x2{s[j][2], s[j][3]};
+            for (int j = 2; j < 5; ++j) { mx = xb_max3(mx, s[t][j - 1][3], s[t][j][0]); mx = xb_max3(mx, s[t][j][1], s[t][j][2]); }
+            mx = xb_rowmax(xb_max(mx, s[t][4][3]));
+            f32x2 sum2 = {0.f, 0.f};
+            const f32x2 nmx = {-mx, -mx};
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const f32x2 d0 = f32x2{s[t][j][0], s[t][j][1]} + nmx, d1 = f32x2{s[t][j][2], s[t][j][3]} + nmx;      // Q carries d^-1/2 log2 e
+                s[t][j][0] = __builtin_amdgcn_exp2f(d0.x); s[t][j][1] = __builtin_amdgcn_exp2f(d0.y);
+                s[t][j][2] = __builtin_amdgcn_exp2f(d1.x); s[t][j][3] = __builtin_amdgcn_exp2f(d1.y);
+                sum2 += f32x2{s[t][j][0], s[t][j][1]} + f32x2{s[t][j][2], s[t][j][3]};
+            }
+            inv[t] = 1.f / xb_rowsum(sum2.x + sum2.y);
+            if (fs) {                                                // sign of a negative font size on the normalised probability
+#pragma unroll
+                for (int j = 0; j < 5; ++j) s[t][j] = s[t][j] * *(const f32x4*)(tab + 96 + (j < 4 ? 32 * (j >> 1) + 8 * q4 + 4 * (j & 1) : 64 + 4 * q4));
+            }
         }
-        const float inv = 1.f / xb_rowsum(sum2.x + sum2.y);
-        if (fs) {                                                    // sign of a negative font size on the normalised probability
+        f32x4 o[T][4];
 #pragma unroll
-            for (int j = 0; j < 5; ++j) s[j] = s[j] * *(const f32x4*)(tab + 96 + (j < 4 ? 32 * (j >> 1) + 8 * q4 + 4 * (j & 1) : 64 + 4 * q4));
-        }
-        f32x4 o[4];
+        for (int t = 0; t < T; ++t)
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int dt = 0; dt < 4; ++dt) o[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int st = 0; st < 3; ++st) {
-            const bf16x8 pf = xb_pack8(s[2 * st], st < 2 ? s[2 * st + 1] : zero4);
+            bf16x8 pf[T];
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(vp + st * 4096 + dt * 256), pf, o[dt], 0, 0, 0);
+            for (int t = 0; t < T; ++t) pf[t] = xb_pack8(s[t][2 * st], st < 2 ? s[t][2 * st + 1] : zero4);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 vf = *(const bf16x8*)(vp + st * 4096 + dt * 256);
+#pragma unroll
+                for (int t = 0; t < T; ++t) o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[t], o[t][dt], 0, 0, 0);
+            }
         }
         // accumulator tiles (2 s2, 2 s2 + 1) of lane (l15, q4): d = 32 s2 + 8 q4 + [0, 8) of query l15
-        *(bf16x8*)(orow + h2 * 64) = xb_pack8(o[0] * inv, o[1] * inv);
-        *(bf16x8*)(orow + h2 * 64 + 32) = xb_pack8(o[2] * inv, o[3] * inv);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            *(bf16x8*)(orow + (size_t)t * 16 * p.ldo + h2 * 64) = xb_pack8(o[t][0] * inv[t], o[t][1] * inv[t]);
+            *(bf16x8*)(orow + (size_t)t * 16 * p.ldo + h2 * 64 + 32) = xb_pack8(o[t][2] * inv[t], o[t][3] * inv[t]);
+        }
     }
 }
 
+int g_c77_t1 = 0;       // debug bit 20: one 16-query tile per wave for every shape (A/B)
 bool cross77_supported(int H, int DP, int tokens, int NK, int nk_valid) {
     return DP == 64 && H % 2 == 0 && tokens % 64 == 0 && NK == 96 && nk_valid >= 1 && nk_valid <= 80;
 }
@@ -503,9 +527,18 @@ void launch_cross77(const AttnArgs& a, hipStream_t st) {
     RT_REQUIRE((long)RT_MAXB * a.NK * a.ldk * 2 < 0x7fffffffL && (long)a.H * 64 * a.ldvt * 2 < 0x7fffffffL, "cross77: K / V^T cache beyond the 2 GiB descriptor range");
     for (int b = 0; b < a.B; ++b) RT_REQUIRE(a.wset[b] < 0 || (a.wabs && a.wsgn), "cross77: multiplier tables");
     for (int b = 0; b < a.B; ++b) RT_REQUIRE(a.k_src[b] == a.v_src[b], "cross77: K and V of one prompt");
+    // two 16-query tiles per wave (K / V^T staged once per 128 queries, every fragment read feeds two MFMAs) when that still leaves two
+    // workgroups per CU; a query's arithmetic does not depend on the choice (bit-identical either way), so it may look at the batch
+    const int T = g_c77_t1 ? 1 : ((a.N % 128 == 0 && (a.N / 128) * a.B * (a.H / 2) >= 512) ? 2 : 1);
     static bool attr = false;
-    if (!attr) { HIP_CHECK(hipFuncSetAttribute((const void*)cross77_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C77_LDS)); attr = true; }
-    hipLaunchKernelGGL(cross77_kernel, dim3((a.N / 64) * a.B * (a.H / 2)), dim3(256), C77_LDS, st, a);
+    if (!attr) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)cross77_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, C77_LDS));
+        HIP_CHECK(hipFuncSetAttribute((const void*)cross77_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, C77_LDS));
+        attr = true;
+    }
+    const dim3 grid((a.N / (64 * T)) * a.B * (a.H / 2));
+    if (T == 2) hipLaunchKernelGGL(cross77_kernel<2>, grid, dim3(256), C77_LDS, st, a);
+    else hipLaunchKernelGGL(cross77_kernel<1>, grid, dim3(256), C77_LDS, st, a);
     HIP_CHECK(hipGetLastError());
 }
 
