@@ -475,7 +475,7 @@ def main():
         traffic = None
         tfile = None
         try:
-            tfile = next(f for f in ("r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            tfile = next(f for f in ("r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
             tj = json.load(open(os.path.join(ROOT, "profiles", tfile)))
             cls = {"gemm_kernel<A_DENSE>": "gemm_dense", "gemm_kernel<A_CONV3*>": "gemm_conv", "attn_kernel<self>": "attn_self",
                    "attn_kernel<cross>": "attn_cross", "gemm16_kernel<EPI_XATTN> (to_q + cross-attention)": "xattn_fused"}[dom]

@@ -11,7 +11,7 @@ CLASSES = {"xattn_fused": lambda n: "gemm16_kernel<0, 5," in n,                 
            "gemm_dense": lambda n: ("gemm" in n and ("<0," in n) and "gemm16_kernel<0, 5," not in n) or "gemm16_dual_kernel" in n,   # (dual: the grouped Q|K + V^T launch)
            "gemm_conv": lambda n: ("gemm" in n and "<0," not in n and "gemm16_dual_kernel" not in n) or "conv3p" in n,
            "attn_self": lambda n: bool(re.search(r"attn_kernel<\d+, \d+, false", n)),       # attn_kernel<DP, KT, CROSS, ...>
-           "attn_cross": lambda n: bool(re.search(r"attn_kernel<\d+, \d+, true", n))}
+           "attn_cross": lambda n: bool(re.search(r"attn_kernel<\d+, \d+, true", n)) or "cross77_kernel" in n}      # round 5: cross77_kernel (xblock.hip)
 BENCH_CLASS = {"xattn_fused": "gemm16_kernel<EPI_XATTN> (to_q + cross-attention)", "gemm_dense": "gemm_kernel<A_DENSE>", "gemm_conv": "gemm_kernel<A_CONV3*>", "attn_self": "attn_kernel<self>", "attn_cross": "attn_kernel<cross>"}
 
 
