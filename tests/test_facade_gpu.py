@@ -157,3 +157,18 @@ def test_many_regions_grow_the_engine():
     r = rel_l2(out, ref)
     print("8 regions (11 streams) vs oracle rel-L2", r)
     assert r < 3e-2
+    # a rank != 0 of a seed-parallel launch holds NO state dict ("empty": its weights arrived as the packed arena in one broadcast,
+    # sample.py build_model); growing its engine must carry the arena over device to device (the rebuilt engine used to come
+    # up unbound and the next forward threw 'weight not bound')
+    from rich_text_to_image_amd.launcher import arena_tensor
+    rx = RegionDiffusionXL(device=0, unet_state_dict="empty", config=cfg)
+    e8 = rx.unet.engine(hw, hw)
+    assert rx.unet.max_streams == 8 and e8.weights_missing()[0] > 0
+    arena_tensor(e8).copy_(arena_tensor(mdl.unet.engine(hw, hw)))             # what launcher.broadcast_weights does on a receiving rank
+    e8.arena_mark_bound()
+    rx.masks = masks
+    out2 = rx.sample(prompt=None, height=8 * hw, width=8 * hw, num_inference_steps=steps, guidance_scale=5.0, latents=lat.clone(),
+                     prompt_embeds=emb[1:], negative_prompt_embeds=emb[:1], pooled_prompt_embeds=pooled[1:], negative_pooled_prompt_embeds=pooled[:1],
+                     output_type="latent", run_rich_text=True, text_format_dict=tfd, inject_selfattn=1.0, inject_background=0.0).images
+    assert rx.unet.max_streams >= R + 3 and rx.unet.engine(hw, hw).weights_missing()[0] == 0
+    assert torch.equal(out2, out)
