@@ -34,12 +34,12 @@ import fullschedule_check as fc  # noqa: E402
 
 # case: (max rel-L2 of the latents at ANY checkpoint, min PSNR [dB] of the final uint8 image, max mean-abs pixel difference, max-abs)
 # Measured on MI355X (profiles/r5_fullschedule_parity.json): config1 4.9e-3 / 53.3 dB / 0.30 / 3; config3 4.1e-3 / 56.2 dB / 0.16 / 2;
-# config5 8.2e-3 / 52.8 dB / 0.33 / 4 - the error of one forward (7e-3 at CFG 1) does not compound over the schedule.
+# config5 8.2e-3 / 52.8 dB / 0.33 / 4; config3_50 (all 50 steps) 2.4e-3 / 58.7 dB / 0.09 / 1 - the error of one forward (7e-3 at CFG 1) does not compound over the schedule.
 TOL = {
     "config1": (1.5e-2, 46.0, 1.0, 8),
     "config2": (2.5e-2, 44.0, 1.5, 12),
     "config3": (1.5e-2, 46.0, 1.0, 8),
-    "config3_50": (2.5e-2, 44.0, 1.5, 12),
+    "config3_50": (1.5e-2, 46.0, 1.0, 8),
     "config5": (2.5e-2, 46.0, 1.0, 8),
 }
 RESULTS = {}
