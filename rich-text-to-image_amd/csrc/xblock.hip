@@ -383,14 +383,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // O = softmax_fs(Q K[prompt]^T) V[prompt] for the cached cross-attention keys (models/attention_processor.py:476-545, font-size softmax
 // :386-401) - the attention unit of xblock_kernel above with Q read from and O written to HBM.  The generic attn_kernel (attention.hip)
 // runs this shape as a one-tile flash loop: 19.6 us for 7 x 1024 tokens x 20 heads, 28 us at 4096 tokens x 10 heads - 2.6 TB/s of its
-// Q + O bytes.  Here a workgroup owns 64 queries x 2 heads; K / V^T of the two heads (80 staged keys, 44 KB) arrive in LDS by
-// coalesced LDS-DMA once, three workgroups share a CU (12 waves hide each other's fragment and softmax latency), every wave runs its 16
-// queries against both heads: S^T = K Q^T (Q rows straight from HBM as the B operand), masked / font-size-biased scores, P^T from the
+// Q + O bytes.  Here a workgroup owns 64 (or 128) queries x 1 head (2 behind debug bit 21); K / V^T of the head (80 staged keys, 22 KB)
+// arrive in LDS by coalesced LDS-DMA once, up to six workgroups share a CU (24 waves hide each other's fragment and softmax latency),
+// every wave runs its 16 (32) queries against the head: S^T = K Q^T (Q rows straight from HBM as the B operand), masked / font-size-biased scores, P^T from the
 // accumulators, O^T = V^T P^T with the V^T rows staged in the pi order, so a lane ends with 8 CONSECUTIVE d of its query per pair of
 // accumulator tiles = one 16-B store.
-#define C77_LDS (2 * XB_KVH + 768)
-template <int T>                                                      // 16-query tiles per wave: a workgroup owns 64 T queries x 2 heads
-__global__ __launch_bounds__(256, 3) void cross77_kernel(AttnArgs p) {
+#define C77_LDS(HPW) ((HPW) * XB_KVH + 768)
+template <int T, int HPW>                                             // 16-query tiles per wave, heads per workgroup: a workgroup owns 64 T queries x HPW heads
+__global__ __launch_bounds__(256, HPW == 2 ? 3 : 4) void cross77_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256, 3) void cross77_kernel(AttnArgs p) {
     }
     const int nqb = p.N / (64 * T);
     const int qb = bid % nqb; bid /= nqb;
-    const int b = bid % p.B, hg = bid / p.B;
+    const int b = bid % p.B, hg = bid / p.B;                         // hg: head group (HPW heads)
     const int prompt = p.k_src[b], wset = p.wset[b];
     const bool fs = wset >= 0;
     float tw = 1.f, tsg = 1.f;
@@ -412,10 +412,11 @@ __global__ __launch_bounds__(256, 3) void cross77_kernel(AttnArgs p) {
     const int lrow = lane >> 3, pslot = lane & 7;
     const int voff_v = xb_pi(lane) * p.ldvt * 2;
 #pragma unroll
-    for (int i = 0; i < 11; ++i) {
+    for (int i = 0; i < (22 * HPW + 3) / 4; ++i) {
         const int pidx = i * 4 + wave;
+        if (pidx >= 22 * HPW) break;                                 // (HPW = 1: 22 pieces, waves 2 and 3 issue five)
         const int h2 = pidx >= 22 ? 1 : 0, pp = pidx - 22 * h2;
-        const int head = hg * 2 + h2;
+        const int head = hg * HPW + h2;
         char* dst = smem + h2 * XB_KVH + pp * 1024;
         if (pp < 10) {
             const int rho = pp * 8 + lrow, j = rho >> 4, i16 = rho & 15;
@@ -428,16 +429,16 @@ __global__ __launch_bounds__(256, 3) void cross77_kernel(AttnArgs p) {
     }
     // ---- Q fragments of this wave's 16 T queries, both heads: d = 32 ks + 8 q4 .. + 7
     const int q0 = qb * 64 * T + wave * 16 * T + l15;
-    const bf16_t* qp = p.Q + ((size_t)p.q_src[b] * p.N + q0) * p.ldq + hg * 128 + 8 * q4;
-    bf16x8 qf[T][2][2];
+    const bf16_t* qp = p.Q + ((size_t)p.q_src[b] * p.N + q0) * p.ldq + hg * (64 * HPW) + 8 * q4;
+    bf16x8 qf[T][HPW][2];
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
+        for (int h2 = 0; h2 < HPW; ++h2) {
             qf[t][h2][0] = *(const bf16x8*)(qp + (size_t)t * 16 * p.ldq + h2 * 64);
             qf[t][h2][1] = *(const bf16x8*)(qp + (size_t)t * 16 * p.ldq + h2 * 64 + 32);
         }
-    float* tabw = (float*)(smem + 2 * XB_KVH);
+    float* tabw = (float*)(smem + HPW * XB_KVH);
     if (tid < 96) {
         tabw[tid] = tid < p.nk_valid ? __builtin_amdgcn_logf(tw) : -INFINITY;          // v_log_f32 = log2; log2(0) = -inf
         tabw[96 + tid] = tsg;
@@ -449,9 +450,9 @@ __global__ __launch_bounds__(256, 3) void cross77_kernel(AttnArgs p) {
     const float* tab = tabw;
     const int key = (l15 >> 1) & 7;
     const int c0 = ((q4 ^ key) << 4), c1 = (((4 + q4) ^ key) << 4);
-    bf16_t* orow = p.O + ((size_t)b * p.N + q0) * p.ldo + hg * 128 + 8 * q4;
+    bf16_t* orow = p.O + ((size_t)b * p.N + q0) * p.ldo + hg * (64 * HPW) + 8 * q4;
 #pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2) {
+    for (int h2 = 0; h2 < HPW; ++h2) {
         const char* kp = smem + h2 * XB_KVH + l15 * 128;
         const char* vp = smem + h2 * XB_KVH + 10240 + (q4 * 64 + l15) * 16;
         f32x4 s[T][5];
@@ -516,9 +517,9 @@ __global__ __launch_bounds__(256, 3) void cross77_kernel(AttnArgs p) {
     }
 }
 
-int g_c77_t1 = 0;       // debug bit 20: one 16-query tile per wave for every shape (A/B)
+int g_c77_t1 = 0;       // debug bits 20 / 21 (A/B): one 16-query tile per wave for every shape / two heads per workgroup
 bool cross77_supported(int H, int DP, int tokens, int NK, int nk_valid) {
-    return DP == 64 && H % 2 == 0 && tokens % 64 == 0 && NK == 96 && nk_valid >= 1 && nk_valid <= 80;
+    return DP == 64 && H >= 1 && tokens % 64 == 0 && NK == 96 && nk_valid >= 1 && nk_valid <= 80;
 }
 
 void launch_cross77(const AttnArgs& a, hipStream_t st) {
@@ -527,18 +528,30 @@ void launch_cross77(const AttnArgs& a, hipStream_t st) {
     RT_REQUIRE((long)RT_MAXB * a.NK * a.ldk * 2 < 0x7fffffffL && (long)a.H * 64 * a.ldvt * 2 < 0x7fffffffL, "cross77: K / V^T cache beyond the 2 GiB descriptor range");
     for (int b = 0; b < a.B; ++b) RT_REQUIRE(a.wset[b] < 0 || (a.wabs && a.wsgn), "cross77: multiplier tables");
     for (int b = 0; b < a.B; ++b) RT_REQUIRE(a.k_src[b] == a.v_src[b], "cross77: K and V of one prompt");
-    // two 16-query tiles per wave (K / V^T staged once per 128 queries, every fragment read feeds two MFMAs) when that still leaves two
-    // workgroups per CU; a query's arithmetic does not depend on the choice (bit-identical either way), so it may look at the batch
-    const int T = g_c77_t1 ? 1 : ((a.N % 128 == 0 && (a.N / 128) * a.B * (a.H / 2) >= 512) ? 2 : 1);
+    // ONE head per workgroup (22.5 KB of LDS: up to 6 workgroups = 24 waves per CU hide each other's latency chain; 12.3 vs 13.9 us at
+    // 7 x 1024 x 20 heads, 19.3 vs 21.4 at 4096 x 10, profiles/r5_cross77_probe.txt) and two 16-query tiles per wave (K / V^T staged once
+    // per 128 queries, every fragment read feeds two MFMAs) when that still leaves two workgroups per CU.  A query's arithmetic does
+    // not depend on these choices (bit-identical either way), so they may look at the batch.
+    // g_c77_mode (debug bits 20 / 21): bit 0 = one tile per wave always, bit 1 = TWO heads per workgroup (the first form of the kernel)
+    const bool one_head = (g_c77_t1 & 2) == 0 || (a.H & 1);
+    const int hpw = one_head ? 1 : 2;
+    const int T = (g_c77_t1 & 1) ? 1 : ((a.N % 128 == 0 && (a.N / 128) * a.B * (a.H / hpw) >= 512) ? 2 : 1);
     static bool attr = false;
     if (!attr) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)cross77_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, C77_LDS));
-        HIP_CHECK(hipFuncSetAttribute((const void*)cross77_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, C77_LDS));
+        HIP_CHECK(hipFuncSetAttribute((const void*)cross77_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, C77_LDS(2)));
+        HIP_CHECK(hipFuncSetAttribute((const void*)cross77_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, C77_LDS(2)));
+        HIP_CHECK(hipFuncSetAttribute((const void*)cross77_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, C77_LDS(1)));
+        HIP_CHECK(hipFuncSetAttribute((const void*)cross77_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, C77_LDS(1)));
         attr = true;
     }
-    const dim3 grid((a.N / (64 * T)) * a.B * (a.H / 2));
-    if (T == 2) hipLaunchKernelGGL(cross77_kernel<2>, grid, dim3(256), C77_LDS, st, a);
-    else hipLaunchKernelGGL(cross77_kernel<1>, grid, dim3(256), C77_LDS, st, a);
+    const dim3 grid((a.N / (64 * T)) * a.B * (a.H / hpw));
+    if (hpw == 2) {
+        if (T == 2) hipLaunchKernelGGL((cross77_kernel<2, 2>), grid, dim3(256), C77_LDS(2), st, a);
+        else hipLaunchKernelGGL((cross77_kernel<1, 2>), grid, dim3(256), C77_LDS(2), st, a);
+    } else {
+        if (T == 2) hipLaunchKernelGGL((cross77_kernel<2, 1>), grid, dim3(256), C77_LDS(1), st, a);
+        else hipLaunchKernelGGL((cross77_kernel<1, 1>), grid, dim3(256), C77_LDS(1), st, a);
+    }
     HIP_CHECK(hipGetLastError());
 }
 

@@ -20,7 +20,7 @@ for name, B, H, N in (("B 7 x 1024 x 20 heads", 7, 20, 1024), ("A 7 x 4096 x 10 
     ia = lambda v: (C.c_int * B)(*v)
     src, prm, ws = ia(range(B)), ia([0, 4, 0, 4, 1, 2, 3][:B]), ia([-1, 1, -1, -1, -1, -1, -1][:B])
     res = {}
-    for flags in (0, 1048576, 524288):
+    for flags in (0, 1048576, 2097152, 3145728, 524288):
         lib.rt_op_gemm_debug(flags)
         def call():
             rc = lib.rt_op_attention(_ptr(Q), HD, _ptr(K), HD, _ptr(VT), P * 96, _ptr(O), HD, src, prm, prm, ws, _ptr(wabs), _ptr(wsgn), B, H, N, 96, 77, 64, 1, None)
@@ -35,4 +35,4 @@ for name, B, H, N in (("B 7 x 1024 x 20 heads", 7, 20, 1024), ("A 7 x 4096 x 10 
         res[flags] = e0.elapsed_time(e1) / 50 * 1e3
     lib.rt_op_gemm_debug(0)
     mb = 2 * B * N * HD * 2 / 1e6
-    print(f"{name}: cross77 {res[0]:.1f} us ({mb / res[0]:.2f} TB/s of Q + O), one tile per wave (bit 20) {res[1048576]:.1f} us, attn_kernel<CROSS> {res[524288]:.1f} us")
+    print(f"{name}: cross77 {res[0]:.1f} us ({mb / res[0]:.2f} TB/s of Q + O), one tile per wave (bit 20) {res[1048576]:.1f} us, two heads per workgroup (bit 21) {res[2097152]:.1f} us, both {res[3145728]:.1f} us, attn_kernel<CROSS> {res[524288]:.1f} us")
