@@ -44,7 +44,7 @@ int main() {
     printf("xblock A (7 x 4096 x 640): %.1f us per launch, %d workgroups; 52.6 GFLOP executed -> %.0f TFLOP/s\n", ms / 50 * 1e3, nwg, 52.57e9 / (ms / 50 * 1e-3) / 1e12);
     const char* names[7] = {"prologue (x + tile 0)", "to_q (20 tiles)", "attention (10 heads)", "to_out chunk 0 (10 tiles)", "epilogue 0 + to_out chunk 1", "epilogue 1", "stores retire"};
     double tot = 0;
-    for (int i = 0; i < 7; ++i) { printf("  %-32s %8.0f cycles (100 MHz ticks x 24?) avg per workgroup\n", names[i], seg[i] / nwg); tot += seg[i] / nwg; }
+    for (int i = 0; i < 7; ++i) { printf("  %-32s %8.0f cycles avg per workgroup (s_memtime)\n", names[i], seg[i] / nwg); tot += seg[i] / nwg; }
     printf("  total %.0f; first entry -> last retire %lld\n", tot, last - first);
     return 0;
 }
