@@ -585,7 +585,31 @@ def main():
                 torch.cuda.synchronize(); eng.set_stream(None)
             return dict(ms_per_step=dtg / args.steps * 1e3, value=args.steps / dtg, identical_latents=same,
                         note="each timed step captured into its own HIP graph (the step index is a launch argument) and replayed back to back")
-        legs = [("graph_replay", graph_replay),
+        def split_estimate():
+            # intra-image split over 2 GPUs (launcher.split_region_step, `sample.py --gpus 2 --split_image`): the forwards of the two stream
+            # ranges timed one after the other on THIS GPU - the step of a 2-GPU run costs the longer one + one 1.8 MB exchange + the
+            # epilogue.  An estimate from one device, labelled as such: the leases here have one GPU.
+            reset(); eng.set_fontsize(torch.tensor([5, 6]), torch.tensor([20.0, 20.0]))
+            out = {}
+            for label, idx in (("injected_step", 0), ("plain_step", nsched - 1)):
+                parts = []
+                for part in range(2):
+                    for _ in range(2):
+                        rng = eng.region_step_part(idx, gs, isa, ibg, True, part, 2)
+                    eng.synchronize(); torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(5):
+                        eng.region_step_part(idx, gs, isa, ibg, True, part, 2)
+                    eng.synchronize(); torch.cuda.synchronize()
+                    parts.append(dict(streams=[rng[0], rng[0] + rng[1] - 1], ms=(time.perf_counter() - t0) / 5 * 1e3))
+                out[label] = dict(parts=parts, longer_part_ms=max(p_["ms"] for p_ in parts))
+            out["predicted_ms_per_step_2_gpus"] = 0.5 * (out["injected_step"]["longer_part_ms"] + out["plain_step"]["longer_part_ms"])
+            out["note"] = ("forwards of the two stream ranges of launcher.split_region_step ({uncond, base, uncond_ref} | {text_ref, regions} while "
+                           "injecting, 4 | 3 streams otherwise) timed on ONE GPU; a 2-GPU step = the longer range + one exchange of the noise "
+                           "predictions (1.8 MB) + the epilogue; ESTIMATE - not a 2-GPU measurement")
+            reset()
+            return out
+        legs = [("intra_image_split_estimate", split_estimate), ("graph_replay", graph_replay),
                 ("batched_2_requests", lambda: e2e.two_requests(eng, lambda sd_: synth_inputs(sd_, R, hw, dev), hw, nsched, args.steps, gs, isa, sched_index, ts, sig, init_sigma)),
                 ("plain_pass", lambda: e2e.plain_pass(eng, inp, hw)),
                 ("end_to_end", lambda: e2e.end_to_end(eng, hw))]

@@ -100,6 +100,25 @@ int rt_region_step(rt_engine* e, int step_index, float guidance_scale, double in
                                                   bit 1: defer the background blend to rt_background_blend() */);
 /* the deferred blend of the last step (colour guidance sits between the scheduler step and the blend: rd.py:151-173) */
 int rt_background_blend(rt_engine* e);
+/* Intra-image split of one rich-text step over `nparts` GPUs (the F forwards at region_diffusion_sdxl.py:787-821 are
+ * independent except that injected region forwards consume the text_ref forward's self-attention Q / K and ResNet feature).  Every
+ * rank holds the same engine state and calls, per step:
+ *   rt_region_step_part(..., part, nparts, &first, &count)   the UNet forwards of ITS contiguous range [first, first + count) of the
+ *                                                            step's stream list [uncond, base, uncond_ref, text_ref, regions...];
+ *                                                            text_ref and the region streams always share the last range, so nothing
+ *                                                            crosses GPUs inside the forward
+ *   (exchange the ranges of the eps buffer, rt_eps_info: stream s at byte offset s * bytes_per_stream - one collective per rank)
+ *   rt_region_step_finish(...)                               mask combine + CFG + scheduler step + blend on all streams (every rank)
+ * Same arguments / flags as rt_region_step; the result is bit-identical with rt_region_step on one GPU. */
+int rt_region_step_part(rt_engine* e, int step_index, float guidance_scale, double inject_selfattn, double inject_background, int xl,
+                        int flags, int part, int nparts, int* first_stream, int* n_streams,
+                        int* plan_info /* optional [3]: streams of the step, its text_ref stream (-1: none), injection on: the arguments
+                                          of rt_op_split_range, from which a rank derives the OTHER ranks' ranges without a collective */);
+int rt_region_step_finish(rt_engine* e, int step_index, float guidance_scale, double inject_selfattn, double inject_background, int xl,
+                          int flags);
+int rt_eps_info(rt_engine* e, void** dev_ptr, unsigned long long* bytes_per_stream, int* max_streams);
+/* host-only: the stream range of `part` for a step of n_streams streams whose text_ref stream is text_ref_stream (-1: none) */
+int rt_op_split_range(int n_streams, int text_ref_stream, int inject, int part, int nparts, int* first_stream, int* n_streams_out);
 /* one iteration of the plain-text loop (rd.py:200-214 / xl.py:880-905): batch-2 forward, CFG, step */
 int rt_plain_step(rt_engine* e, int step_index, float guidance_scale);
 

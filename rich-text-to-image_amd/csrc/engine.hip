@@ -843,6 +843,12 @@ struct rt_engine {
 
     // ---------------------------------------------------------------------------- step drivers
     void region_step(int i, float g, double inject_selfattn, double inject_background, bool xl, bool elide, bool defer_blend);
+    void region_plan(int i, float g, double isa, double ibg, bool xl, bool elide, bool defer_blend, FwdIn& in, StepArgs& a, bool& blend_out, bool& inject_out);
+    void region_finish(int i, StepArgs& a, bool blend_deferred);
+    // intra-image split (step_driver.inl): the forwards of this rank's contiguous stream range, then - after the ranks exchanged their
+    // slices of `eps` - the epilogue on all of them
+    void region_step_part(int i, float g, double isa, double ibg, bool xl, bool elide, bool defer_blend, int part, int nparts, int* first, int* count, int* plan_info);
+    void region_step_finish(int i, float g, double isa, double ibg, bool xl, bool elide, bool defer_blend);
     bool pending_blend = false;
     void plain_step(int i, float g);
 };
@@ -1043,6 +1049,19 @@ int rt_get_state_ptrs(rt_engine* e, float** latents, float** noise_pred) {
 int rt_region_step(rt_engine* e, int i, float g, double isa, double ibg, int xl, int elide) {
     RT_TRY(e, { need_device(e); e->region_step(i, g, isa, ibg, xl != 0, (elide & 1) != 0, (elide & 2) != 0); })
 }
+int rt_region_step_part(rt_engine* e, int i, float g, double isa, double ibg, int xl, int flags, int part, int nparts, int* first, int* count,
+                        int* plan_info) {
+    RT_TRY(e, { need_device(e); RT_REQUIRE(first && count, "rt_region_step_part: null outputs");
+                e->region_step_part(i, g, isa, ibg, xl != 0, (flags & 1) != 0, (flags & 2) != 0, part, nparts, first, count, plan_info); })
+}
+int rt_region_step_finish(rt_engine* e, int i, float g, double isa, double ibg, int xl, int flags) {
+    RT_TRY(e, { need_device(e); e->region_step_finish(i, g, isa, ibg, xl != 0, (flags & 1) != 0, (flags & 2) != 0); })
+}
+int rt_eps_info(rt_engine* e, void** dev_ptr, unsigned long long* bytes_per_stream, int* max_streams) {
+    RT_TRY(e, { need_device(e); RT_REQUIRE(dev_ptr && bytes_per_stream && max_streams, "rt_eps_info: null outputs");
+                RT_REQUIRE(e->lat_h > 0, "rt_eps_info: call rt_set_latents first");
+                *dev_ptr = e->eps; *bytes_per_stream = (unsigned long long)e->lat_h * e->lat_w * 4 * 4; *max_streams = e->cfg.max_streams; })
+}
 int rt_background_blend(rt_engine* e) {
     RT_TRY(e, {
         need_device(e);
@@ -1175,6 +1194,10 @@ static float* op_store_stats(size_t floats, hipStream_t st) {
     catch (const std::exception& ex) { g_op_error = ex.what(); return RT_E_INVALID; }
 
 const char* rt_op_last_error(void) { return g_op_error.c_str(); }
+// the stream ranges of the intra-image split (step_driver.inl) as a host-only query
+int rt_op_split_range(int n_streams, int text_ref_stream, int inject, int part, int nparts, int* first, int* count) {
+    OP_TRY({ RT_REQUIRE(first && count, "rt_op_split_range: null outputs"); region_split_range(n_streams, text_ref_stream, inject != 0, part, nparts, first, count); })
+}
 extern int g_store_legacy;
 extern int g_store_own_stats;
 extern int g_store_apply_v1;

@@ -32,7 +32,11 @@ static void pndm_coeffs(rt_engine* e, int i, StepArgs& a) {
     e->pndm_counter++;
 }
 
-void rt_engine::region_step(int i, float g, double isa, double ibg, bool xl, bool elide, bool defer_blend) {
+// The streams of rich-text step i and the flags of its epilogue (everything of region_step that is a pure function of the schedule
+// position): `in` = the F batched forwards with their mode words, `a` = the epilogue's arguments without the scheduler coefficients
+// (PNDM's are stateful: region_finish computes them once).
+void rt_engine::region_plan(int i, float g, double isa, double ibg, bool xl, bool elide, bool defer_blend, FwdIn& in, StepArgs& a, bool& blend_out,
+                            bool& inject_out) {
     require_bound();
     const int n = (int)timesteps.size(), R = n_regions;
     RT_REQUIRE(i >= 0 && i < n, "region_step: step index out of range");
@@ -59,9 +63,9 @@ void rt_engine::region_step(int i, float g, double isa, double ibg, bool xl, boo
     }
     if (!run_ref) step_ref = false;
 
-    FwdIn in{}; in.h = lat_h; in.w = lat_w; in.t = t; in.eps_out = eps;
+    in = FwdIn{}; in.h = lat_h; in.w = lat_w; in.t = t; in.eps_out = eps;
     const float scale = xl ? 1.f / std::sqrt(table[i] * table[i] + 1.f) : 1.f;
-    StepArgs a{};
+    a = StepArgs{};
     int F = 0;
     auto add = [&](const float* x, int prompt, int fs) {
         RT_REQUIRE(F < cfg.max_streams, "region_step: more streams than max_streams");
@@ -78,16 +82,77 @@ void rt_engine::region_step(int i, float g, double isa, double ibg, bool xl, boo
         a.s_region[r] = s;
     }
     in.B = F;
-    unet_forward(in);
-
     a.eps = eps; a.masks = masks; a.lat = lat; a.lat_ref = lat_ref; a.HW = lat_h * lat_w; a.R = R; a.g = g; a.plain = 0;
     a.noise_pred = noise_pred;
     a.sched = sched_kind; a.step_ref = step_ref ? 1 : 0; a.blend = (blend && !defer_blend) ? 1 : 0;
-    pending_blend = blend && defer_blend;
+    blend_out = blend && defer_blend;
+    inject_out = feat && run_ref;
+}
+
+// mask combine + CFG + scheduler step + blend on the eps of ALL streams of step i (models/region_diffusion.py:119-147,
+// region_diffusion_sdxl.py:810-846)
+void rt_engine::region_finish(int i, StepArgs& a, bool blend_deferred) {
+    pending_blend = blend_deferred;
     if (sched_kind == RT_SCHED_EULER) a.dsigma = table[i + 1] - table[i];
     else pndm_coeffs(this, i, a);
     launch_step_epilogue(a, stream);
     steps_done++;
+}
+
+void rt_engine::region_step(int i, float g, double isa, double ibg, bool xl, bool elide, bool defer_blend) {
+    FwdIn in; StepArgs a; bool blend_deferred, inject;
+    region_plan(i, g, isa, ibg, xl, elide, defer_blend, in, a, blend_deferred, inject);
+    unet_forward(in);
+    region_finish(i, a, blend_deferred);
+}
+
+// ---- intra-image split of a step over `nparts` GPUs.  The F forwards of a step are independent except that the
+// region streams of an injected step consume the self-attention Q / K and one ResNet feature of the text_ref stream, layer by layer
+// (0.42 GB per step if shipped).  The streams are therefore cut into `nparts` CONTIGUOUS ranges of the step's stream list
+// [uncond, base, uncond_ref, text_ref, region 0 ..] such that text_ref and every region stream land in the same (the last) range: no
+// per-layer traffic at all, ONE exchange of the noise predictions (F x 4 x h x w fp32: 1.8 MB at SDXL) per step, after which every
+// rank runs the (elementwise) epilogue on the full set and holds identical latents.  With 2 parts: {uncond, base, uncond_ref} |
+// {text_ref, regions} while the injection is on, halves otherwise.  Batch invariance (a stream's forward does not depend on the
+// other streams of its launch) makes the split run bit-identical with the one-GPU step.
+static void region_split_range(int F, int s_tref, bool inject, int part, int nparts, int* first, int* count) {
+    RT_REQUIRE(nparts >= 1 && part >= 0 && part < nparts && F >= 1, "split: part index");
+    // even prefix split of the stream list; while the injection is on, everything from text_ref on forms the LAST part and the streams
+    // before it (uncond, base, uncond_ref: independent forwards) are dealt evenly to the other parts
+    int lo, hi;
+    if (inject && s_tref >= 0 && nparts > 1) {
+        const int head = s_tref, np = nparts - 1;
+        auto bound = [&](int k) { return (int)(((long)head * k + np - 1) / np); };       // ceil(head k / (nparts - 1))
+        if (part == nparts - 1) { lo = head; hi = F; } else { lo = bound(part); hi = bound(part + 1); }
+    } else {
+        auto bound = [&](int k) { return (int)(((long)F * k + nparts - 1) / nparts); };   // ceil(F k / nparts)
+        lo = bound(part); hi = bound(part + 1);
+    }
+    *first = lo; *count = hi > lo ? hi - lo : 0;
+}
+
+void rt_engine::region_step_part(int i, float g, double isa, double ibg, bool xl, bool elide, bool defer_blend, int part, int nparts, int* first,
+                                 int* count, int* plan_info) {
+    FwdIn in; StepArgs a; bool blend_deferred, inject;
+    region_plan(i, g, isa, ibg, xl, elide, defer_blend, in, a, blend_deferred, inject);
+    region_split_range(in.B, a.s_tref, inject, part, nparts, first, count);
+    if (plan_info) { plan_info[0] = in.B; plan_info[1] = a.s_tref; plan_info[2] = inject ? 1 : 0; }      // what rt_op_split_range needs for the other parts' ranges
+    if (*count == 0) return;
+    FwdIn sub{}; sub.h = in.h; sub.w = in.w; sub.t = in.t; sub.B = *count;
+    sub.eps_out = eps + (size_t)*first * lat_h * lat_w * 4;          // the range is contiguous: its predictions land in their own slots
+    for (int b = 0; b < *count; ++b) {
+        const int s = *first + b;
+        sub.x[b] = in.x[s]; sub.scale[b] = in.scale[s]; sub.prompt[b] = in.prompt[s]; sub.fontsize[b] = in.fontsize[s];
+        RT_REQUIRE(in.qk_src[s] >= *first && in.qk_src[s] < *first + *count, "split: a stream's Q / K source lies outside its part");
+        sub.qk_src[b] = in.qk_src[s] - *first;
+        sub.res_src[b] = in.res_src[s] < 0 ? -1 : in.res_src[s] - *first;
+    }
+    unet_forward(sub);
+}
+
+void rt_engine::region_step_finish(int i, float g, double isa, double ibg, bool xl, bool elide, bool defer_blend) {
+    FwdIn in; StepArgs a; bool blend_deferred, inject;
+    region_plan(i, g, isa, ibg, xl, elide, defer_blend, in, a, blend_deferred, inject);
+    region_finish(i, a, blend_deferred);
 }
 
 void rt_engine::plain_step(int i, float g) {

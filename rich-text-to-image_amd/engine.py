@@ -71,6 +71,7 @@ _SYMBOLS = [
     "rt_vae_last_error", "rt_vae_weight_count", "rt_vae_weight_info", "rt_vae_bind_weight", "rt_vae_synchronize", "rt_vae_decode",
     "rt_vae_color_guidance", "rt_vae_arena_info", "rt_vae_arena_mark_bound", "rt_op_cast_bf16", "rt_op_attention_probs_avg", "rt_op_embed", "rt_op_activation", "rt_op_causal_attention",
     "rt_op_cross_attn_block", "rt_op_gemm16_variant", "rt_op_gemm16_pick", "rt_profile_read2", "rt_op_gemm_qk_vt", "rt_op_gemm_pair_pick",
+    "rt_region_step_part", "rt_region_step_finish", "rt_eps_info", "rt_op_split_range",
 ]
 
 
@@ -344,6 +345,25 @@ class Engine:
     def region_step(self, i, guidance_scale, inject_selfattn=0.0, inject_background=0.0, xl=True, elide=False, defer_blend=False):
         self._chk(self.lib.rt_region_step(self.h, i, C.c_float(guidance_scale), C.c_double(inject_selfattn),
                                           C.c_double(inject_background), int(xl), int(bool(elide)) | (2 if defer_blend else 0)))
+
+    # ---- intra-image split of a step over the ranks of a process group (launcher.split_region_step drives these)
+    def region_step_part(self, i, guidance_scale, inject_selfattn, inject_background, xl, part, nparts, elide=False, defer_blend=False):
+        """The UNet forwards of this rank's contiguous stream range of step i -> (first_stream, n_streams, (streams of the step, its
+        text_ref stream or -1, injection on))."""
+        first, count, info = C.c_int(), C.c_int(), (C.c_int * 3)()
+        self._chk(self.lib.rt_region_step_part(self.h, i, C.c_float(guidance_scale), C.c_double(inject_selfattn), C.c_double(inject_background),
+                                               int(xl), int(bool(elide)) | (2 if defer_blend else 0), part, nparts, C.byref(first), C.byref(count), info))
+        return first.value, count.value, (info[0], info[1], bool(info[2]))
+
+    def region_step_finish(self, i, guidance_scale, inject_selfattn, inject_background, xl, elide=False, defer_blend=False):
+        self._chk(self.lib.rt_region_step_finish(self.h, i, C.c_float(guidance_scale), C.c_double(inject_selfattn), C.c_double(inject_background),
+                                                 int(xl), int(bool(elide)) | (2 if defer_blend else 0)))
+
+    def eps_info(self):
+        """(device pointer, bytes per stream, max streams) of the noise-prediction buffer [max_streams][h*w][4] fp32."""
+        p, b, m = C.c_void_p(), C.c_uint64(), C.c_int()
+        self._chk(self.lib.rt_eps_info(self.h, C.byref(p), C.byref(b), C.byref(m)))
+        return p.value, b.value, m.value
 
     def background_blend(self):
         self._chk(self.lib.rt_background_blend(self.h))

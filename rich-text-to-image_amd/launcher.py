@@ -194,3 +194,49 @@ def max_over_ranks(value, device="cpu"):
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
+
+
+# ---------------------------------------------------------------------------------------------- intra-image split (SURVEY 8e / 8f f4)
+def split_ranges(n_streams, text_ref_stream, inject, nparts):
+    """[(first, count)] per part: the rule of csrc/step_driver.inl::region_split_range (host-only query of the C ABI)."""
+    import ctypes as C
+    from .engine import load_library
+    lib = load_library()
+    out = []
+    for part in range(nparts):
+        first, count = C.c_int(), C.c_int()
+        rc = lib.rt_op_split_range(n_streams, text_ref_stream, int(bool(inject)), part, nparts, C.byref(first), C.byref(count))
+        if rc != 0:
+            raise ValueError(lib.rt_op_last_error().decode())
+        out.append((first.value, count.value))
+    return out
+
+
+def eps_tensor(engine):
+    """The engine's noise-prediction buffer as a flat uint8 tensor (no copy) + bytes per stream."""
+    ptr, per, nmax = engine.eps_info()
+    return torch.as_tensor(_DevicePointer(ptr, per * nmax), device=f"cuda:{engine.device}"), per
+
+
+def split_region_step(engine, i, guidance_scale, inject_selfattn, inject_background, xl, elide=False, defer_blend=False):
+    """ONE rich-text step of ONE image on all ranks of the process group: every rank holds the same engine state, runs the UNet forwards
+    of its contiguous range of the step's streams (text_ref and the region streams that inject from it always share the last range, so
+    nothing crosses GPUs inside a forward), the ranks exchange their slices of the noise predictions - one broadcast per rank, 1.8 MB
+    in total at SDXL - and every rank runs the step epilogue on the full set.  Bit-identical with engine.region_step on one GPU
+    (a stream's forward does not depend on the other streams of its launch).  Returns the ranges [(first, count)] per rank."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    if world == 1:
+        engine.region_step(i, guidance_scale, inject_selfattn, inject_background, xl=xl, elide=elide, defer_blend=defer_blend)
+        return [(0, -1)]
+    first, count, (n_streams, s_tref, inject) = engine.region_step_part(i, guidance_scale, inject_selfattn, inject_background, xl, rank, world,
+                                                                          elide=elide, defer_blend=defer_blend)
+    ranges = split_ranges(n_streams, s_tref, inject, world)          # a function of the step alone: no collective needed to agree on it
+    assert ranges[rank] == (first, count)
+    engine.synchronize()
+    eps, per = eps_tensor(engine)
+    for r, (f, c) in enumerate(ranges):
+        if c > 0:
+            broadcast_tensor(eps[f * per:(f + c) * per], src=r)
+    engine.region_step_finish(i, guidance_scale, inject_selfattn, inject_background, xl, elide=elide, defer_blend=defer_blend)
+    return ranges

@@ -89,8 +89,12 @@ class RegionDiffusion:
         eng.set_schedule(1, self.scheduler.timesteps.tolist(), self.scheduler.table(), num_inference_steps)
         eng.set_latents(latents.to(self.device))
         for i, t in enumerate(self.scheduler.timesteps):
-            eng.region_step(i, guidance_scale, inject_selfattn, inject_background, xl=False, elide=elide_dead_forwards,
-                            defer_blend=use_guidance)
+            if getattr(self, "split_image", False):      # intra-image split over the ranks of the process group (launcher.split_region_step)
+                from .launcher import split_region_step
+                split_region_step(eng, i, guidance_scale, inject_selfattn, inject_background, False, elide=elide_dead_forwards, defer_blend=use_guidance)
+            else:
+                eng.region_step(i, guidance_scale, inject_selfattn, inject_background, xl=False, elide=elide_dead_forwards,
+                                defer_blend=use_guidance)
             if use_guidance:
                 if t < tfd['guidance_start_step']:                           # rd.py:151
                     lat_ptr, eps_ptr = eng.state_ptrs()

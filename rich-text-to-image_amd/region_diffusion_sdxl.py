@@ -105,8 +105,14 @@ class RegionDiffusionXL:
             tfd = text_format_dict or {}
             eng.set_fontsize(tfd.get("word_pos"), tfd.get("font_size"))
             for i in range(n):
-                eng.region_step(i, guidance_scale, inject_selfattn, inject_background, xl=True, elide=elide_dead_forwards,
-                                defer_blend=use_guidance)
+                if getattr(self, "split_image", False):
+                    # intra-image split (launcher.split_region_step): the ranks of the process group share THIS image's step - each runs
+                    # the forwards of its stream range, one exchange of the noise predictions, every rank finishes the step
+                    from .launcher import split_region_step
+                    split_region_step(eng, i, guidance_scale, inject_selfattn, inject_background, True, elide=elide_dead_forwards, defer_blend=use_guidance)
+                else:
+                    eng.region_step(i, guidance_scale, inject_selfattn, inject_background, xl=True, elide=elide_dead_forwards,
+                                    defer_blend=use_guidance)
                 if use_guidance:
                     t = float(self.scheduler.timesteps[i])
                     if t < tfd['guidance_start_step']:                   # xl.py:849; predict_x0 on the unscaled Euler latents (quirk 4)

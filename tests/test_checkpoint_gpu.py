@@ -176,6 +176,33 @@ def test_sample_cli_two_ranks_receive_the_pipeline_by_broadcast(tmp_path):
         assert open(tmp_path / "out2" / f"req1_seed2_{kind}.jpg", "rb").read() == open(tmp_path / "out1" / f"seed2_{kind}.jpg", "rb").read(), kind
 
 
+def test_sample_cli_split_image_two_ranks_share_one_image(tmp_path):
+    """`--gpus 2 --split_image` (intra-image split): the two ranks work on the SAME request - every rich-text step's
+    forwards are cut into two contiguous stream ranges ({uncond, base, uncond_ref} | {text_ref, regions} while the injection is on: the
+    streams that inject from text_ref stay with it, so nothing crosses ranks inside a forward), the ranks exchange their slices of the
+    noise predictions (launcher.split_region_step: one broadcast per rank and step) and both finish the step.  Real engines, two ranks on
+    ONE GPU over gloo (as above).  The image rank 0 writes must be byte-identical to the one-process run: a stream's forward does not
+    depend on the other streams of its launch."""
+    import subprocess
+    import sys
+    from rich_text_to_image_amd import sample
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    _write_dir(str(tmp_path / "ckpt"))
+    ja = json.dumps({"ops": [{"insert": "a "}, {"attributes": {"link": "a wooden fence covered in snow"}, "insert": "fence"}, {"insert": " and a "},
+                             {"attributes": {"font": "slabo"}, "insert": "barn"}, {"insert": " under a night sky\n"}]})
+    (tmp_path / "a.json").write_text(ja)
+    common = ["--load_path", str(tmp_path / "ckpt"), "--model", "SD", "--sample_steps", "12", "--num_segments", "4", "--inject_selfattn", "0.5"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(PYTHONPATH=root + os.pathsep + env.get("PYTHONPATH", ""), RTDIFF_DIST_BACKEND="gloo", RTDIFF_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "rich_text_to_image_amd.sample", "--gpus", "2", "--split_image", "--rich_text_json", str(tmp_path / "a.json"),
+                        "--seeds", "3", "--run_dir", str(tmp_path / "out2")] + common, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "[rank 0] request 0 seed 3" in r.stdout and "[rank 1] request 0 seed 3" in r.stdout          # both ranks ran the one request
+    sample.main(["--rich_text_json", ja, "--seed", "3", "--run_dir", str(tmp_path / "out1")] + common)
+    for kind in ("plain", "rich"):
+        assert open(tmp_path / "out2" / f"seed3_{kind}.jpg", "rb").read() == open(tmp_path / "out1" / f"seed3_{kind}.jpg", "rb").read(), kind
+
+
 def test_lora_checkpoint_merged_at_load_matches_oracle_on_merged_weights(tmp_path):
     """SURVEY 8f row f4 (sample.py:29-30 AnimeXL / README.md:21-22 LoRA checkpoints): a kohya-layout LoRA file merged by
     `load_pipeline(lora_path=...)` must make the ENGINE compute what the oracle computes on explicitly merged weights, and must

@@ -142,3 +142,23 @@ def test_text_encoder_empty_state_dict_has_the_shapes_of_a_real_one():
     norm = lambda k: k if k.startswith("text_model.") or k.startswith("text_projection") else "text_model." + k
     real = {norm(k): tuple(v.shape) for k, v in real.items() if "position_ids" not in k}
     assert {k: tuple(v.shape) for k, v in mine.items()} == real
+
+
+def test_intra_image_split_keeps_injecting_streams_with_their_source():
+    """The stream ranges of launcher.split_region_step (csrc/step_driver.inl::region_split_range through the host-only C-ABI query):
+    contiguous, disjoint, covering every stream of the step; while the injection is on, text_ref and all region streams (which read its
+    self-attention Q / K and ResNet feature layer by layer) share the LAST range, and the independent streams before it are dealt
+    evenly to the other ranks."""
+    from rich_text_to_image_amd.launcher import split_ranges
+    for F, s_tref, inject in ((7, 3, True), (7, 3, False), (5, -1, False), (11, 3, True), (2, -1, False), (4, 3, True)):
+        for nparts in (1, 2, 3, 4):
+            r = split_ranges(F, s_tref, inject, nparts)
+            assert len(r) == nparts and r[0][0] == 0 and sum(c for _, c in r) == F
+            for (f0, c0), (f1, _) in zip(r, r[1:]):
+                assert f0 + c0 == f1                                   # contiguous, in order
+            if inject and nparts > 1:
+                assert r[-1] == (s_tref, F - s_tref)                   # text_ref + regions together
+                assert max(c for _, c in r[:-1]) - min(c for _, c in r[:-1]) <= 1
+            elif nparts > 1:
+                assert max(c for _, c in r) - min(c for _, c in r) <= 1
+    assert split_ranges(7, 3, True, 2) == [(0, 3), (3, 4)]            # config 3: {uncond, base, uncond_ref} | {text_ref, 3 regions}
