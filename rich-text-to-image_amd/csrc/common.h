@@ -177,7 +177,7 @@ void gemm_set_debug(int d);        // bit 0: eligible 3x3 convolutions through t
 bool gemm_xblock_enabled();       // the one-launch cross-attention block (xblock.hip) is switched on (debug bit 16 SET - opt-in; gemm16 on, no forced configuration)
 bool gemm_xattn_enabled();         // the fused to_q + cross-attention kernel is allowed (debug bit 4 clear, gemm16 on, no forced configuration)
 // gemm16.hip: 16x16x32-MFMA family (224-row tiles, intra-tile K split); dense problems with K % 64 == 0 only
-#define RT_G16_NVAR 13
+#define RT_G16_NVAR 14
 bool gemm16_supported(const GemmArgs& a);
 int gemm16_pick(const GemmArgs& a, int weights_on_rows, int* wstat);      // variant id or -1; pure function of the shape
 void launch_gemm16_variant(const GemmArgs& a, int variant, int wstat, hipStream_t st);

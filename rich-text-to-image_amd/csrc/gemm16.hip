@@ -267,7 +267,7 @@ static __device__ __forceinline__ void gemm16_tile(const GemmArgs& p, const int 
 }
 
 template <int MODE, int EPI, int TMW, int TNW, int WM, int WN, int WK, int S>
-__global__ __launch_bounds__(WM * WN * WK * 64) void gemm16_kernel(GemmArgs p, int wstat) {
+__global__ __launch_bounds__(WM * WN * WK * 64, (WM * WN * WK == 4) ? 2 : 1) void gemm16_kernel(GemmArgs p, int wstat) {     // (four-wave forms: two workgroups per CU)
     const unsigned bid_in = blockIdx.x;
 #include "gemm16_body.inl"
 }
@@ -302,6 +302,7 @@ static const G16Var kVar[RT_G16_NVAR] = {
     {128, 320, 1, 2, 0},   // 10 class A, 320 columns, 128 rows  } the 640-channel level of the same small batches (its class is A whatever
     {64, 320, 1, 3, 0},    // 11 class A, 320 columns, 64 rows   } the batch: 224-row tiles give 74 workgroups for 2 streams)
     {160, 64, 2, 3, 0},    // 12 class B transposed, 64 token columns (V^T of the same small batches)
+    {128, 160, 1, 2, 0},   // 13 (round 5 probe) FOUR waves, 73.7 KB of LDS: two workgroups per CU whose phases interleave (class A arithmetic: no K split)
     // (measured and dropped, profiles/r3_gemm16_probe_v2_timing.txt: FOUR-wave forms of 224x160 / 224x320 / 224x256 - one wave per
     //  SIMD with its accumulators in AGPRs, no K split / no exchange - run their K loop at 46 k instead of 25.5 k cycles: a single
     //  compiler-scheduled wave does not keep the matrix pipe fed.  The kernel template still takes WM*WN*WK == 4.)
@@ -346,6 +347,7 @@ static void launch_e(const GemmArgs& a, int v, int wstat, hipStream_t st) {
                 case 10: launch_v<MODE, EPI, 4, 5, 2, 4, 1, 2>(a, wstat, st); return;
                 case 11: launch_v<MODE, EPI, 2, 5, 2, 4, 1, 3>(a, wstat, st); return;
                 case 12: launch_v<MODE, EPI, 5, 2, 2, 2, 2, 3>(a, wstat, st); return;
+                case 13: launch_v<MODE, EPI, 4, 5, 2, 2, 1, 2>(a, wstat, st); return;
                 default: break;
             }
         }

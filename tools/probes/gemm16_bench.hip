@@ -3,7 +3,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -DRT_PROBE tools/probes/gemm16_bench.hip \
 //         rich-text-to-image_amd/csrc/gemm16.hip -o tools/probes/gemm16_bench        (two translation units)
 #include "../../rich-text-to-image_amd/csrc/gemm.hip"
-static const struct { int BM, BN; } kVar[RT_G16_NVAR] = {{224, 160}, {128, 160}, {224, 256}, {256, 256}, {224, 320}, {256, 320}, {160, 224}, {160, 128}, {128, 256}, {64, 160}, {128, 320}, {64, 320}, {160, 64}};
+static const struct { int BM, BN; } kVar[RT_G16_NVAR] = {{224, 160}, {128, 160}, {224, 256}, {256, 256}, {224, 320}, {256, 320}, {160, 224}, {160, 128}, {128, 256}, {64, 160}, {128, 320}, {64, 320}, {160, 64}, {128, 160}};
 #include <vector>
 #include <cstring>
 #include <cmath>
@@ -52,15 +52,15 @@ int main(int argc, char** argv) {
 
     // name, M, N, K, epi, residual, weights_on_rows, {old configs}, {new variants}, try wstat 0 and 1
     const Case cases[] = {
-        {"attn.to_out / to_q 1280 (f16 trunk + res)", 7168, 1280, 1280, EPI_F16, 1, 0, {2, -1, -1}, {0, -1, 1, -1, -1, -1}, 0},
+        {"attn.to_out / to_q 1280 (f16 trunk + res)", 7168, 1280, 1280, EPI_F16, 1, 0, {2, -1, -1}, {0, 13, 1, -1, -1, -1}, 0},
         {"to_out 1280 (f16 trunk, NO residual)", 7168, 1280, 1280, EPI_F16, 0, 0, {2, -1, -1}, {0, -1, -1, -1, -1, -1}, 0},
-        {"attn2.to_q 1280 (bf16)", 7168, 1280, 1280, EPI_BF16, 0, 0, {2, -1, -1}, {0, -1, -1, -1, -1, -1}, 0},
-        {"ff.net.2 1280 (K = 5120, f16 + res)", 7168, 1280, 5120, EPI_F16, 1, 0, {2, -1, -1}, {0, -1, -1, -1, -1, -1}, 0},
+        {"attn2.to_q 1280 (bf16)", 7168, 1280, 1280, EPI_BF16, 0, 0, {2, -1, -1}, {0, 13, -1, -1, -1, -1}, 0},
+        {"ff.net.2 1280 (K = 5120, f16 + res)", 7168, 1280, 5120, EPI_F16, 1, 0, {2, -1, -1}, {0, 13, -1, -1, -1, -1}, 0},
         {"attn1 Q|K 1280 (N = 2560)", 7168, 2560, 1280, EPI_BF16, 0, 0, {2, -1, -1}, {0, -1, 4, -1, 2, -1}, 0},
         {"attn1 Q|K 1280, 4 streams", 4096, 2560, 1280, EPI_BF16, 0, 0, {2, -1, -1}, {4, 1, 3, -1, -1, -1}, 0},
         {"GEGLU 1280", 7168, 10240, 1280, EPI_GEGLU, 0, 0, {3, -1, -1}, {2, -1, 3, -1, -1, -1}, 1},
         {"GEGLU 640", 28672, 5120, 640, EPI_GEGLU, 0, 0, {3, -1, -1}, {2, -1, 3, -1, -1, -1}, 0},
-        {"to_out / to_q 640 (f16 + res)", 28672, 640, 640, EPI_F16, 1, 0, {8, -1, -1}, {0, 4, -1, -1, -1, -1}, 0},
+        {"to_out / to_q 640 (f16 + res)", 28672, 640, 640, EPI_F16, 1, 0, {8, -1, -1}, {0, 4, 13, -1, -1, -1}, 0},
         {"to_q 640 (bf16)", 28672, 640, 640, EPI_BF16, 0, 0, {8, -1, -1}, {0, 4, -1, -1, -1, -1}, 0},
         {"ff.net.2 640 (K = 2560)", 28672, 640, 2560, EPI_F16, 1, 0, {8, -1, -1}, {0, 4, -1, -1, -1, -1}, 0},
         {"attn1 Q|K 640 (N = 1280)", 28672, 1280, 640, EPI_BF16, 0, 0, {8, -1, -1}, {0, 4, 2, -1, -1, -1}, 0},
