@@ -497,6 +497,13 @@ void launch_attn_store(const AttnStoreArgs& a, hipStream_t st) {
         HIP_CHECK(hipGetLastError());
         return;
     }
+    if (a.stats && a.stats_ready && a.DP == 64 && a.NKpad % 32 == 0 && a.NKpad <= 1024 && !g_store_apply_v1 && !(g_store_legacy & 3) &&
+        (long)a.NKrows * a.ldk * 2 < 0x7fffffffL) {
+        // small maps (the N x 77 cross maps) whose attention launch left the statistics (cross77_kernel, AttnArgs.stats): the apply kernel alone
+        hipLaunchKernelGGL(attn_store_apply2_kernel, dim3(cdiv(a.N, 64), cdiv(a.NKpad, 16 * AS2_MT)), dim3(256), 0, st, a);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     if (a.NKpad <= 1024 && a.NKpad % 16 == 0 && !(g_store_legacy & 1)) {
         // every map the token-map producer consumes (32x32 self maps, N x 77 cross maps; attention_utils.py:243-248): one pass,
         // 8 waves per 16 query rows

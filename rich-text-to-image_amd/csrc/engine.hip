@@ -125,6 +125,8 @@ struct FwdIn {
     int store_stream = -1;       // stream whose head-averaged attention maps are recorded (plain pass: the conditional one)
 };
 
+extern int g_store_own_stats;
+static inline bool g_store_own_stats_flag() { return g_store_own_stats != 0; }
 // step epilogue kernels (defined in step.hip)
 struct StepArgs;
 void launch_step_epilogue(const StepArgs& a, hipStream_t st);
@@ -610,6 +612,10 @@ struct rt_engine {
                     for (int b = 0; b < B; ++b) { a.q_src[b] = b; a.k_src[b] = in.prompt[b]; a.v_src[b] = in.prompt[b]; a.wset[b] = in.fontsize[b] ? 1 : -1; }      // -1: plain softmax, no multiplier tables
                     a.wabs = wabs; a.wsgn = wsgn;
                     a.B = B; a.H = t.heads; a.N = HW; a.NK = 96; a.nk_valid = 77; a.DP = t.DP; a.cross = 1;
+                    // a recorded layer on cross77_kernel: the launch leaves the softmax statistics of the recorded stream (as the self-attention
+                    // launch does for attn1), the store runs its apply kernel only
+                    const bool stats2 = c77 && capture2 && k.store_calls[1] + 1 > 10 && !g_store_own_stats_flag();
+                    if (stats2) { a.stats = store_stats; a.stats_b = in.store_stream; }
                     prof_begin(RT_PROF_ATTN_CROSS, 4.0 * B * t.heads * (double)HW * 77 * t.d);
                     if (c77) launch_cross77(a, stream); else launch_attention(a, stream);
                     prof_end();
@@ -619,6 +625,7 @@ struct rt_engine {
                         sa.K = k.kcache; sa.ldk = HD; sa.k_row0 = (long)in.prompt[in.store_stream] * 96;
                         sa.out = k.store[1]; sa.H = t.heads; sa.N = HW; sa.NK = 77; sa.NKpad = 96; sa.NKrows = 96; sa.DP = t.DP;
                         sa.overwrite = k.store_mode[1] == 2;
+                        if (stats2) { sa.stats = store_stats; sa.stats_ready = 1; }
                         prof_begin(RT_PROF_ATTN_STORE, 2.0 * 2.0 * t.heads * (double)HW * 77 * t.d, 8.0 * HW * 77 + 2.0 * (HW + 96.0) * HD);
                         launch_attn_store(sa, stream);
                         prof_end();
@@ -1199,7 +1206,6 @@ int rt_op_split_range(int n_streams, int text_ref_stream, int inject, int part, 
     OP_TRY({ RT_REQUIRE(first && count, "rt_op_split_range: null outputs"); region_split_range(n_streams, text_ref_stream, inject != 0, part, nparts, first, count); })
 }
 extern int g_store_legacy;
-extern int g_store_own_stats;
 extern int g_store_apply_v1;
 extern int g_c77_t1;
 int rt_op_gemm_debug(int d) { gemm_set_debug(d); g_store_own_stats = (d >> 17) & 1; g_store_apply_v1 = (d >> 18) & 1; g_c77_t1 = (d >> 20) & 3; g_store_legacy = ((d & 32) ? 1 : 0) | ((d & 64) ? 2 : 0); attention_set_prio(((d >> 14) & 1) ^ 1); return RT_OK; }

@@ -485,6 +485,9 @@ __global__ __launch_bounds__(256, HPW == 2 ? 3 : 4) void cross77_kernel(AttnArgs
                 sum2 += f32x2{s[t][j][0], s[t][j][1]} + f32x2{s[t][j][2], s[t][j][3]};
             }
             inv[t] = 1.f / xb_rowsum(sum2.x + sum2.y);
+            // token-map capture (plain pass): P(q, k) = exp2(s_k - mx) / sum for the valid keys of this head - what attn_store_apply2_kernel needs
+            if (p.stats != nullptr && b == p.stats_b && q4 == 0)
+                ((float2*)p.stats)[(size_t)(hg * HPW + h2) * p.N + (q0 - l15) + t * 16 + l15] = make_float2(mx, inv[t] / (float)p.H);
             if (fs) {                                                // sign of a negative font size on the normalised probability
 #pragma unroll
                 for (int j = 0; j < 5; ++j) s[t][j] = s[t][j] * *(const f32x4*)(tab + 96 + (j < 4 ? 32 * (j >> 1) + 8 * q4 + 4 * (j & 1) : 64 + 4 * q4));
