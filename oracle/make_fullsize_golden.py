@@ -47,7 +47,27 @@ CASES = {
                        word_pos=[5, 6], font_size=[20.0, 20.0], checkpoints=[1, 2, 5, 10, 15, 20, 25, 26, 30, 35, 40, 45, 50]),
     "config5": dict(model="sdxl", hw=128, R=4, steps=4, gs=7.5, isa=0.0, ibg=0.5, guided=True, unet_seed=103, vae_seed=203, seed=305,
                     word_pos=[4], font_size=[8.0], n_color=1, color_weight=20.0, checkpoints=[1, 2, 3, 4]),
+    # round 6: the cases at BASELINE's own shape, and a regime in which the accumulated update dominates the start noise
+    # config3_unit: config3_50 started from UNIT-variance latents (`latents` handed over at 1 / init_noise_sigma, so prepare_latents'
+    #   multiplication, xl.py:536, gives std 1 instead of 14.6): sum_k (sigma_k+1 - sigma_k) eps_k is then an order of magnitude above lat0
+    #   and a relative error of the latents IS a relative error of the update.
+    "config3_unit": dict(model="sdxl", hw=128, R=4, steps=50, gs=5.0, isa=0.5, ibg=0.0, guided=False, unet_seed=103, vae_seed=203, seed=303,
+                         word_pos=[5, 6], font_size=[20.0, 20.0], unit_start=True, checkpoints=[1, 2, 5, 10, 15, 20, 25, 26, 30, 35, 40, 45, 50]),
+    # config2_50: BASELINE config 2 at its own length - 50 requested steps = 51 PLMS iterations, 4 regions, colour guidance on 2 regions
+    #   (weight 20 as in `config2`, not BASELINE's 1: with seeded random weights the gradient is small, and a guidance term below the bf16 noise would test nothing)
+    "config2_50": dict(model="sd15", hw=64, R=4, steps=50, gs=7.5, isa=0.0, ibg=0.0, guided=True, unet_seed=101, vae_seed=201, seed=302,
+                       word_pos=[2], font_size=[3.0], n_color=2, color_weight=20.0, checkpoints=[1, 2, 3, 6, 11, 21, 31, 41, 51]),
+    # config5_50: BASELINE config 5 on its 50-step schedule, "10 segments" = 10 Voronoi cells on 32 x 32 dealt to the 4 regions,
+    #   footnote (font size) + colour guidance, inject_background 0.5 => blend after loop index 25 (xl.py:870); the loop is stopped after
+    #   iteration 30 (`stop_after`: 8 forwards + one fp32 VAE forward / backward per step cost ~3 CPU-minutes each in the build container)
+    "config5_50": dict(model="sdxl", hw=128, R=4, steps=50, gs=7.5, isa=0.0, ibg=0.5, guided=True, unet_seed=103, vae_seed=203, seed=305,
+                       word_pos=[4], font_size=[8.0], n_color=1, color_weight=20.0, masks="voronoi10", stop_after=30,
+                       checkpoints=[1, 2, 5, 10, 15, 20, 25, 26, 27, 30]),
 }
+
+
+class StopLoop(Exception):
+    """Raised by the trace / callback of a `stop_after` case to leave the loop after the last recorded iteration."""
 
 
 def smooth_masks(R, hw, g):
@@ -55,6 +75,22 @@ def smooth_masks(R, hw, g):
     m = torch.softmax(torch.randn(R, 1, hw // 4, hw // 4, generator=g) * 4, dim=0)
     m = torch.nn.functional.interpolate(m, size=(hw, hw), mode="bilinear", align_corners=False)
     return (m / (m.sum(0, keepdim=True) + 1e-8)).repeat(1, 4, 1, 1)
+
+
+def voronoi_masks(R, hw, g, cells=10, grid=32):
+    """`num_segments = 10` of BASELINE config 5: 10 Voronoi cells on the 32 x 32 self-attention grid, every region owning
+    at least one, then exactly what get_token_maps does with its binary cluster maps (attention_utils.py:322-327): bicubic antialiased
+    resize to the latent size, clamp(0, 1), division by the sum over regions + 1e-8.  4 identical channels; last mask = background."""
+    pts = torch.rand(cells, 2, generator=g) * grid
+    owner = torch.cat([torch.arange(R), torch.randint(0, R, (cells - R,), generator=g)])[torch.randperm(cells, generator=g)]
+    yy, xx = torch.meshgrid(torch.arange(grid) + 0.5, torch.arange(grid) + 0.5, indexing="ij")
+    d = (yy[None] - pts[:, 0, None, None]) ** 2 + (xx[None] - pts[:, 1, None, None]) ** 2
+    region = owner[d.argmin(0)]                                                   # [grid, grid] region index per cell of the grid
+    maps = torch.stack([(region == r).to(torch.float64) for r in range(R)])      # binary, float64 like the numpy maps of the reference
+    assert all(m.sum() > 0 for m in maps)
+    m = torch.cat([torch.nn.functional.interpolate(t[None, None], (hw, hw), mode="bicubic", antialias=True)[0] for t in maps]).clamp(0, 1)
+    m = m / (m.sum(0, True) + 1e-8)
+    return m.float().unsqueeze(1).repeat(1, 4, 1, 1)
 
 
 def case_inputs(name):
@@ -67,8 +103,11 @@ def case_inputs(name):
     if xl:
         d["pooled"] = torch.randn(R + 1, 1280, generator=g)
         d["time_ids"] = torch.tensor([[8.0 * hw, 8.0 * hw, 0, 0, 8.0 * hw, 8.0 * hw]])
-    d["masks"] = smooth_masks(R, hw, g)
+    d["masks"] = voronoi_masks(R, hw, g) if c.get("masks") == "voronoi10" else smooth_masks(R, hw, g)
     d["latents"] = torch.randn(1, 4, hw, hw, generator=g)                 # unscaled: prepare_latents multiplies by init_noise_sigma (xl.py:533-536)
+    if c.get("unit_start"):
+        sched = OracleEuler(); sched.set_timesteps(c["steps"])
+        d["latents"] = d["latents"] / sched.init_noise_sigma                  # what the caller hands to `sample(latents=...)`
     tfd = {"word_pos": torch.tensor(c["word_pos"]), "font_size": torch.tensor(c["font_size"])}
     if c["guided"]:
         n = c["n_color"]
@@ -119,20 +158,27 @@ def run_case(name):
     masks = [m[r:r + 1] for r in range(c["R"])]
     guidance = {"vae": vae, "scaling": vcfg["scaling_factor"]} if c["guided"] else None
 
+    stop_after = c.get("stop_after")
+
     class Progress(list):                                                  # the loops append one latent per iteration
         def append(self, x):
             super().append(x)
             print(f"[{name}] iteration {len(self)} done at {time.perf_counter() - t0:.0f} s, latent std {x.std():.4f}", flush=True)
+            if stop_after and len(self) == stop_after:
+                raise StopLoop
     trace = Progress()
-    if xl:
-        sched = OracleEuler(); sched.set_timesteps(c["steps"])
-        lat0 = inp["latents"] * sched.init_noise_sigma
-        final = rich_loop_xl(unet, OracleEuler(), inp["emb"], inp["pooled"], inp["time_ids"], masks, lat0, c["steps"], c["gs"], inp["tfd"],
-                             c["isa"], c["ibg"], use_guidance=c["guided"], guidance=guidance, trace=trace)
-    else:
-        lat0 = inp["latents"]
-        final = rich_loop_sd(unet, OraclePNDM(), inp["emb"], masks, lat0, c["steps"], c["gs"], inp["tfd"], c["isa"], c["ibg"],
-                             use_guidance=c["guided"], guidance=guidance, trace=trace)
+    try:
+        if xl:
+            sched = OracleEuler(); sched.set_timesteps(c["steps"])
+            lat0 = inp["latents"] * sched.init_noise_sigma
+            final = rich_loop_xl(unet, OracleEuler(), inp["emb"], inp["pooled"], inp["time_ids"], masks, lat0, c["steps"], c["gs"], inp["tfd"],
+                                 c["isa"], c["ibg"], use_guidance=c["guided"], guidance=guidance, trace=trace)
+        else:
+            lat0 = inp["latents"]
+            final = rich_loop_sd(unet, OraclePNDM(), inp["emb"], masks, lat0, c["steps"], c["gs"], inp["tfd"], c["isa"], c["ibg"],
+                                 use_guidance=c["guided"], guidance=guidance, trace=trace)
+    except StopLoop:
+        final = trace[-1]
     assert torch.equal(final, trace[-1]) and len(trace) == c["checkpoints"][-1], (len(trace), c["checkpoints"])
     with torch.no_grad():
         image = to_uint8(vae.decode(final / vcfg["scaling_factor"]))

@@ -150,7 +150,24 @@ struct GemmArgs {
     int xa_nk_valid;                 // keys >= xa_nk_valid of the 96 cached rows are masked (77)
     const float* xa_wabs; const float* xa_wsgn;      // [nsets, 96] font-size multipliers (attention_processor.py:386-401)
     int xa_prompt[RT_MAXB], xa_wset[RT_MAXB];        // per stream: prompt index into the cache, multiplier set (-1: plain softmax)
+    // LayerNorm folded into the projections (gemm16.hip, "LNF"; models/attention.py:150,168,181).
+    //  consumer (ln_part != null; EPI_BF16 / EPI_GEGLU on the 16x16x32 family only): the token operand (A, or W when weights_on_rows) is the
+    //    RAW fp16 trunk, the weight operand is W' = fp16(gamma W) (ln_fold_derive), `bias` = c = b + W beta, ln_s = row sums of W';
+    //    out = rstd (x W'^T - mu s) + c with (mu, rstd) of every token from ln_part [tokens][ln_npart] float2 (sum, sum of squares)
+    //  producer (ln_emit != null; EPI_F16 on the 16x16x32 family's 80-column wave tiles): leaves those partials of its OUTPUT rows
+    const float* ln_part; int ln_npart;
+    const float* ln_s;
+    float ln_inv_c, ln_eps;
+    float* ln_emit;
 };
+// LayerNorm fold plumbing (host-only predicates are pure functions of the shape, like every routing decision)
+int gemm_route16(const GemmArgs& a);                    // variant of the 16x16x32 family launch_gemm would take for this problem, -1: another route
+bool gemm_ln_emit_ok(const GemmArgs& a);                // launch_gemm(a) with a.ln_emit set would leave the partials (EPI_F16, 80-column wave tiles, N % 640 == 0)
+bool gemm_ln_fold_ok(const GemmArgs& a);                // launch_gemm(a) with a.ln_part set has a folded instantiation
+bool gemm16_ln_variant_ok(const GemmArgs& a, int v);    // gemm16.hip: variant v has the LayerNorm-fold instantiation a.ln_part / a.ln_emit ask for
+void launch_ln_partials(const f16_t* x, float* part, int rows, int C, hipStream_t st);      // stand-alone producer of the same partials (norm.hip)
+void launch_ln_fold_derive(const bf16_t* W, int ldw, const float* bias, const float* gamma, const float* beta, int N, int K,
+                           f16_t* Wf, float* s, float* c, hipStream_t st);                 // W' = fp16(gamma W), s = row sums of W', c = bias + W beta
 // Fused to_q -> 77-key cross-attention (one launch instead of two; Q never reaches HBM).  Eligible: head dim 64, H * 64 % 320 == 0,
 // tokens % 128 == 0, C % 64 == 0, C >= 192.
 bool xattn_fused_supported(int C, int H, int DP, int tokens);
@@ -174,6 +191,7 @@ bool gemm_pair_output_ok(const GemmArgs& a);            // host-only: launch_gem
 size_t gemm_splitk_scratch_floats(const GemmArgs& a);   // fp32 partial sums launch_gemm needs for this problem (0: not split)
 void gemm_force_config(int cfg);   // -1: shape-based choice; 0..8: force a gemm.hip tile configuration (also keeps gemm16.hip out)
 void gemm_set_debug(int d);        // bit 0: eligible 3x3 convolutions through the implicit-GEMM kernels; bit 1: keep gemm16.hip out; bit 4: no fused cross-attention
+bool gemm_lnfold_enabled();       // LayerNorm folded into its consumers (debug bit 22 clear, gemm16 on, no forced configuration)
 bool gemm_xblock_enabled();       // the one-launch cross-attention block (xblock.hip) is switched on (debug bit 16 SET - opt-in; gemm16 on, no forced configuration)
 bool gemm_xattn_enabled();         // the fused to_q + cross-attention kernel is allowed (debug bit 4 clear, gemm16 on, no forced configuration)
 // gemm16.hip: 16x16x32-MFMA family (224-row tiles, intra-tile K split); dense problems with K % 64 == 0 only

@@ -78,6 +78,10 @@ struct ResnetP {
 struct TBlockP {
     NormW ln1, ln2, ln3;
     MatW qk1, v1, out1, q2, k2, v2, out2, ff1, ff2;
+    // LayerNorm folded into its consumers (gemm16.hip, "LNF"): W' = fp16(gamma W) in the place of w, c = b + W beta in the place of b,
+    // s = row sums of W'.  Derived from the packed arena by ensure_fold(); null when the block's width has no folded form.
+    MatW qk1f, v1f, q2f, ff1f;
+    float* qk1s = nullptr; float* v1s = nullptr; float* q2s = nullptr; float* ff1s = nullptr;
     bf16_t* kcache = nullptr;    // [maxP*96, H*DP]
     bf16_t* vtcache = nullptr;   // [H*DP, maxP*96]
     // token-map attention store: index 0 = attn1, 1 = attn2
@@ -147,6 +151,11 @@ struct rt_engine {
 
     Arena arena;                 // packed weights only (this is what a multi-GPU launch broadcasts)
     Arena sarena;                // K/V caches + per-image sampler state
+    Arena farena;                // LayerNorm-folded copies of the projections that consume a LayerNorm (derived on every rank from the
+                                 // packed arena: not part of what a multi-GPU launch broadcasts)
+    char* farena_base = nullptr;
+    size_t farena_bytes = 0;
+    bool fold_dirty = true;      // a weight was bound / the arena was filled since the last derivation
     char* arena_base = nullptr;
     char* sarena_base = nullptr;
     size_t arena_bytes = 0, sarena_bytes = 0;
@@ -279,6 +288,22 @@ struct rt_engine {
         add_slot(name + ".bias", {C}, pk_vec(m.b, C));
         return m;
     }
+    // widths whose LayerNorms can be folded: C / 80 = 8 or 16 partial sums per token (SDXL's 640 / 1280; SD-v1.5's 320 / 960-free levels
+    // have K = 320, outside the 16x16x32 family)
+    static bool ln_fold_width(int C) { return C == 640 || C == 1280; }
+    // W' / s / c of every folded projection from the packed arena (idempotent; a few ms, once per checkpoint)
+    void ensure_fold() {
+        if (!fold_dirty || !farena_base) { fold_dirty = false; return; }
+        for (auto& sl : slots) if (!sl.bound) return;                   // not all weights are there yet
+        for_each_tblock([&](TransformerP& t, TBlockP& k) {
+            if (!k.qk1f.w) return;
+            launch_ln_fold_derive(k.qk1.w, k.qk1.K, k.qk1.b, k.ln1.g, k.ln1.b, k.qk1.N, k.qk1.K, (f16_t*)k.qk1f.w, k.qk1s, k.qk1f.b, stream);
+            launch_ln_fold_derive(k.v1.w, k.v1.K, k.v1.b, k.ln1.g, k.ln1.b, k.v1.N, k.v1.K, (f16_t*)k.v1f.w, k.v1s, k.v1f.b, stream);
+            launch_ln_fold_derive(k.q2.w, k.q2.K, k.q2.b, k.ln2.g, k.ln2.b, k.q2.N, k.q2.K, (f16_t*)k.q2f.w, k.q2s, k.q2f.b, stream);
+            launch_ln_fold_derive(k.ff1.w, k.ff1.K, k.ff1.b, k.ln3.g, k.ln3.b, k.ff1.N, k.ff1.K, (f16_t*)k.ff1f.w, k.ff1s, k.ff1f.b, stream);
+        });
+        fold_dirty = false;
+    }
     TransformerP mk_transformer(const std::string& name, int C, int heads, int nlayers, int level) {
         TransformerP t; t.name = name; t.C = C; t.heads = heads; t.d = C / heads; t.DP = pad_head_dim(t.d); t.level = level;
         RT_REQUIRE(C % heads == 0, "channels not divisible by heads");
@@ -317,6 +342,15 @@ struct rt_engine {
             k.ff2 = mk_linear(b + ".ff.net.2", 4 * C, C, true);
             k.kcache = (bf16_t*)sarena.alloc((size_t)cfg.max_prompts * 96 * HD * 2);
             k.vtcache = (bf16_t*)sarena.alloc((size_t)cfg.max_prompts * 96 * HD * 2);
+            if (ln_fold_width(C)) {
+                auto mkf = [&](const MatW& w, MatW& f, float*& sv) {
+                    f.N = w.N; f.K = w.K;
+                    f.w = (bf16_t*)farena.alloc((size_t)w.N * w.K * 2);                 // fp16 bits
+                    f.b = (float*)farena.alloc((size_t)w.N * 4);
+                    sv = (float*)farena.alloc((size_t)w.N * 4);
+                };
+                mkf(k.qk1, k.qk1f, k.qk1s); mkf(k.v1, k.v1f, k.v1s); mkf(k.q2, k.q2f, k.q2s); mkf(k.ff1, k.ff1f, k.ff1s);
+            }
             t.blocks.push_back(k);
         }
         t.pout = mk_linear(name + ".proj_out", C, C, true, !cfg.use_linear_projection);
@@ -393,12 +427,33 @@ struct rt_engine {
         g.splitk_ws = splitk_buf; g.splitk_ws_floats = splitk_floats;
         return true;
     }
-    void gemm(const bf16_t* A, int lda, const MatW& W, int M, void* out, int ldo, int epi, const void* res = nullptr,
-              int ldres = 0, const float* temb = nullptr, int rows_per_batch = 0) {
+    // LayerNorm fold of a launch (gemm16.hip, "LNF"): `part` set = consumer (A / X is the raw fp16 trunk, W the folded copy whose .b is
+    // c, `s` its row sums); `emit` set = producer of the partials of its output rows
+    struct LnFold { const float* part = nullptr; int npart = 0; const float* s = nullptr; float* emit = nullptr; };
+    void ln_apply(GemmArgs& g, const LnFold* ln, int C) const {
+        if (!ln) return;
+        g.ln_part = ln->part; g.ln_npart = ln->npart; g.ln_s = ln->s; g.ln_emit = ln->emit;
+        g.ln_inv_c = 1.f / (float)C; g.ln_eps = 1e-5f;
+    }
+    GemmArgs dense_args(const bf16_t* A, int lda, const MatW& W, int M, void* out, int ldo, int epi, const void* res = nullptr,
+                        int ldres = 0, const float* temb = nullptr, int rows_per_batch = 0) const {
         GemmArgs g{}; g.A = A; g.W = W.w; g.bias = W.b; g.out = out; g.res = res; g.temb = temb; g.zero = zero;
         g.mode = A_DENSE; g.epi = epi; g.M = M; g.N = W.N; g.K = W.K; g.lda = lda; g.ldw = W.K; g.ldo = ldo;
         g.ldres = ldres; g.temb_ld = W.N; g.rows_per_batch = rows_per_batch;
         if (cur_hw > 0) { g.split_tiles = cdiv(cur_hw, 128) * cdiv(W.N, 128); g.rows_per_stream = cur_hw; }
+        return g;
+    }
+    GemmArgs vt_args(const MatW& Wv, const bf16_t* X, int ldx, int M, bf16_t* out, int ldo) const {
+        GemmArgs g{}; g.A = Wv.w; g.W = X; g.bias = Wv.b; g.out = out; g.zero = zero;
+        g.mode = A_DENSE; g.epi = EPI_BF16; g.M = Wv.N; g.N = M; g.K = Wv.K; g.lda = Wv.K; g.ldw = ldx; g.ldo = ldo;
+        g.weights_on_rows = 1;
+        if (cur_hw > 0) { g.split_tiles = cdiv(Wv.N, 128) * cdiv(cur_hw, 128); g.rows_per_stream = cur_hw; }
+        return g;
+    }
+    void gemm(const bf16_t* A, int lda, const MatW& W, int M, void* out, int ldo, int epi, const void* res = nullptr,
+              int ldres = 0, const float* temb = nullptr, int rows_per_batch = 0, const LnFold* ln = nullptr) {
+        GemmArgs g = dense_args(A, lda, W, M, out, ldo, epi, res, ldres, temb, rows_per_batch);
+        ln_apply(g, ln, ln && ln->part ? W.K : W.N);
         if (!run_gemm(g)) return;
         prof_begin(RT_PROF_GEMM_DENSE, 2.0 * M * W.N * W.K);
         launch_gemm(g, stream);
@@ -406,10 +461,7 @@ struct rt_engine {
     }
     // V^T = Wv [HD, K] x X[M, K]^T -> [HD, M]
     void gemm_vt(const MatW& Wv, const bf16_t* X, int ldx, int M, bf16_t* out, int ldo) {
-        GemmArgs g{}; g.A = Wv.w; g.W = X; g.bias = nullptr; g.out = out; g.zero = zero;
-        g.mode = A_DENSE; g.epi = EPI_BF16; g.M = Wv.N; g.N = M; g.K = Wv.K; g.lda = Wv.K; g.ldw = ldx; g.ldo = ldo;
-        g.weights_on_rows = 1;
-        if (cur_hw > 0) { g.split_tiles = cdiv(Wv.N, 128) * cdiv(cur_hw, 128); g.rows_per_stream = cur_hw; }
+        GemmArgs g = vt_args(Wv, X, ldx, M, out, ldo);
         if (!run_gemm(g)) return;
         prof_begin(RT_PROF_GEMM_DENSE, 2.0 * M * Wv.N * Wv.K);
         launch_gemm(g, stream);
@@ -417,16 +469,11 @@ struct rt_engine {
     }
     // attn1: the stacked Q|K projection of the first Mqk rows and V^T of all M rows read the same LayerNorm output: ONE grouped launch
     // where gemm16.hip has the pair of tiles (launch_gemm_pair), otherwise one launch each - the same tile bodies either way
-    void gemm_qk_vt(const bf16_t* X, int ldx, const MatW& Wqk, int Mqk, bf16_t* qk, int ldqk, const MatW& Wv, int M, bf16_t* vt, int ldvt) {
-        GemmArgs a{}; a.A = X; a.W = Wqk.w; a.bias = Wqk.b; a.out = qk; a.zero = zero;
-        a.mode = A_DENSE; a.epi = EPI_BF16; a.M = Mqk; a.N = Wqk.N; a.K = Wqk.K; a.lda = ldx; a.ldw = Wqk.K; a.ldo = ldqk; a.temb_ld = Wqk.N;
-        GemmArgs b{}; b.A = Wv.w; b.W = X; b.bias = nullptr; b.out = vt; b.zero = zero;
-        b.mode = A_DENSE; b.epi = EPI_BF16; b.M = Wv.N; b.N = M; b.K = Wv.K; b.lda = Wv.K; b.ldw = ldx; b.ldo = ldvt;
-        b.weights_on_rows = 1;
-        if (cur_hw > 0) {
-            a.split_tiles = cdiv(cur_hw, 128) * cdiv(Wqk.N, 128); a.rows_per_stream = cur_hw;
-            b.split_tiles = cdiv(Wv.N, 128) * cdiv(cur_hw, 128); b.rows_per_stream = cur_hw;
-        }
+    void gemm_qk_vt(const bf16_t* X, int ldx, const MatW& Wqk, int Mqk, bf16_t* qk, int ldqk, const MatW& Wv, int M, bf16_t* vt, int ldvt,
+                    const LnFold* lnqk = nullptr, const LnFold* lnv = nullptr) {
+        GemmArgs a = dense_args(X, ldx, Wqk, Mqk, qk, ldqk, EPI_BF16);
+        GemmArgs b = vt_args(Wv, X, ldx, M, vt, ldvt);
+        ln_apply(a, lnqk, Wqk.K); ln_apply(b, lnv, Wv.K);
         const bool ra = run_gemm(a), rb = run_gemm(b);
         if (!ra || !rb) return;
         prof_begin(RT_PROF_GEMM_DENSE, 2.0 * Mqk * Wqk.N * Wqk.K + 2.0 * M * Wv.N * Wv.K);
@@ -524,17 +571,43 @@ struct rt_engine {
         {
             Scope sc(ws);
             f16_t* hcur = ws.f16((size_t)M * C);
+            // LayerNorm folded into its consumers (gemm16.hip, "LNF"; attention.py:150,168,181) wherever every consumer of the LayerNorm has
+            // the folded instantiation - a pure function of the layer's shape (width, tokens per stream), never of the batch.  The trunk's
+            // producers (proj_in, to_out, ff.net.2: fp16-trunk epilogues) then leave the per-row partial sums next to it; a producer
+            // without that form is followed by the stand-alone partials kernel.  Debug bit 22 restores the LayerNorm launches.
+            const int npart = C / 80;
+            float* part = ws.f32((size_t)M * 16 * 2);
+            bool fold1 = false, fold2 = false, fold3 = false, emit_pin = false, emit_out = false, emit_ff2 = false;
+            if (gemm_lnfold_enabled() && ln_fold_width(C) && !t.blocks.empty() && t.blocks[0].qk1f.w) {
+                const TBlockP& k0 = t.blocks[0];
+                GemmArgs cq = dense_args(nullptr, C, k0.qk1f, M, nullptr, 2 * HD, EPI_BF16); cq.ln_npart = npart;
+                GemmArgs cv = vt_args(k0.v1f, nullptr, C, M, nullptr, M); cv.ln_npart = npart;
+                GemmArgs c2 = dense_args(nullptr, C, k0.q2f, M, nullptr, HD, EPI_BF16); c2.ln_npart = npart;
+                GemmArgs c3 = dense_args(nullptr, C, k0.ff1f, M, nullptr, 4 * C, EPI_GEGLU); c3.ln_npart = npart;
+                fold1 = gemm_ln_fold_ok(cq) && gemm_ln_fold_ok(cv);
+                fold2 = gemm_ln_fold_ok(c2);
+                fold3 = gemm_ln_fold_ok(c3);
+                emit_pin = gemm_ln_emit_ok(dense_args(nullptr, C, t.pin, M, nullptr, C, EPI_F16));
+                emit_out = gemm_ln_emit_ok(dense_args(nullptr, HD, k0.out1, M, nullptr, C, EPI_F16));
+                emit_ff2 = gemm_ln_emit_ok(dense_args(nullptr, 4 * C, k0.ff2, M, nullptr, C, EPI_F16));
+            }
+            // partials of the trunk as it stands, for the LayerNorm that follows: from the producer's epilogue (`em` was passed to it) or here
+            auto partials_after = [&](bool emitted) { if (!emitted && !dry()) launch_ln_partials(hcur, part, M, C, stream); };
+            LnFold em; em.emit = part;
             {
                 Scope s2(ws);
                 bf16_t* g = ws.b16((size_t)M * C);
                 groupnorm(x.p, nullptr, 2, C, 0, B, HW, t.gn, 1e-6f, false, g, nullptr);
-                gemm(g, C, t.pin, M, hcur, C, EPI_F16);
+                gemm(g, C, t.pin, M, hcur, C, EPI_F16, nullptr, 0, nullptr, 0, fold1 && emit_pin ? &em : nullptr);
+                if (fold1) partials_after(emit_pin);
             }
-            for (TBlockP& k : t.blocks) {
+            for (size_t bi = 0; bi < t.blocks.size(); ++bi) {
+                TBlockP& k = t.blocks[bi];
+                const bool last = bi + 1 == t.blocks.size();
                 Scope s2(ws);
                 bf16_t* n = ws.b16((size_t)M * C);
                 // --- attn1 (self; attention_processor.py:476-545)
-                layernorm(hcur, k.ln1, n, M);
+                if (!fold1) layernorm(hcur, k.ln1, n, M);
                 bf16_t* qk = ws.b16((size_t)M * 2 * HD);
                 bf16_t* vt = ws.b16((size_t)HD * M);
                 bf16_t* o = ws.b16((size_t)M * HD);
@@ -543,7 +616,11 @@ struct rt_engine {
                 // text_ref stream's Q,K: attention_processor.py:522-524 discards their own scores)
                 int nqk = 0;
                 for (int b = 0; b < B; ++b) nqk = std::max(nqk, in.qk_src[b] + 1);
-                gemm_qk_vt(n, C, k.qk1, nqk * HW, qk, 2 * HD, k.v1, M, vt, M);
+                if (fold1) {
+                    LnFold lq; lq.part = part; lq.npart = npart; lq.s = k.qk1s;
+                    LnFold lv; lv.part = part; lv.npart = npart; lv.s = k.v1s;
+                    gemm_qk_vt((const bf16_t*)hcur, C, k.qk1f, nqk * HW, qk, 2 * HD, k.v1f, M, vt, M, &lq, &lv);
+                } else gemm_qk_vt(n, C, k.qk1, nqk * HW, qk, 2 * HD, k.v1, M, vt, M);
                 if (!dry()) {
                     AttnArgs a{}; a.Q = qk; a.ldq = 2 * HD; a.K = qk + HD; a.ldk = 2 * HD; a.VT = vt; a.ldvt = M; a.O = o; a.ldo = HD;
                     for (int b = 0; b < B; ++b) { a.q_src[b] = in.qk_src[b]; a.k_src[b] = in.qk_src[b]; a.v_src[b] = b; a.wset[b] = 0; }
@@ -568,9 +645,10 @@ struct rt_engine {
                         k.store_rows[0] = HW; k.store_cols[0] = HW;
                     }
                 }
-                gemm(o, HD, k.out1, M, hcur, C, EPI_F16, hcur, C);
+                gemm(o, HD, k.out1, M, hcur, C, EPI_F16, hcur, C, nullptr, 0, fold2 && emit_out ? &em : nullptr);
+                if (fold2) partials_after(emit_out);
                 // --- attn2 (cross, K/V from the per-prompt cache; font-size softmax on flagged streams)
-                layernorm(hcur, k.ln2, n, M);
+                if (!fold2) layernorm(hcur, k.ln2, n, M);
                 // to_q and the 77-key attention as ONE launch (gemm16.hip, EPI_XATTN: the Q tile stays in LDS) wherever the tiling
                 // allows it - a pure function of the layer's shape; the token-map capture of the plain pass reads Q from HBM and
                 // keeps the two-launch form for the layers it records
@@ -578,9 +656,9 @@ struct rt_engine {
                 // round 5: the 77-key attention on its own kernel (cross77_kernel, xblock.hip: 64 queries x 2 heads per workgroup, K / V^T in
                 // LDS) behind the plain to_q GEMM is faster than the fused launch of round 4 and serves the capturing layers too (Q is in HBM)
                 const bool c77 = gemm_cross77_enabled() && cross77_supported(t.heads, t.DP, HW, 96, 77) && t.d == 64;
-                const bool fused2 = !c77 && gemm_xattn_enabled() && xattn_fused_supported(C, t.heads, t.DP, HW) && !capture2;
+                const bool fused2 = !c77 && !fold2 && gemm_xattn_enabled() && xattn_fused_supported(C, t.heads, t.DP, HW) && !capture2;
                 // the 640-channel level: to_q, attention AND to_out + residual as one launch with Q / P / O in registers (xblock.hip)
-                const bool block2 = gemm_xblock_enabled() && xblock_supported(C, t.heads, t.DP, HW) && t.d == 64 && !capture2;
+                const bool block2 = !fold2 && gemm_xblock_enabled() && xblock_supported(C, t.heads, t.DP, HW) && t.d == 64 && !capture2;
                 if (block2) {
                     if (!dry()) {
                         XBlockArgs xa{}; xa.x = n; xa.wq = k.q2.w; xa.wo = k.out2.w; xa.bo = k.out2.b; xa.kc = k.kcache; xa.vt = k.vtcache;
@@ -592,6 +670,7 @@ struct rt_engine {
                         launch_xblock(xa, stream);
                         prof_end();
                     }
+                    if (fold3) partials_after(false);
                 } else {
                 if (fused2) {
                     if (!dry()) {
@@ -605,7 +684,10 @@ struct rt_engine {
                         prof_end();
                     }
                 } else {
-                gemm(n, C, k.q2, M, qk, HD, EPI_BF16);
+                if (fold2) {
+                    LnFold l2; l2.part = part; l2.npart = npart; l2.s = k.q2s;
+                    gemm((const bf16_t*)hcur, C, k.q2f, M, qk, HD, EPI_BF16, nullptr, 0, nullptr, 0, &l2);
+                } else gemm(n, C, k.q2, M, qk, HD, EPI_BF16);
                 if (!dry()) {
                     AttnArgs a{}; a.Q = qk; a.ldq = HD; a.K = k.kcache; a.ldk = HD; a.VT = k.vtcache; a.ldvt = cfg.max_prompts * 96;
                     a.O = o; a.ldo = HD;
@@ -633,13 +715,21 @@ struct rt_engine {
                     }
                 }
                 }
-                gemm(o, HD, k.out2, M, hcur, C, EPI_F16, hcur, C);
+                gemm(o, HD, k.out2, M, hcur, C, EPI_F16, hcur, C, nullptr, 0, fold3 && emit_out ? &em : nullptr);
+                if (fold3) partials_after(emit_out);
                 }
                 // --- GEGLU feed-forward (attention.py:209-304)
-                layernorm(hcur, k.ln3, n, M);
                 bf16_t* gg = ws.b16((size_t)M * 4 * C);
-                gemm(n, C, k.ff1, M, gg, 4 * C, EPI_GEGLU);
-                gemm(gg, 4 * C, k.ff2, M, hcur, C, EPI_F16, hcur, C);
+                if (fold3) {
+                    LnFold l3; l3.part = part; l3.npart = npart; l3.s = k.ff1s;
+                    gemm((const bf16_t*)hcur, C, k.ff1f, M, gg, 4 * C, EPI_GEGLU, nullptr, 0, nullptr, 0, &l3);
+                } else {
+                    layernorm(hcur, k.ln3, n, M);
+                    gemm(n, C, k.ff1, M, gg, 4 * C, EPI_GEGLU);
+                }
+                const bool need1 = fold1 && !last;                   // the next block's norm1 reads what ff.net.2 leaves
+                gemm(gg, 4 * C, k.ff2, M, hcur, C, EPI_F16, hcur, C, nullptr, 0, need1 && emit_ff2 ? &em : nullptr);
+                if (need1) partials_after(emit_ff2);
             }
             bf16_t* hb = ws.b16((size_t)M * C);
             if (!dry()) launch_cast_f16_bf16(hcur, hb, (size_t)M * C, stream);
@@ -654,6 +744,7 @@ struct rt_engine {
         RT_REQUIRE(B >= 1 && B <= cfg.max_streams && B <= RT_MAXB, "forward: too many streams");
         RT_REQUIRE(Hh <= cfg.latent_h && Ww <= cfg.latent_w, "forward: latent larger than configured");
         RT_REQUIRE((Hh % (1 << (cfg.n_levels - 1))) == 0 && (Ww % (1 << (cfg.n_levels - 1))) == 0, "forward: latent size not divisible");
+        if (!dry()) ensure_fold();       // (normally a no-op: rt_set_prompts derived the folded projections already)
         const size_t m0 = ws.mark();
         // time / addition embeddings (unet_2d_condition.py:784-877)
         float* emb = ws.f32((size_t)B * temb_dim);
@@ -882,9 +973,9 @@ int rt_create(const rt_config* cfg, int device, rt_engine** out) {
         e = new rt_engine();
         e->cfg = *cfg; e->device = device;
         // pass 1: measure the arena (no device needed: lets CPU-only hosts enumerate the weight table)
-        e->arena = Arena(); e->sarena = Arena(); e->ws.dry = true;
+        e->arena = Arena(); e->sarena = Arena(); e->farena = Arena(); e->ws.dry = true;
         e->build_plan();
-        e->arena_bytes = e->arena.off + 256; e->sarena_bytes = e->sarena.off + 256;
+        e->arena_bytes = e->arena.off + 256; e->sarena_bytes = e->sarena.off + 256; e->farena_bytes = e->farena.off + 256;
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0 || device < 0) {
             // weight-table-only engine (CPU box): every device call will fail with RT_E_STATE
@@ -899,8 +990,11 @@ int rt_create(const rt_config* cfg, int device, rt_engine** out) {
         HIP_CHECK(hipMemset(e->arena_base, 0, e->arena_bytes));
         HIP_CHECK(hipMalloc((void**)&e->sarena_base, e->sarena_bytes));
         HIP_CHECK(hipMemset(e->sarena_base, 0, e->sarena_bytes));
+        HIP_CHECK(hipMalloc((void**)&e->farena_base, e->farena_bytes));
+        HIP_CHECK(hipMemset(e->farena_base, 0, e->farena_bytes));
         e->arena = Arena(); e->arena.base = e->arena_base; e->arena.cap = e->arena_bytes;
         e->sarena = Arena(); e->sarena.base = e->sarena_base; e->sarena.cap = e->sarena_bytes;
+        e->farena = Arena(); e->farena.base = e->farena_base; e->farena.cap = e->farena_bytes;
         e->build_plan();
         // pass 2: measure the workspace with a dry forward at the largest shape
         {
@@ -962,7 +1056,7 @@ int rt_destroy(rt_engine* e) {
     if (e->arena_base) {
         (void)hipSetDevice(e->device); (void)hipStreamSynchronize(e->stream);
         for (auto& r : e->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
-        (void)hipFree(e->arena_base); (void)hipFree(e->sarena_base); (void)hipFree(e->ws.base); (void)hipFree(e->temb_tab_dev); (void)hipFree(e->splitk_buf); (void)hipStreamDestroy(e->own_stream);
+        (void)hipFree(e->arena_base); (void)hipFree(e->sarena_base); (void)hipFree(e->farena_base); (void)hipFree(e->ws.base); (void)hipFree(e->temb_tab_dev); (void)hipFree(e->splitk_buf); (void)hipStreamDestroy(e->own_stream);
     }
     delete e;
     return RT_OK;
@@ -999,6 +1093,7 @@ int rt_bind_weight(rt_engine* e, const char* name, const void* ptr, int dtype, c
         PackArgs p = s.pack; p.src = ptr; p.src_dtype = dtype;
         launch_pack(p, e->stream);
         s.bound = true;
+        e->fold_dirty = true;
     })
 }
 int rt_weights_missing(rt_engine* e, char* buf, int cap) {
@@ -1008,10 +1103,10 @@ int rt_weights_missing(rt_engine* e, char* buf, int cap) {
     return n;
 }
 int rt_arena_info(rt_engine* e, void** p, uint64_t* bytes) { RT_TRY(e, { need_device(e); *p = e->arena_base; *bytes = e->arena_bytes; }) }
-int rt_arena_mark_bound(rt_engine* e) { for (auto& s : e->slots) s.bound = true; return RT_OK; }
+int rt_arena_mark_bound(rt_engine* e) { for (auto& s : e->slots) s.bound = true; e->fold_dirty = true; return RT_OK; }
 
 int rt_set_prompts(rt_engine* e, const float* pe, const float* pooled, const float* tids, int P, int pooled_dim) {
-    RT_TRY(e, { need_device(e); e->set_prompts(pe, pooled, tids, P, pooled_dim); })
+    RT_TRY(e, { need_device(e); e->ensure_fold(); e->set_prompts(pe, pooled, tids, P, pooled_dim); })
 }
 int rt_set_masks(rt_engine* e, const float* m, int R, int h, int w) {
     RT_TRY(e, {
@@ -1224,6 +1319,50 @@ int rt_op_gemm(const void* A, const void* W, const float* bias, void* out, const
         g.ldres = ldres; g.temb_ld = temb_ld; g.rows_per_batch = rows_per_batch; g.Hin = Hin; g.Win = Win; g.Cin = Cin;
         g.Hout = Hout; g.Wout = Wout;
         launch_gemm(g, (hipStream_t)stream);
+    })
+}
+int rt_op_ln_partials(const void* x_f16, float* partials, int rows, int C, void* stream) {
+    OP_TRY({ launch_ln_partials((const f16_t*)x_f16, partials, rows, C, (hipStream_t)stream); })
+}
+int rt_op_gemm_emit_partials(const void* A, const void* W, const float* bias, void* out_f16, const void* res_f16, int M, int N, int K,
+                             int rows_per_stream, float* partials, void* stream) {
+    OP_TRY({
+        GemmArgs g{}; g.A = (const bf16_t*)A; g.W = (const bf16_t*)W; g.bias = bias; g.out = out_f16; g.res = res_f16; g.zero = op_zero_page();
+        g.mode = A_DENSE; g.epi = EPI_F16; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldo = N; g.ldres = N;
+        g.rows_per_stream = rows_per_stream; if (rows_per_stream > 0) g.split_tiles = cdiv(rows_per_stream, 128) * cdiv(N, 128);
+        if (!gemm_ln_emit_ok(g)) throw rt_error(RT_E_UNSUPPORTED, "rt_op_gemm_emit_partials: this shape's route has no partial-emitting epilogue");
+        g.ln_emit = partials;
+        launch_gemm(g, (hipStream_t)stream);
+    })
+}
+int rt_op_ln_gemm(const void* x_f16, const float* gamma, const float* beta, const void* W_bf16, const float* bias, void* out, int tokens,
+                  int N, int C, int epi, int weights_on_rows, int rows_per_stream, const float* partials, void* stream) {
+    OP_TRY({
+        RT_REQUIRE((C == 640 || C == 1280) && tokens > 0 && N > 0 && (epi == EPI_BF16 || epi == EPI_GEGLU) && !(weights_on_rows && epi != EPI_BF16), "rt_op_ln_gemm: shape");
+        hipStream_t st = (hipStream_t)stream;
+        GemmArgs g{}; g.zero = op_zero_page(); g.mode = A_DENSE; g.epi = epi; g.K = C; g.out = out;
+        if (weights_on_rows) { g.M = N; g.N = tokens; g.lda = C; g.ldw = C; g.ldo = tokens; g.weights_on_rows = 1; }
+        else { g.M = tokens; g.N = N; g.lda = C; g.ldw = C; g.ldo = epi == EPI_GEGLU ? N / 2 : N; }
+        g.rows_per_stream = rows_per_stream;
+        if (rows_per_stream > 0) g.split_tiles = weights_on_rows ? cdiv(N, 128) * cdiv(rows_per_stream, 128) : cdiv(rows_per_stream, 128) * cdiv(N, 128);
+        g.ln_npart = C / 80; g.ln_inv_c = 1.f / (float)C; g.ln_eps = 1e-5f;
+        if (!gemm_ln_fold_ok(g)) throw rt_error(RT_E_UNSUPPORTED, "rt_op_ln_gemm: this shape's route has no folded instantiation");
+        // scratch of the op (the engine keeps these in its own arenas): W', s, c, partials
+        f16_t* Wf = nullptr; float* sc = nullptr; float* part = nullptr;
+        HIP_CHECK(hipMalloc((void**)&Wf, (size_t)N * C * 2));
+        HIP_CHECK(hipMalloc((void**)&sc, (size_t)N * 8));
+        try {
+            launch_ln_fold_derive((const bf16_t*)W_bf16, C, bias, gamma, beta, N, C, Wf, sc, sc + N, st);
+            if (!partials) {
+                HIP_CHECK(hipMalloc((void**)&part, (size_t)tokens * (C / 80) * 8));
+                launch_ln_partials((const f16_t*)x_f16, part, tokens, C, st);
+            }
+            g.ln_part = partials ? partials : part; g.ln_s = sc; g.bias = sc + N;
+            if (weights_on_rows) { g.A = (const bf16_t*)Wf; g.W = (const bf16_t*)x_f16; } else { g.A = (const bf16_t*)x_f16; g.W = (const bf16_t*)Wf; }
+            launch_gemm(g, st);
+            HIP_CHECK(hipStreamSynchronize(st));
+        } catch (...) { (void)hipFree(Wf); (void)hipFree(sc); (void)hipFree(part); throw; }
+        (void)hipFree(Wf); (void)hipFree(sc); (void)hipFree(part);
     })
 }
 int rt_op_attention(const void* Q, int ldq, const void* K, int ldk, const void* VT, int ldvt, void* O, int ldo, const int* q_src,

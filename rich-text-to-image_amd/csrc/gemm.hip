@@ -1234,6 +1234,7 @@ static int g_no_triple = 0;
 static int g_pair = 1;
 static int g_cross77 = 1;
 static int g_xblock = 0;      // measured slower than the separate launches (LABNOTES R5.2): opt-in
+static int g_lnfold = 1;      // round 6: LayerNorm folded into its consumers (gemm16.hip, "LNF"); debug bit 22 restores the LayerNorm launches
 #ifdef RT_PROBE
 int g_conv3p_tn = 0;          // probe override of the patch kernel's column-tile count
 #endif
@@ -1245,10 +1246,12 @@ void gemm_set_debug(int flags) {
     g_xattn = (flags & 16) ? 0 : 1;
     g_xblock = (flags & 65536) ? 1 : 0;                               // bit 16: the 640-channel cross-attention block as xblock.hip's ONE launch (opt-in: measured slower, LABNOTES R5.2)
     g_cross77 = (flags & 524288) ? 0 : 1;                             // bit 19: cross-attention on the round-4 kernels (EPI_XATTN / attn_kernel<CROSS>) instead of cross77_kernel
+    g_lnfold = (flags & 4194304) ? 0 : 1;                             // bit 22: LayerNorm launches + bf16 projections (rounds 1 - 5) instead of the folded form
     g_pair = (flags & 8192) ? 0 : 1;                                  // bit 13: attn1's Q|K and V^T projections as two launches instead of one grouped launch
     g_no_triple = ((flags & 128) ? 1 : 0) | ((flags & 256) ? 2 : 0) | ((flags & 512) ? 4 : 0) | ((flags & 32768) ? 8 : 0);   // bit 15: dense hi / lo contractions as three launches   // (bits 8 / 9: only the gemm16 / only the patch-kernel route)              // bit 7: the precise VAE's contractions as three launches (round 3) instead of one
 }
 bool gemm_cross77_enabled() { return g_cross77 != 0; }
+bool gemm_lnfold_enabled() { return g_lnfold != 0 && g_use16 != 0 && g_force_cfg < 0; }
 bool gemm_xblock_enabled() { return g_xblock != 0 && g_use16 != 0 && g_force_cfg < 0; }
 bool gemm_xattn_enabled() { return g_xattn != 0 && g_use16 != 0 && g_force_cfg < 0; }
 
@@ -1485,8 +1488,27 @@ bool gemm_pair_output_ok(const GemmArgs& a) {
     return !(a.mode == A_CONV3 && g_use16 && g_conv16 && g_conv_patch && !a.prefer_patch_conv && gemm16_pick(a, 0, &ws) >= 0);
 }
 
+// LayerNorm fold (gemm16.hip, "LNF"): which route launch_gemm takes is a pure function of the shape, so the engine can ask beforehand
+// whether a producer would leave the partials / a consumer has the folded instantiation - and keep the LayerNorm launch otherwise.
+int gemm_route16(const GemmArgs& a) {
+    if (a.mode != A_DENSE || a.A_lo || a.W_lo || a.pair_lo || g_force_cfg >= 0 || !g_use16) return -1;
+    if ((g_splitk ? splitk_slices(a) : 1) != 1) return -1;
+    int wstat = 0;
+    return gemm16_pick(a, a.weights_on_rows, &wstat);
+}
+bool gemm_ln_emit_ok(const GemmArgs& a_in) {
+    GemmArgs a = a_in; a.ln_part = nullptr; a.ln_emit = (float*)(uintptr_t)256;          // (any non-null value: host-side shape test only)
+    return a.epi == EPI_F16 && gemm16_ln_variant_ok(a, gemm_route16(a));
+}
+bool gemm_ln_fold_ok(const GemmArgs& a_in) {
+    GemmArgs a = a_in; a.ln_emit = nullptr; a.ln_part = (const float*)(uintptr_t)256;
+    if (a.ln_npart != 8 && a.ln_npart != 16) return false;
+    return gemm16_ln_variant_ok(a, gemm_route16(a));
+}
+
 void launch_gemm(const GemmArgs& a, hipStream_t st) {
     check_gemm_args(a);
+    if (a.ln_part || a.ln_emit) RT_REQUIRE(gemm16_ln_variant_ok(a, gemm_route16(a)), "gemm: LayerNorm fold asked of a route without it (gemm_ln_fold_ok / gemm_ln_emit_ok)");
     if (a.pair_lo) RT_REQUIRE(gemm_pair_output_ok(a) && a.ldo % 4 == 0 && ((uintptr_t)a.pair_lo & 7) == 0, "gemm: pair output is only built into the patch convolution (gemm_pair_output_ok)");
     // In-place residual (out == res) is safe: every element is read and written by the same thread.
     // split-K is a function of the shape only (not of a forced tile configuration, not of stream capture): the same problem

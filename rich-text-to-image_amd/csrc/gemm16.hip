@@ -44,6 +44,34 @@ __device__ long long g_g16_times[8192 * 8];
 
 #define RT_G16_OOB 0x7fff0000       // a voffset beyond every descriptor range used here: the lane's 16 bytes arrive as zeros
 
+// ---------------------------------------------------------------------------------------------- LNF: LayerNorm folded into the projections (round 6)
+// BasicTransformerBlock normalises the fp16 trunk three times per block (models/attention.py:150,168,181: norm1 -> attn1, norm2 -> attn2,
+// norm3 -> ff) and every LayerNorm was its own launch (210 per SDXL forward: 37 MB in, 37 MB out, 9.3 us + a kernel boundary each).
+//     LN(x) W^T + b = rstd_m (x (W diag(gamma))^T - mu_m s_n) + c_n,     s_n = sum_k gamma_k W_nk,   c_n = b_n + sum_k beta_k W_nk
+// so the consumer GEMM can read the RAW trunk: the trunk is fp16 in HBM and v_mfma_f32_16x16x32_f16 takes it as it is - the A operand
+// is exact (the LayerNorm launch rounded LN(x) to bf16: 2^-9 relative) - against W' = fp16(gamma W) derived once per checkpoint
+// (ln_fold_derive_kernel, norm.hip); the per-token (mu, rstd) come from per-row partial sums (sum x, sum x^2 over 80-column blocks)
+// that the PRODUCER of the trunk - the fp16-trunk epilogue of to_out / ff.net.2 / proj_in - leaves next to its output.
+//   LNF = 0  plain kernel (the measured binaries of rounds 3 - 5, unchanged)
+//   LNF = 1  consumer, tokens on the rows: f16 MFMA; every workgroup turns the partials of its 224 (...) token rows into an LDS table
+//            (mu, rstd) while its first K tiles are in flight; the epilogue applies rstd (acc - mu s_col) + c_col (GEGLU: in front of the gelu)
+//   LNF = 3  consumer, tokens on the COLUMNS (V^T = Wv X^T): the same with per-column statistics and per-row s, c
+//   LNF = 2  producer (EPI_F16 only): after rounding a 16 x 80 piece of the trunk to fp16 the wave reduces sum / sum of squares of the
+//            ROUNDED values per row in a fixed order (LDS scratch + quad DPP: deterministic) and stores [row][block] float2
+// var = E[x^2] - mu^2 in fp32 from 8 / 16 hierarchical partials: relative error of rstd ~ 1e-7 (1 + mu^2 / sigma^2).
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+template <bool H16>
+static __device__ __forceinline__ f32x4_t g16_mma(const bf16x8& b, const bf16x8& a, const f32x4_t& c) {
+    if constexpr (H16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, b), __builtin_bit_cast(f16x8_t, a), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, c, 0, 0, 0);
+}
+#define RT_LNF_NONE 0
+#define RT_LNF_ROWS 1
+#define RT_LNF_EMIT 2
+#define RT_LNF_COLS 3
+#define RT_LN_BLOCK 80               // columns per partial of the producer (the wave tile of every 160- / 320-column variant)
+#define RT_LN_TAB 5120               // bytes of the table behind the ring: [320] (mu, rstd) | [320] s | [320] c of the tile
+
 // ---------------------------------------------------------------------------------------------- EPI_XATTN: fused to_q + cross-attention
 // The SDXL cross-attention block (models/attention.py:169-189, models/attention_processor.py:476-545, font-size softmax :386-401)
 // ran as to_q GEMM -> 96-key attention -> to_out GEMM; the attention launch does 2.8 GFLOP and is bound by reading Q and writing O
@@ -261,12 +289,12 @@ static __device__ __forceinline__ void xattn_tail(const GemmArgs& p, char* smem,
 //
 // The body of one output tile lives in gemm16_body.inl (see there why it is included twice).  `bid_in` = the workgroup's linear id inside
 // ITS problem's grid: blockIdx.x for a plain launch, blockIdx.x minus the first problem's workgroups inside a grouped launch.
-template <int MODE, int EPI, int TMW, int TNW, int WM, int WN, int WK, int S>
+template <int MODE, int EPI, int TMW, int TNW, int WM, int WN, int WK, int S, int LNF = 0>
 static __device__ __forceinline__ void gemm16_tile(const GemmArgs& p, const int wstat, const unsigned bid_in) {
 #include "gemm16_body.inl"
 }
 
-template <int MODE, int EPI, int TMW, int TNW, int WM, int WN, int WK, int S>
+template <int MODE, int EPI, int TMW, int TNW, int WM, int WN, int WK, int S, int LNF = 0>
 __global__ __launch_bounds__(WM * WN * WK * 64, (WM * WN * WK == 4) ? 2 : 1) void gemm16_kernel(GemmArgs p, int wstat) {     // (four-wave forms: two workgroups per CU)
     const unsigned bid_in = blockIdx.x;
 #include "gemm16_body.inl"
@@ -279,10 +307,10 @@ __global__ __launch_bounds__(WM * WN * WK * 64, (WM * WN * WK == 4) ? 2 : 1) voi
 // boundary (launch ramp + the write-back of what A left dirty) disappears per attn1.  B's XCD-aware tile order survives any nwg_a:
 // workgroups are dealt to the XCDs round-robin by blockIdx.x, so B's local id & 7 names the hardware XCD rotated by nwg_a & 7 - a
 // relabelling of the XCDs, which is all the bijective remap needs (same label <=> same L2).
-template <int TMW_A, int TNW_A, int S_A, int TMW_B, int TNW_B>
+template <int TMW_A, int TNW_A, int S_A, int TMW_B, int TNW_B, bool LN = false>
 __global__ __launch_bounds__(512) void gemm16_dual_kernel(GemmArgs pa, GemmArgs pb, int nwg_a) {
-    if ((int)blockIdx.x < nwg_a) gemm16_tile<A_DENSE, EPI_BF16, TMW_A, TNW_A, 2, 4, 1, S_A>(pa, 0, blockIdx.x);
-    else gemm16_tile<A_DENSE, EPI_BF16, TMW_B, TNW_B, 2, 2, 2, 3>(pb, 0, blockIdx.x - (unsigned)nwg_a);
+    if ((int)blockIdx.x < nwg_a) gemm16_tile<A_DENSE, EPI_BF16, TMW_A, TNW_A, 2, 4, 1, S_A, LN ? RT_LNF_ROWS : 0>(pa, 0, blockIdx.x);
+    else gemm16_tile<A_DENSE, EPI_BF16, TMW_B, TNW_B, 2, 2, 2, 3, LN ? RT_LNF_COLS : 0>(pb, 0, blockIdx.x - (unsigned)nwg_a);
 }
 
 // ---------------------------------------------------------------------------------------------- launch
@@ -308,19 +336,81 @@ static const G16Var kVar[RT_G16_NVAR] = {
     //  compiler-scheduled wave does not keep the matrix pipe fed.  The kernel template still takes WM*WN*WK == 4.)
 };
 
-template <int MODE, int EPI, int TMW, int TNW, int WM, int WN, int WK, int S>
+template <int MODE, int EPI, int TMW, int TNW, int WM, int WN, int WK, int S, int LNF = 0>
 static void launch_v(const GemmArgs& a, int wstat, hipStream_t st) {
     constexpr int BM = WM * TMW * 16, BN = WN * TNW * 16;
-    constexpr int LDS = S * (BM + BN) * 128;
+    constexpr int LDS = S * (BM + BN) * 128 + ((LNF == RT_LNF_ROWS || LNF == RT_LNF_COLS) ? RT_LN_TAB : 0);
     static bool attr = false;
     if (!attr) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)gemm16_kernel<MODE, EPI, TMW, TNW, WM, WN, WK, S>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        HIP_CHECK(hipFuncSetAttribute((const void*)gemm16_kernel<MODE, EPI, TMW, TNW, WM, WN, WK, S, LNF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr = true;
     }
     const int ntn = cdiv(a.N, BN), ntm = cdiv(a.M, BM);
     if (wstat && (ntn % 8 != 0)) wstat = 0;
-    hipLaunchKernelGGL((gemm16_kernel<MODE, EPI, TMW, TNW, WM, WN, WK, S>), dim3(ntm * ntn), dim3(WM * WN * WK * 64), LDS, st, a, wstat);
+    hipLaunchKernelGGL((gemm16_kernel<MODE, EPI, TMW, TNW, WM, WN, WK, S, LNF>), dim3(ntm * ntn), dim3(WM * WN * WK * 64), LDS, st, a, wstat);
     HIP_CHECK(hipGetLastError());
+}
+
+// LayerNorm fold ("LNF" at the top of this file): the instantiations that exist.  Producer of the partials: the fp16-trunk epilogue of
+// every variant with 80-column wave tiles (160- / 320-column tiles).  Consumers: every bf16-output / GEGLU variant of the dense family -
+// tokens on the rows (LNF = 1) or, for the V^T form, on the columns (LNF = 3).  Same tile shapes, wave layouts and k order as the plain
+// kernels of the variant, so a variant's class keeps its meaning (batch invariance: gemm16_pick decides exactly as before).
+static bool ln_variant_ok(int epi, int v, int lnf) {
+    if (lnf == RT_LNF_EMIT) return epi == EPI_F16 && (v == 0 || v == 1 || v == 4 || v == 5 || v == 9 || v == 10 || v == 11);
+    if (lnf == RT_LNF_COLS) return epi == EPI_BF16 && (v == 6 || v == 7 || v == 12);
+    if (lnf == RT_LNF_ROWS) {
+        if (epi == EPI_GEGLU) return v == 2 || v == 3 || v == 8;
+        return epi == EPI_BF16 && (v == 0 || v == 1 || v == 2 || v == 3 || v == 4 || v == 5 || v == 8 || v == 9 || v == 10 || v == 11);
+    }
+    return false;
+}
+static void launch_ln(const GemmArgs& a, int v, int wstat, int lnf, hipStream_t st) {
+    RT_REQUIRE(a.mode == A_DENSE && ln_variant_ok(a.epi, v, lnf), "gemm16: no LayerNorm-fold instantiation of this variant / epilogue");
+    if (lnf == RT_LNF_EMIT) {
+        RT_REQUIRE(a.N % RT_LN_BLOCK == 0 && a.ldo == a.N, "gemm16: partials are emitted per 80-column block of a dense output");
+        switch (v) {
+            case 0: launch_v<A_DENSE, EPI_F16, 7, 5, 2, 2, 2, 3, RT_LNF_EMIT>(a, wstat, st); return;
+            case 1: launch_v<A_DENSE, EPI_F16, 4, 5, 2, 2, 2, 3, RT_LNF_EMIT>(a, wstat, st); return;
+            case 4: launch_v<A_DENSE, EPI_F16, 7, 5, 2, 4, 1, 2, RT_LNF_EMIT>(a, wstat, st); return;
+            case 5: launch_v<A_DENSE, EPI_F16, 8, 5, 2, 4, 1, 2, RT_LNF_EMIT>(a, wstat, st); return;
+            case 9: launch_v<A_DENSE, EPI_F16, 2, 5, 2, 2, 2, 3, RT_LNF_EMIT>(a, wstat, st); return;
+            case 10: launch_v<A_DENSE, EPI_F16, 4, 5, 2, 4, 1, 2, RT_LNF_EMIT>(a, wstat, st); return;
+            default: launch_v<A_DENSE, EPI_F16, 2, 5, 2, 4, 1, 3, RT_LNF_EMIT>(a, wstat, st); return;
+        }
+    }
+    RT_REQUIRE(a.ln_part && a.ln_s && (a.ln_npart == 8 || a.ln_npart == 16) && a.ln_inv_c > 0.f, "gemm16: LayerNorm-fold consumer arguments (8 or 16 partials per token)");
+    if (lnf == RT_LNF_COLS) {
+        switch (v) {
+            case 6: launch_v<A_DENSE, EPI_BF16, 5, 7, 2, 2, 2, 3, RT_LNF_COLS>(a, wstat, st); return;
+            case 7: launch_v<A_DENSE, EPI_BF16, 5, 4, 2, 2, 2, 3, RT_LNF_COLS>(a, wstat, st); return;
+            default: launch_v<A_DENSE, EPI_BF16, 5, 2, 2, 2, 2, 3, RT_LNF_COLS>(a, wstat, st); return;
+        }
+    }
+    if (a.epi == EPI_GEGLU) {
+        switch (v) {
+            case 2: launch_v<A_DENSE, EPI_GEGLU, 7, 4, 2, 4, 1, 2, RT_LNF_ROWS>(a, wstat, st); return;
+            case 3: launch_v<A_DENSE, EPI_GEGLU, 8, 4, 2, 4, 1, 2, RT_LNF_ROWS>(a, wstat, st); return;
+            default: launch_v<A_DENSE, EPI_GEGLU, 4, 4, 2, 4, 1, 3, RT_LNF_ROWS>(a, wstat, st); return;
+        }
+    }
+    switch (v) {
+        case 0: launch_v<A_DENSE, EPI_BF16, 7, 5, 2, 2, 2, 3, RT_LNF_ROWS>(a, wstat, st); return;
+        case 1: launch_v<A_DENSE, EPI_BF16, 4, 5, 2, 2, 2, 3, RT_LNF_ROWS>(a, wstat, st); return;
+        case 2: launch_v<A_DENSE, EPI_BF16, 7, 4, 2, 4, 1, 2, RT_LNF_ROWS>(a, wstat, st); return;
+        case 3: launch_v<A_DENSE, EPI_BF16, 8, 4, 2, 4, 1, 2, RT_LNF_ROWS>(a, wstat, st); return;
+        case 4: launch_v<A_DENSE, EPI_BF16, 7, 5, 2, 4, 1, 2, RT_LNF_ROWS>(a, wstat, st); return;
+        case 5: launch_v<A_DENSE, EPI_BF16, 8, 5, 2, 4, 1, 2, RT_LNF_ROWS>(a, wstat, st); return;
+        case 8: launch_v<A_DENSE, EPI_BF16, 4, 4, 2, 4, 1, 3, RT_LNF_ROWS>(a, wstat, st); return;
+        case 9: launch_v<A_DENSE, EPI_BF16, 2, 5, 2, 2, 2, 3, RT_LNF_ROWS>(a, wstat, st); return;
+        case 10: launch_v<A_DENSE, EPI_BF16, 4, 5, 2, 4, 1, 2, RT_LNF_ROWS>(a, wstat, st); return;
+        default: launch_v<A_DENSE, EPI_BF16, 2, 5, 2, 4, 1, 3, RT_LNF_ROWS>(a, wstat, st); return;
+    }
+}
+bool gemm16_ln_variant_ok(const GemmArgs& a, int v) {
+    if (a.mode != A_DENSE || v < 0) return false;
+    if (a.ln_part) return (a.ln_npart == 8 || a.ln_npart == 16) && ln_variant_ok(a.epi, v, a.weights_on_rows ? RT_LNF_COLS : RT_LNF_ROWS);
+    if (a.ln_emit) return a.N % (8 * RT_LN_BLOCK) == 0 && a.N / RT_LN_BLOCK <= 16 && a.ldo == a.N && ln_variant_ok(a.epi, v, RT_LNF_EMIT);
+    return true;
 }
 
 template <int MODE, int EPI>
@@ -401,6 +491,9 @@ bool gemm16_supported(const GemmArgs& a) {
 void launch_gemm16_variant(const GemmArgs& a, int v, int wstat, hipStream_t st) {
     RT_REQUIRE(gemm16_supported(a), "gemm16: problem outside the family's domain (dense K % 128 == 0, K >= 256; or a 3x3 stride-1 convolution with Cin % 64 == 0)");
     RT_REQUIRE(v >= 0 && v < RT_G16_NVAR, "gemm16: variant");
+    RT_REQUIRE(!(a.ln_part && a.ln_emit), "gemm16: a launch consumes OR produces LayerNorm partials");
+    if (a.ln_part) { launch_ln(a, v, wstat, a.weights_on_rows ? RT_LNF_COLS : RT_LNF_ROWS, st); return; }
+    if (a.ln_emit) { launch_ln(a, v, wstat, RT_LNF_EMIT, st); return; }
     if (a.mode == A_CONV3) {
         RT_REQUIRE(kVar[v].WK == 1 || (a.K / BK16) % 2 == 0, "gemm16: the K-split class needs an even number of K tiles");
         switch (a.epi) {
@@ -419,17 +512,17 @@ void launch_gemm16_variant(const GemmArgs& a, int v, int wstat, hipStream_t st) 
     }
 }
 
-template <int TMW_A, int TNW_A, int S_A, int TMW_B, int TNW_B>
+template <int TMW_A, int TNW_A, int S_A, int TMW_B, int TNW_B, bool LN = false>
 static void launch_dual_v(const GemmArgs& a, const GemmArgs& b, hipStream_t st) {
     constexpr int BMA = 2 * TMW_A * 16, BNA = 4 * TNW_A * 16, BMB = 2 * TMW_B * 16, BNB = 2 * TNW_B * 16;
-    constexpr int LDS_A = S_A * (BMA + BNA) * 128, LDS_B = 3 * (BMB + BNB) * 128, LDS = LDS_A > LDS_B ? LDS_A : LDS_B;
+    constexpr int LDS_A = S_A * (BMA + BNA) * 128, LDS_B = 3 * (BMB + BNB) * 128, LDS = (LDS_A > LDS_B ? LDS_A : LDS_B) + (LN ? RT_LN_TAB : 0);
     static bool attr = false;
     if (!attr) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)gemm16_dual_kernel<TMW_A, TNW_A, S_A, TMW_B, TNW_B>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        HIP_CHECK(hipFuncSetAttribute((const void*)gemm16_dual_kernel<TMW_A, TNW_A, S_A, TMW_B, TNW_B, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr = true;
     }
     const int nwg_a = cdiv(a.M, BMA) * cdiv(a.N, BNA), nwg_b = cdiv(b.M, BMB) * cdiv(b.N, BNB);
-    hipLaunchKernelGGL((gemm16_dual_kernel<TMW_A, TNW_A, S_A, TMW_B, TNW_B>), dim3(nwg_a + nwg_b), dim3(512), LDS, st, a, b, nwg_a);
+    hipLaunchKernelGGL((gemm16_dual_kernel<TMW_A, TNW_A, S_A, TMW_B, TNW_B, LN>), dim3(nwg_a + nwg_b), dim3(512), LDS, st, a, b, nwg_a);
     HIP_CHECK(hipGetLastError());
 }
 // Grouped launch of (a: tokens on the rows, class A) + (b: weights on the rows, class B transposed).  Returns false - nothing launched -
@@ -437,6 +530,7 @@ static void launch_dual_v(const GemmArgs& a, const GemmArgs& b, hipStream_t st) 
 int gemm16_pair_variant(const GemmArgs& a_in, const GemmArgs& b_in) {            // id of the grouped instantiation (0..3), -1: none
     if (a_in.mode != A_DENSE || b_in.mode != A_DENSE || a_in.epi != EPI_BF16 || b_in.epi != EPI_BF16 || a_in.weights_on_rows || !b_in.weights_on_rows) return -1;
     if (a_in.res || b_in.res || a_in.A_lo || b_in.A_lo) return -1;
+    if ((a_in.ln_part != nullptr) != (b_in.ln_part != nullptr) || a_in.ln_emit || b_in.ln_emit) return -1;       // both fold the same LayerNorm or neither
     int wa = 0, wb = 0;
     const int va = gemm16_pick(a_in, 0, &wa), vb = gemm16_pick(b_in, 1, &wb);
     if (wa || wb) return -1;
@@ -450,6 +544,17 @@ int gemm16_pair_variant(const GemmArgs& a_in, const GemmArgs& b_in) {           
 bool launch_gemm16_pair(const GemmArgs& a_in, const GemmArgs& b_in, hipStream_t st) {
     const int va = gemm16_pair_variant(a_in, b_in);
     if (va < 0) return false;
+    if (a_in.ln_part) {
+        RT_REQUIRE(a_in.ln_s && b_in.ln_s && (a_in.ln_npart == 8 || a_in.ln_npart == 16) && b_in.ln_npart == a_in.ln_npart && a_in.ln_inv_c > 0.f,
+                   "gemm16 pair: LayerNorm-fold consumer arguments");
+        switch (va) {
+            case 0: launch_dual_v<7, 5, 2, 5, 7, true>(a_in, b_in, st); break;
+            case 1: launch_dual_v<7, 4, 2, 5, 7, true>(a_in, b_in, st); break;
+            case 2: launch_dual_v<4, 4, 3, 5, 2, true>(a_in, b_in, st); break;
+            default: launch_dual_v<7, 4, 2, 5, 4, true>(a_in, b_in, st); break;
+        }
+        return true;
+    }
     switch (va) {
         case 0: launch_dual_v<7, 5, 2, 5, 7>(a_in, b_in, st); break;
         case 1: launch_dual_v<7, 4, 2, 5, 7>(a_in, b_in, st); break;

@@ -2,8 +2,8 @@
 // in - and by gemm16_tile, the device-function form the grouped launch (gemm16_dual_kernel) calls.  Two inclusions instead of one
 // function because hipcc allocates registers differently for the two forms: with the kernels calling a shared always-inline function the
 // fp16-trunk epilogues of the 224 x 160 K-split kernels spilled their residual window (196 B of scratch per lane), the kernel form does not.
-// In scope: template parameters MODE, EPI, TMW, TNW, WM, WN, WK, S; `p` (GemmArgs), `wstat`, `bid_in` (the workgroup's linear id inside
-// its problem's grid).
+// In scope: template parameters MODE, EPI, TMW, TNW, WM, WN, WK, S, LNF; `p` (GemmArgs), `wstat`, `bid_in` (the workgroup's linear id inside
+// its problem's grid).  LNF: LayerNorm fold (gemm16.hip, "LNF"): 0 none, 1 / 3 consumer (token rows / token columns), 2 producer of the partials.
     constexpr int NW = WM * WN * WK;                       // 8 waves (two per SIMD) or 4 waves (one per SIMD, 512 registers each)
     static_assert(NW == 8 || NW == 4, "4 or 8 waves");
     static_assert(WK == 1 || (WK == 2 && S == 3), "K split over at most two waves (3-slot ring)");
@@ -14,6 +14,12 @@
     constexpr int KS = 2 / WK;                             // 32-deep k steps per K tile and wave
     static_assert(EPI != EPI_GEGLU || TNW % 4 == 0, "GEGLU: a wave owns whole packed 64-column blocks [32 value | 32 gate]");
     static_assert((S - 2) * PW <= 63 && S >= 2 && S <= 3, "ring depth");
+    constexpr bool LNC = LNF == RT_LNF_ROWS || LNF == RT_LNF_COLS;    // consumer of a folded LayerNorm: fp16 operands, epilogue correction
+    static_assert(!LNC || (MODE == A_DENSE && (EPI == EPI_BF16 || EPI == EPI_GEGLU)), "LayerNorm fold: dense bf16-output / GEGLU consumers");
+    static_assert(LNF != RT_LNF_EMIT || (MODE == A_DENSE && EPI == EPI_F16 && TNW == 5), "LayerNorm partials: fp16-trunk epilogue, 80-column wave tiles");
+    static_assert(LNF != RT_LNF_COLS || EPI == EPI_BF16, "column statistics: the V^T form");
+    constexpr int LN_NST = LNF == RT_LNF_COLS ? BN : BM;   // token rows (columns) of the tile whose (mu, rstd) the workgroup tabulates
+    static_assert(!LNC || (LN_NST * 8 <= 2560 && LN_NST <= NW * 64 && BM <= 320 && BN <= 320 && BM <= NW * 64 && BN <= NW * 64), "statistics table: [320] (mu, rstd) | [320] s | [320] c");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     G16_T(0)
@@ -45,6 +51,31 @@
     const int xa_b = EPI == EPI_XATTN ? m0 / p.xa_tokens : 0;
     const int xa_prompt = EPI == EPI_XATTN ? p.xa_prompt[xa_b] : 0, xa_wset = EPI == EPI_XATTN ? p.xa_wset[xa_b] : -1;
     const int xa_head0 = n0 >> 6;
+    // LNF consumers: thread t requests the partial sums of token row (column) t of the tile NOW, ahead of the prologue's LDS-DMA pieces
+    // (VMEM loads retire in order: the first counted wait of the prologue covers them); they become the (mu, rstd) table behind the
+    // first barrier.  ln_npart = C / 80 float2 partials per token, 8 or 16 (host-checked): four or eight 16-B loads.
+    float4 lnp[LNC ? 8 : 1];
+    if constexpr (LNC) {
+        int trow = (LNF == RT_LNF_COLS ? n0 : m0) + tid;
+        const int lim = LNF == RT_LNF_COLS ? p.N : p.M;
+        if (trow >= lim) trow = lim - 1;
+        const float4* pp = (const float4*)(p.ln_part + (size_t)trow * p.ln_npart * 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lnp[j] = pp[j];
+#pragma unroll
+        for (int j = 4; j < 8; ++j) lnp[j] = p.ln_npart > 8 ? pp[j] : float4{0.f, 0.f, 0.f, 0.f};
+    }
+    // ... and s / c of weight row (V^T form: of the tile's weight rows; else: of its columns) t: staged in the same table, so that the
+    // epilogue needs no registers for them before the K-split exchange has freed half of the accumulators
+    constexpr int LN_NW = LNF == RT_LNF_COLS ? BM : BN;    // weight rows of the tile
+    float ln_sw = 0.f, ln_cw = 0.f;
+    if constexpr (LNC) {
+        int wrow = (LNF == RT_LNF_COLS ? m0 : n0) + tid;
+        const int lim = LNF == RT_LNF_COLS ? p.M : p.N;
+        if (wrow >= lim) wrow = lim - 1;
+        ln_sw = p.ln_s[wrow];
+        ln_cw = p.bias ? p.bias[wrow] : 0.f;
+    }
 
     // ---- loader: piece i of this wave copies 8-row group g = i*NW + wave of the (A rows | W rows) list.  Buffer-descriptor LDS-DMA
     // (buffer_load_dwordx4 ... offen lds, guide T8): per piece ONE 32-bit VGPR byte offset, the K-tile offset is a scalar (soffset)
@@ -157,6 +188,25 @@
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     G16_T(1)
+    if constexpr (LNC) {
+        // (mu, rstd) of the tile's tokens -> LDS behind the ring; read in the epilogue, many barriers later.  Fixed summation order.
+        // Written by inline ds_write_b64: in front of a compiler-visible LDS store hipcc's waitcnt pass would put s_waitcnt vmcnt(0),
+        // i.e. wait for every ring slot in flight (LABNOTES R4.1).
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s1 += lnp[j].x; s2 += lnp[j].y; s1 += lnp[j].z; s2 += lnp[j].w; }
+        const float mu = s1 * p.ln_inv_c;
+        const float var = fmaxf(s2 * p.ln_inv_c - mu * mu, 0.f);
+        const float rs = rsqrtf(var + p.ln_eps);
+        const unsigned tbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(smem + S * STAGE);
+        if (tid < LN_NST) {
+            const unsigned long long w64 = ((unsigned long long)__float_as_uint(rs) << 32) | __float_as_uint(mu);
+            asm volatile("ds_write_b64 %0, %1" ::"v"(tbase + (unsigned)tid * 8u), "v"(w64) : "memory");
+        }
+        if (tid < LN_NW) {
+            asm volatile("ds_write_b32 %0, %1 offset:2560\n\tds_write_b32 %0, %2 offset:3840" ::"v"(tbase + (unsigned)tid * 4u), "v"(ln_sw), "v"(ln_cw) : "memory");
+        }
+    }
     bf16x8 fa[TMW], fb[2][TNW];
 #pragma unroll
     for (int j = 0; j < TNW; ++j) fb[0][j] = *(const bf16x8*)(smem + boff[0] + j * 2048);
@@ -183,7 +233,7 @@
 #if RT_G16_ABLATE == 2
             asm volatile("" ::"v"(fb[CUR][j]), "v"(fa[0]));
 #else
-            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[CUR][j], fa[0], acc[0][j], 0, 0, 0);
+            acc[0][j] = g16_mma<LNC>(fb[CUR][j], fa[0], acc[0][j]);
 #endif
         }
         if constexpr (NEXT == 2) {
@@ -204,7 +254,7 @@
 #if RT_G16_ABLATE == 2
                 asm volatile("" ::"v"(fb[CUR][j]), "v"(fa[i]));
 #else
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[CUR][j], fa[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = g16_mma<LNC>(fb[CUR][j], fa[i], acc[i][j]);
 #endif
             }
             if constexpr (NEXT != 0) fa[i] = *(const bf16x8*)(na + i * 2048);
@@ -282,8 +332,11 @@
     constexpr int NIT = (16 * IPR + 63) / 64;
     // a rolling window of RW owned tiles (static register indices: the s-th owned tile of a wave is tile s or H0 + s)
     constexpr int NOWN = WK == 2 ? H0 : TMW;                         // owned tiles of the kh = 0 half (kh = 1 owns TMW - H0 <= H0)
-    constexpr int RW = NOWN < 4 ? NOWN : 4;
-    uint4 rres[F16 ? RW : 1][F16 ? NIT : 1];
+    constexpr int RW = NOWN < 4 ? NOWN : ((LNF == RT_LNF_EMIT && WK == 2) ? 3 : 4);   // (producer of the LayerNorm partials, K-split form: a window of three tiles keeps it free of scratch)
+    // (producer of the LayerNorm partials: the window as ext-vector values that an empty asm pins at their use - see the store loop)
+    typedef unsigned int g16_u4 __attribute__((ext_vector_type(4)));
+    using RresT = std::conditional_t<LNF == RT_LNF_EMIT, g16_u4, uint4>;
+    RresT rres[F16 ? RW : 1][F16 ? NIT : 1];
     auto load_res = [&](int s_own, int slot) {                       // residual of the s_own-th owned tile -> window slot (static)
         const int i = (WK == 2 && kh == 1) ? H0 + s_own : s_own;
 #pragma unroll
@@ -292,7 +345,7 @@
             const int r = idx / IPR, c8 = idx - r * IPR;
             int row = m0 + (wm * TMW + i) * 16 + r; if (row >= p.M) row = p.M - 1;
             int col = ocol0 + c8 * 8; if (col >= NO) col = 0;
-            if (F16) rres[F16 ? slot : 0][F16 ? it : 0] = (r < 16 && i < TMW) ? *(const uint4*)((const f16_t*)p.res + (size_t)row * p.ldres + col) : uint4{0, 0, 0, 0};
+            if (F16) rres[F16 ? slot : 0][F16 ? it : 0] = (r < 16 && i < TMW) ? *(const RresT*)((const f16_t*)p.res + (size_t)row * p.ldres + col) : RresT{0, 0, 0, 0};
         }
     };
     // K-split forms: ahead of the exchange (its round trip, 7 - 8 k cycles for the chip-wide 18 MB burst, hides behind the LDS pass:
@@ -313,7 +366,7 @@
     for (int t = 0; t < TNO; ++t) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { bias_v[t][e] = 0.f; if (EPI == EPI_GEGLU) bias_g[t][e] = 0.f; }
-        if (p.bias) {
+        if (p.bias && !LNC) {
             if constexpr (EPI == EPI_GEGLU) {
                 // packed columns: per 64-block [32 value | 32 gate]; output tile t (16 columns) = value tile 4*(t/2) + t%2, gate + 2
                 const int col = wcol0 + ((t >> 1) * 4 + (t & 1)) * 16 + 4 * q4;
@@ -364,6 +417,24 @@
         __builtin_amdgcn_s_barrier();                                // the exchange region becomes the transpose slabs
     }
     G16_T(3)
+    // LNF consumers: s / c of this wave's columns out of the table behind the ring (c takes the place of the bias)
+    float lns_v[LNF == RT_LNF_ROWS ? TNO : 1][4], lns_g[(LNF == RT_LNF_ROWS && EPI == EPI_GEGLU) ? TNO : 1][4];
+    if constexpr (LNF == RT_LNF_ROWS) {
+        const char* tb = smem + S * STAGE;
+#pragma unroll
+        for (int t = 0; t < TNO; ++t) {
+            const int cl = wn * TNW * 16 + (EPI == EPI_GEGLU ? ((t >> 1) * 4 + (t & 1)) * 16 : t * 16) + 4 * q4;     // column inside the tile (GEGLU: packed value column)
+            const float4 sv = *(const float4*)(tb + 2560 + cl * 4), cv = *(const float4*)(tb + 3840 + cl * 4);
+            lns_v[t][0] = sv.x; lns_v[t][1] = sv.y; lns_v[t][2] = sv.z; lns_v[t][3] = sv.w;
+            bias_v[t][0] = cv.x; bias_v[t][1] = cv.y; bias_v[t][2] = cv.z; bias_v[t][3] = cv.w;
+            if constexpr (EPI == EPI_GEGLU) {
+                constexpr int tg = EPI == EPI_GEGLU ? 1 : 0;
+                const float4 sg = *(const float4*)(tb + 2560 + (cl + 32) * 4), cg = *(const float4*)(tb + 3840 + (cl + 32) * 4);
+                lns_g[tg * t][0] = sg.x; lns_g[tg * t][1] = sg.y; lns_g[tg * t][2] = sg.z; lns_g[tg * t][3] = sg.w;
+                bias_g[tg * t][0] = cg.x; bias_g[tg * t][1] = cg.y; bias_g[tg * t][2] = cg.z; bias_g[tg * t][3] = cg.w;
+            }
+        }
+    }
     if constexpr (F16 && !RES_EARLY) {
         if (p.res) {
 #pragma unroll
@@ -376,6 +447,9 @@
     constexpr int RS = TNO * 16 * ES + 16;                           // slab row stride (16-B pad: conflict-free 16-B column writes)
     static_assert(NW * 16 * RS <= S * STAGE, "slabs");
     char* slab = smem + (size_t)wave * 16 * RS;
+    static_assert(LNF != RT_LNF_EMIT || (IPR == 10 && NW * 16 * RS + NW * 16 * IPR * 8 <= S * STAGE), "partials scratch behind the slabs");
+    const unsigned ln_scr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(smem + NW * 16 * RS + wave * (16 * IPR * 8));
+    (void)ln_scr;
     if constexpr (!BIAS_EARLY) load_bias();
 #ifdef RT_G16_TIMING
     { float bsum = 0.f; for (int t = 0; t < TNO; ++t) bsum += bias_v[t][0]; asm volatile("" ::"v"(bsum)); G16_T(5) }
@@ -383,6 +457,17 @@
 #pragma unroll
     for (int i = 0; i < TMW; ++i) {
         if (!owned(i)) continue;
+        // LNF consumers: (mu, rstd) of the lane's token row / s, c of its weight row, from the table
+        float ln_mu = 0.f, ln_rs = 1.f, ln_sr = 0.f, ln_cr = 0.f;
+        if constexpr (LNF == RT_LNF_ROWS) {
+            const float2 st = *(const float2*)(smem + S * STAGE + ((wm * TMW + i) * 16 + l15) * 8);
+            ln_mu = st.x; ln_rs = st.y;
+        }
+        if constexpr (LNF == RT_LNF_COLS) {
+            ln_sr = *(const float*)(smem + S * STAGE + 2560 + ((wm * TMW + i) * 16 + l15) * 4);
+            ln_cr = *(const float*)(smem + S * STAGE + 3840 + ((wm * TMW + i) * 16 + l15) * 4);
+        }
+        (void)ln_mu; (void)ln_rs; (void)ln_sr; (void)ln_cr;
         // registers -> slab
 #pragma unroll
         for (int t = 0; t < TNO; ++t) {
@@ -391,11 +476,27 @@
                 const int tv = (t >> 1) * 4 + (t & 1);
 #pragma unroll
                 for (int e = 0; e < 4; e += 2) {                     // two gates per packed-fp32 issue slot
-                    const f32x2 gt = {acc[i][tv + 2][e] + bias_g[t][e], acc[i][tv + 2][e + 1] + bias_g[t][e + 1]};
-                    const f32x2 vl = {acc[i][tv][e] + bias_v[t][e], acc[i][tv][e + 1] + bias_v[t][e + 1]};
+                    f32x2 gt, vl;
+                    if constexpr (LNF == RT_LNF_ROWS) {              // LN(x) W^T + b = rstd (x W'^T - mu s) + c, in front of the gelu
+                        const float mu = ln_mu, rs = ln_rs;
+                        constexpr int tg = (LNF == RT_LNF_ROWS && EPI == EPI_GEGLU) ? 1 : 0;
+                        gt = f32x2{fmaf(rs, fmaf(-mu, lns_g[tg * t][e], acc[i][tv + 2][e]), bias_g[t][e]), fmaf(rs, fmaf(-mu, lns_g[tg * t][e + 1], acc[i][tv + 2][e + 1]), bias_g[t][e + 1])};
+                        vl = f32x2{fmaf(rs, fmaf(-mu, lns_v[t][e], acc[i][tv][e]), bias_v[t][e]), fmaf(rs, fmaf(-mu, lns_v[t][e + 1], acc[i][tv][e + 1]), bias_v[t][e + 1])};
+                    } else {
+                        gt = f32x2{acc[i][tv + 2][e] + bias_g[t][e], acc[i][tv + 2][e + 1] + bias_g[t][e + 1]};
+                        vl = f32x2{acc[i][tv][e] + bias_v[t][e], acc[i][tv][e + 1] + bias_v[t][e + 1]};
+                    }
                     const f32x2 o = vl * gelu_erf_x2(gt);
                     v[e] = o.x; v[e + 1] = o.y;
                 }
+            } else if constexpr (LNF == RT_LNF_ROWS) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(ln_rs, fmaf(-ln_mu, lns_v[LNF == RT_LNF_ROWS ? t : 0][e], acc[i][t][e]), bias_v[t][e]);
+            } else if constexpr (LNF == RT_LNF_COLS) {
+                const float4 ca = *(const float4*)(smem + S * STAGE + (wn * TNW * 16 + t * 16 + 4 * q4) * 8);            // (mu, rstd) of columns 4 q4, 4 q4 + 1
+                const float4 cb = *(const float4*)(smem + S * STAGE + (wn * TNW * 16 + t * 16 + 4 * q4) * 8 + 16);       // ... + 2, + 3
+                v[0] = fmaf(ca.y, fmaf(-ca.x, ln_sr, acc[i][t][0]), ln_cr); v[1] = fmaf(ca.w, fmaf(-ca.z, ln_sr, acc[i][t][1]), ln_cr);
+                v[2] = fmaf(cb.y, fmaf(-cb.x, ln_sr, acc[i][t][2]), ln_cr); v[3] = fmaf(cb.w, fmaf(-cb.z, ln_sr, acc[i][t][3]), ln_cr);
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][t][e] + bias_v[t][e];
@@ -415,6 +516,16 @@
         // slab -> HBM (LDS operations of one wave execute in order: no barrier)
         const int row0 = m0 + (wm * TMW + i) * 16;
         if constexpr (F16) {
+            // (producer of the LayerNorm partials: nothing of this tile's store section may move above this point - with the partial-sum
+            //  code in the loop the scheduler otherwise converts the whole residual window to fp32 where it is loaded: twice the registers,
+            //  scratch, and the wait for the residual's round trip in front of the K-split exchange instead of behind it)
+            if constexpr (LNF == RT_LNF_EMIT) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (p.res) {
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(rres[F16 ? ((i < H0 ? i : i - H0) % RW) : 0][F16 ? it : 0]));
+                }
+            }
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int idx = it * 64 + lane;
@@ -432,6 +543,33 @@
 #pragma unroll
                 for (int e = 0; e < 8; ++e) oh[e] = (f16_t)v[e];
                 *(uint4*)((f16_t*)p.out + (size_t)row * p.ldo + col) = o;
+                if constexpr (LNF == RT_LNF_EMIT) {
+                    // sum / sum of squares of the 8 ROUNDED trunk values of this item -> the wave's scratch [16 rows][10 items] behind the slabs.
+                    // Inline ds_write_b64 / ds_read_b64 below: compiler-visible LDS traffic behind a global store makes hipcc's waitcnt pass
+                    // wait for the store (vmcnt(0)); a wave's LDS operations execute in order, which is all that is needed here.
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float x = (float)oh[e]; s1 += x; s2 = fmaf(x, x, s2); }
+                    const unsigned long long w64 = ((unsigned long long)__float_as_uint(s2) << 32) | __float_as_uint(s1);
+                    asm volatile("ds_write_b64 %0, %1" ::"v"(ln_scr + (unsigned)idx * 8u), "v"(w64) : "memory");
+                }
+            }
+            if constexpr (LNF == RT_LNF_EMIT) {
+                // lane (row rr, quarter jj) adds items jj, jj + 4, jj + 8 of its row, the four quarters meet by two quad-DPP exchanges
+                // (fixed order: deterministic); quarter 0 stores the row's (sum, sum of squares) over these 80 columns
+                const int rr = lane >> 2, jj = lane & 3;
+                unsigned long long x0, x1, x2;
+                asm volatile("ds_read_b64 %0, %3\n\tds_read_b64 %1, %3 offset:32\n\tds_read_b64 %2, %3 offset:64\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(x0), "=&v"(x1), "=&v"(x2) : "v"(ln_scr + (unsigned)(rr * IPR + jj) * 8u) : "memory");
+                float a1 = __uint_as_float((unsigned)x0) + __uint_as_float((unsigned)x1);
+                float a2 = __uint_as_float((unsigned)(x0 >> 32)) + __uint_as_float((unsigned)(x1 >> 32));
+                if (jj < 2) { a1 += __uint_as_float((unsigned)x2); a2 += __uint_as_float((unsigned)(x2 >> 32)); }
+                a1 += __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(a1), 0xB1, 0xF, 0xF, true));     // quad_perm [1, 0, 3, 2]
+                a2 += __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(a2), 0xB1, 0xF, 0xF, true));
+                a1 += __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(a1), 0x4E, 0xF, 0xF, true));     // quad_perm [2, 3, 0, 1]
+                a2 += __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(a2), 0x4E, 0xF, 0xF, true));
+                if (jj == 0 && row0 + rr < p.M)
+                    *(float2*)(p.ln_emit + ((size_t)(row0 + rr) * (p.N / RT_LN_BLOCK) + ocol0 / RT_LN_BLOCK) * 2) = make_float2(a1, a2);
             }
             // the window slot of this tile is free: request the residual of the owned tile RW positions further on
             const int s_own = i < H0 ? i : i - H0;                   // compile-time after unrolling

@@ -425,3 +425,67 @@ void launch_layernorm(const void* x, int x_f16, const float* gamma, const float*
 #undef RT_LN
     HIP_CHECK(hipGetLastError());
 }
+
+// ---------------------------------------------------------------------------------------------- LayerNorm fold (gemm16.hip, "LNF")
+// W' = fp16(gamma_k W_nk) from the packed bf16 weight, s_n = sum_k W'_nk (of the ROUNDED values: the correction must cancel what the
+// MFMA adds up), c_n = b_n + sum_k beta_k W_nk  (models/attention.py:150,168,181: norm1 -> attn1, norm2 -> attn2, norm3 -> ff).
+// One workgroup per weight row, fixed-order tree reduction: a pure function of the checkpoint (every rank derives the same bits).
+__global__ __launch_bounds__(256) void ln_fold_derive_kernel(const bf16_t* __restrict__ W, int ldw, const float* __restrict__ bias,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta, int K,
+                                                             f16_t* __restrict__ Wf, float* __restrict__ s_out, float* __restrict__ c_out) {
+    __shared__ float red[2][256];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    float s = 0.f, c = 0.f;
+    for (int k = tid; k < K; k += 256) {
+        const float w = bf16_to_f32(W[(size_t)n * ldw + k]);
+        const f16_t wf = (f16_t)(gamma[k] * w);
+        Wf[(size_t)n * ldw + k] = wf;
+        s += (float)wf;
+        c = fmaf(beta[k], w, c);
+    }
+    red[0][tid] = s; red[1][tid] = c;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if (tid < h) { red[0][tid] += red[0][tid + h]; red[1][tid] += red[1][tid + h]; }
+        __syncthreads();
+    }
+    if (tid == 0) { s_out[n] = red[0][0]; c_out[n] = red[1][0] + (bias ? bias[n] : 0.f); }
+}
+void launch_ln_fold_derive(const bf16_t* W, int ldw, const float* bias, const float* gamma, const float* beta, int N, int K,
+                           f16_t* Wf, float* s, float* c, hipStream_t st) {
+    RT_REQUIRE(N > 0 && K > 0 && ldw >= K, "ln_fold_derive: shape");
+    hipLaunchKernelGGL(ln_fold_derive_kernel, dim3(N), dim3(256), 0, st, W, ldw, bias, gamma, beta, K, Wf, s, c);
+    HIP_CHECK(hipGetLastError());
+}
+
+// Stand-alone producer of the partials the fp16-trunk epilogues of gemm16.hip emit (LNF = 2): part[row][C / 80] = (sum, sum of squares)
+// of 80 consecutive trunk values, added in the SAME order as there (8-value items sequentially; items j, j + 4, j + 8 per quarter; the
+// quarters as (q0 + q1) + (q2 + q3)), so a trunk that some other kernel produced gives the consumer bit-identical statistics.
+__global__ __launch_bounds__(256) void ln_partials_kernel(const f16_t* __restrict__ x, float* __restrict__ part, int rows, int nblk) {
+    const long id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (long)rows * nblk) return;
+    const f16_t* p = x + id * 80;                                     // rows are dense: row * C + blk * 80 = id * 80
+    float i1[10], i2[10];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+        const uint4 v = *(const uint4*)(p + j * 8);
+        const f16_t* h = (const f16_t*)&v;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float f = (float)h[e]; s1 += f; s2 = fmaf(f, f, s2); }
+        i1[j] = s1; i2[j] = s2;
+    }
+    float q1[4], q2[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        q1[jj] = i1[jj] + i1[jj + 4]; q2[jj] = i2[jj] + i2[jj + 4];
+        if (jj < 2) { q1[jj] += i1[jj + 8]; q2[jj] += i2[jj + 8]; }
+    }
+    *(float2*)(part + id * 2) = make_float2((q1[0] + q1[1]) + (q1[2] + q1[3]), (q2[0] + q2[1]) + (q2[2] + q2[3]));
+}
+void launch_ln_partials(const f16_t* x, float* part, int rows, int C, hipStream_t st) {
+    RT_REQUIRE(rows > 0 && C % 80 == 0, "ln_partials: C must be a multiple of 80");
+    const long n = (long)rows * (C / 80);
+    hipLaunchKernelGGL(ln_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, part, rows, C / 80);
+    HIP_CHECK(hipGetLastError());
+}
