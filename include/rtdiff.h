@@ -211,20 +211,24 @@ int rt_op_layernorm(const float* x, const float* gamma, const float* beta, void*
 int rt_op_layernorm_f16(const void* x_f16, const float* gamma, const float* beta, void* out_bf16, int rows, int C, float eps, void* stream);
 /* LayerNorm folded into the projection that consumes it (round 6; csrc/gemm16.hip "LNF").  BasicTransformerBlock applies norm1 / norm2 /
  * norm3 in front of attn1 / attn2 / ff (/root/reference/models/attention.py:150,168,181); the engine computes
- *     LN(x) W^T + b = rstd (x W'^T - mu s) + c,   W' = fp16(gamma W),  s = row sums of W',  c = b + W beta
- * on the RAW fp16 trunk with fp16 MFMA operands, (mu, rstd) of a token from per-row partial sums over 80-column blocks that the trunk's
- * producer leaves (`partials` [tokens][C / 80][2] fp32: sum, sum of squares), eps = 1e-5.
- * rt_op_ln_gemm: x fp16 [tokens, C]; W bf16 packed [N, C] (GEGLU: rows interleaved per 64-block [32 value | 32 gate], as rt_op_gemm epi 3);
+ *     LN(x) W^T + b = rstd (xb W'^T - mu s) + c,   W' = bf16(gamma W),  s = row sums of W',  c = b + W beta
+ * on xb = the UN-normalised trunk as bf16, which the trunk's producer leaves next to the fp16 trunk together with ONE (sum, sum of squares)
+ * of xb per token and column tile of its grid (`tile_cols` = 160 or 320 columns), from which (mu, rstd) of a token follow; eps = 1e-5.
+ * `partials`: pair-major [C / tile_cols / 2][tokens] float4 = (sum, sumsq) of two neighbouring tiles.
+ * rt_op_ln_gemm: W bf16 packed [N, C] (GEGLU: rows interleaved per 64-block [32 value | 32 gate], as rt_op_gemm epi 3);
  *   epi 0: out bf16 [tokens, N] (weights_on_rows = 1: out = [N, tokens], the V^T form) | epi 3: GEGLU, out bf16 [tokens, N / 2];
- *   partials NULL: computed here by the stand-alone kernel.  C = 640 or 1280.  RT_E_UNSUPPORTED (-5) when the shape has no folded form
- *   (the engine then keeps the LayerNorm launch).  rows_per_stream as rt_op_gemm16_pick.
- * rt_op_gemm_emit_partials: the fp16-trunk GEMM (rt_op_gemm epi 4, optional fp16 residual) that ALSO leaves the partials of its output rows
- *   (N = 640 or 1280); RT_E_UNSUPPORTED when the shape's tile variant has no such epilogue. */
+ *   (xb_bf16, partials) as a producer left them, or both NULL: made here from the fp16 trunk x_f16 [tokens, C] by the stand-alone kernel.
+ *   C = 640 or 1280.  RT_E_UNSUPPORTED (-5) when the shape has no folded form (the engine then keeps the LayerNorm launch).
+ *   rows_per_stream as rt_op_gemm16_pick.
+ * rt_op_gemm_emit_partials: the fp16-trunk GEMM (rt_op_gemm epi 4, optional fp16 residual) that ALSO leaves xb [M, N] bf16 and the
+ *   partials of its output rows (N = 640 or 1280; *tile_cols = the width its tile class uses); RT_E_UNSUPPORTED when the shape's tile
+ *   variant has no such epilogue. */
 int rt_op_ln_gemm(const void* x_f16, const float* gamma, const float* beta, const void* W_bf16, const float* bias, void* out, int tokens,
-                  int N, int C, int epi, int weights_on_rows, int rows_per_stream, const float* partials, void* stream);
+                  int N, int C, int epi, int weights_on_rows, int rows_per_stream, const void* xb_bf16, const float* partials, int tile_cols,
+                  void* stream);
 int rt_op_gemm_emit_partials(const void* A, const void* W, const float* bias, void* out_f16, const void* res_f16, int M, int N, int K,
-                             int rows_per_stream, float* partials, void* stream);
-int rt_op_ln_partials(const void* x_f16, float* partials, int rows, int C, void* stream);      /* the stand-alone producer of the same partials */
+                             int rows_per_stream, void* xb_bf16, float* partials, int* tile_cols, void* stream);
+int rt_op_ln_partials(const void* x_f16, void* xb_bf16, float* partials, int rows, int C, int tile_cols, void* stream);      /* the stand-alone producer of (xb, partials) */
 int rt_op_small_linear(const float* a, int lda, const void* W_bf16, int ldw, const float* bias, float* out, int ldo,
                        int B, int N, int K, int silu_in, int accumulate, void* stream);
 int rt_op_timestep_embed(const float* t, int n, int dim, float* out, int ldo, void* stream);

@@ -151,23 +151,29 @@ struct GemmArgs {
     const float* xa_wabs; const float* xa_wsgn;      // [nsets, 96] font-size multipliers (attention_processor.py:386-401)
     int xa_prompt[RT_MAXB], xa_wset[RT_MAXB];        // per stream: prompt index into the cache, multiplier set (-1: plain softmax)
     // LayerNorm folded into the projections (gemm16.hip, "LNF"; models/attention.py:150,168,181).
-    //  consumer (ln_part != null; EPI_BF16 / EPI_GEGLU on the 16x16x32 family only): the token operand (A, or W when weights_on_rows) is the
-    //    RAW fp16 trunk, the weight operand is W' = fp16(gamma W) (ln_fold_derive), `bias` = c = b + W beta, ln_s = row sums of W';
-    //    out = rstd (x W'^T - mu s) + c with (mu, rstd) of every token from ln_part [tokens][ln_npart] float2 (sum, sum of squares)
-    //  producer (ln_emit != null; EPI_F16 on the 16x16x32 family's 80-column wave tiles): leaves those partials of its OUTPUT rows
-    const float* ln_part; int ln_npart;
+    //  consumer (ln_part != null; EPI_BF16 / EPI_GEGLU on the 16x16x32 family only): the token operand (A, or W when weights_on_rows) is
+    //    xb = the UN-normalised trunk as bf16, the weight operand is W' = bf16(gamma W) (ln_fold_derive), ln_s = [weight rows] (s, c)
+    //    pairs: s = row sums of W', c = b + W beta (`bias` is unused); out = rstd (xb W'^T - mu s) + c with (mu, rstd) of every token
+    //    from ln_part: one (sum, sum of squares) of xb per token and column tile of the producer, pair-major [ln_npair][ln_ld] float4
+    //    = two tiles each (ln_npair = 1, 2 or 4)
+    //  producer (ln_emit != null; EPI_F16 on the 16x16x32 family's 80-column wave tiles): besides the fp16 trunk leaves xb in ln_copy
+    //    [M, ldo] and that array for its OUTPUT rows in ln_emit (ln_ld = M)
+    const float* ln_part; int ln_npair;
+    int ln_ld;
     const float* ln_s;
     float ln_inv_c, ln_eps;
+    bf16_t* ln_copy;
     float* ln_emit;
 };
 // LayerNorm fold plumbing (host-only predicates are pure functions of the shape, like every routing decision)
 int gemm_route16(const GemmArgs& a);                    // variant of the 16x16x32 family launch_gemm would take for this problem, -1: another route
-bool gemm_ln_emit_ok(const GemmArgs& a);                // launch_gemm(a) with a.ln_emit set would leave the partials (EPI_F16, 80-column wave tiles, N % 640 == 0)
+int gemm_ln_emit_bn(const GemmArgs& a);                 // column-tile width (160 / 320) of the partials launch_gemm(a) with a.ln_emit set would leave; 0: this route has no such epilogue
 bool gemm_ln_fold_ok(const GemmArgs& a);                // launch_gemm(a) with a.ln_part set has a folded instantiation
 bool gemm16_ln_variant_ok(const GemmArgs& a, int v);    // gemm16.hip: variant v has the LayerNorm-fold instantiation a.ln_part / a.ln_emit ask for
-void launch_ln_partials(const f16_t* x, float* part, int rows, int C, hipStream_t st);      // stand-alone producer of the same partials (norm.hip)
+void launch_ln_partials(const f16_t* x, bf16_t* xb, float* part, int rows, int C, int bn, hipStream_t st);      // stand-alone producer of xb + partials (column tiles of bn = 160 / 320) from an fp16 trunk (norm.hip)
 void launch_ln_fold_derive(const bf16_t* W, int ldw, const float* bias, const float* gamma, const float* beta, int N, int K,
-                           f16_t* Wf, float* s, float* c, hipStream_t st);                 // W' = fp16(gamma W), s = row sums of W', c = bias + W beta
+                           bf16_t* Wf, float* sc, hipStream_t st);                         // W' = bf16(gamma W), sc[n] = (row sum of W', bias + W beta)
+int gemm16_variant_bn(int v);                           // column-tile width of a gemm16 variant
 // Fused to_q -> 77-key cross-attention (one launch instead of two; Q never reaches HBM).  Eligible: head dim 64, H * 64 % 320 == 0,
 // tokens % 128 == 0, C % 64 == 0, C >= 192.
 bool xattn_fused_supported(int C, int H, int DP, int tokens);

@@ -78,8 +78,8 @@ struct ResnetP {
 struct TBlockP {
     NormW ln1, ln2, ln3;
     MatW qk1, v1, out1, q2, k2, v2, out2, ff1, ff2;
-    // LayerNorm folded into its consumers (gemm16.hip, "LNF"): W' = fp16(gamma W) in the place of w, c = b + W beta in the place of b,
-    // s = row sums of W'.  Derived from the packed arena by ensure_fold(); null when the block's width has no folded form.
+    // LayerNorm folded into its consumers (gemm16.hip, "LNF"): W' = bf16(gamma W) in the place of w (no .b), and per weight row the pair
+    // (s, c) = (row sum of W', b + W beta).  Derived from the packed arena by ensure_fold(); null when the block's width has no folded form.
     MatW qk1f, v1f, q2f, ff1f;
     float* qk1s = nullptr; float* v1s = nullptr; float* q2s = nullptr; float* ff1s = nullptr;
     bf16_t* kcache = nullptr;    // [maxP*96, H*DP]
@@ -297,10 +297,10 @@ struct rt_engine {
         for (auto& sl : slots) if (!sl.bound) return;                   // not all weights are there yet
         for_each_tblock([&](TransformerP& t, TBlockP& k) {
             if (!k.qk1f.w) return;
-            launch_ln_fold_derive(k.qk1.w, k.qk1.K, k.qk1.b, k.ln1.g, k.ln1.b, k.qk1.N, k.qk1.K, (f16_t*)k.qk1f.w, k.qk1s, k.qk1f.b, stream);
-            launch_ln_fold_derive(k.v1.w, k.v1.K, k.v1.b, k.ln1.g, k.ln1.b, k.v1.N, k.v1.K, (f16_t*)k.v1f.w, k.v1s, k.v1f.b, stream);
-            launch_ln_fold_derive(k.q2.w, k.q2.K, k.q2.b, k.ln2.g, k.ln2.b, k.q2.N, k.q2.K, (f16_t*)k.q2f.w, k.q2s, k.q2f.b, stream);
-            launch_ln_fold_derive(k.ff1.w, k.ff1.K, k.ff1.b, k.ln3.g, k.ln3.b, k.ff1.N, k.ff1.K, (f16_t*)k.ff1f.w, k.ff1s, k.ff1f.b, stream);
+            launch_ln_fold_derive(k.qk1.w, k.qk1.K, k.qk1.b, k.ln1.g, k.ln1.b, k.qk1.N, k.qk1.K, k.qk1f.w, k.qk1s, stream);
+            launch_ln_fold_derive(k.v1.w, k.v1.K, k.v1.b, k.ln1.g, k.ln1.b, k.v1.N, k.v1.K, k.v1f.w, k.v1s, stream);
+            launch_ln_fold_derive(k.q2.w, k.q2.K, k.q2.b, k.ln2.g, k.ln2.b, k.q2.N, k.q2.K, k.q2f.w, k.q2s, stream);
+            launch_ln_fold_derive(k.ff1.w, k.ff1.K, k.ff1.b, k.ln3.g, k.ln3.b, k.ff1.N, k.ff1.K, k.ff1f.w, k.ff1s, stream);
         });
         fold_dirty = false;
     }
@@ -345,9 +345,8 @@ struct rt_engine {
             if (ln_fold_width(C)) {
                 auto mkf = [&](const MatW& w, MatW& f, float*& sv) {
                     f.N = w.N; f.K = w.K;
-                    f.w = (bf16_t*)farena.alloc((size_t)w.N * w.K * 2);                 // fp16 bits
-                    f.b = (float*)farena.alloc((size_t)w.N * 4);
-                    sv = (float*)farena.alloc((size_t)w.N * 4);
+                    f.w = (bf16_t*)farena.alloc((size_t)w.N * w.K * 2);
+                    sv = (float*)farena.alloc((size_t)w.N * 8);
                 };
                 mkf(k.qk1, k.qk1f, k.qk1s); mkf(k.v1, k.v1f, k.v1s); mkf(k.q2, k.q2f, k.q2s); mkf(k.ff1, k.ff1f, k.ff1s);
             }
@@ -427,12 +426,12 @@ struct rt_engine {
         g.splitk_ws = splitk_buf; g.splitk_ws_floats = splitk_floats;
         return true;
     }
-    // LayerNorm fold of a launch (gemm16.hip, "LNF"): `part` set = consumer (A / X is the raw fp16 trunk, W the folded copy whose .b is
-    // c, `s` its row sums); `emit` set = producer of the partials of its output rows
-    struct LnFold { const float* part = nullptr; int npart = 0; const float* s = nullptr; float* emit = nullptr; };
+    // LayerNorm fold of a launch (gemm16.hip, "LNF"): `part` set = consumer (A / X is xb, the un-normalised trunk as bf16; W the folded
+    // copy, `s` its (row sum, c) pairs); `emit` set = producer: leaves xb in `copy` and the partials of its output rows in `emit`
+    struct LnFold { const float* part = nullptr; int npair = 0; int ld = 0; const float* s = nullptr; float* emit = nullptr; bf16_t* copy = nullptr; };
     void ln_apply(GemmArgs& g, const LnFold* ln, int C) const {
         if (!ln) return;
-        g.ln_part = ln->part; g.ln_npart = ln->npart; g.ln_s = ln->s; g.ln_emit = ln->emit;
+        g.ln_part = ln->part; g.ln_npair = ln->npair; g.ln_ld = ln->ld; g.ln_s = ln->s; g.ln_emit = ln->emit; g.ln_copy = ln->copy;
         g.ln_inv_c = 1.f / (float)C; g.ln_eps = 1e-5f;
     }
     GemmArgs dense_args(const bf16_t* A, int lda, const MatW& W, int M, void* out, int ldo, int epi, const void* res = nullptr,
@@ -575,25 +574,30 @@ struct rt_engine {
             // the folded instantiation - a pure function of the layer's shape (width, tokens per stream), never of the batch.  The trunk's
             // producers (proj_in, to_out, ff.net.2: fp16-trunk epilogues) then leave the per-row partial sums next to it; a producer
             // without that form is followed by the stand-alone partials kernel.  Debug bit 22 restores the LayerNorm launches.
-            const int npart = C / 80;
-            float* part = ws.f32((size_t)M * 16 * 2);
+            float* part = ws.f32((size_t)M * 16);                    // up to 4 tile pairs x float4 per token
+            bf16_t* xb = ws.b16((size_t)M * C);                      // the trunk as bf16, written next to it by its producer
             bool fold1 = false, fold2 = false, fold3 = false, emit_pin = false, emit_out = false, emit_ff2 = false;
+            int ln_bn = 160;                                         // column-tile width of the partials (a function of the class of the producers: of (C, tokens per stream))
             if (gemm_lnfold_enabled() && ln_fold_width(C) && !t.blocks.empty() && t.blocks[0].qk1f.w) {
                 const TBlockP& k0 = t.blocks[0];
-                GemmArgs cq = dense_args(nullptr, C, k0.qk1f, M, nullptr, 2 * HD, EPI_BF16); cq.ln_npart = npart;
-                GemmArgs cv = vt_args(k0.v1f, nullptr, C, M, nullptr, M); cv.ln_npart = npart;
-                GemmArgs c2 = dense_args(nullptr, C, k0.q2f, M, nullptr, HD, EPI_BF16); c2.ln_npart = npart;
-                GemmArgs c3 = dense_args(nullptr, C, k0.ff1f, M, nullptr, 4 * C, EPI_GEGLU); c3.ln_npart = npart;
+                const int bn_pin = gemm_ln_emit_bn(dense_args(nullptr, C, t.pin, M, nullptr, C, EPI_F16));
+                const int bn_out = gemm_ln_emit_bn(dense_args(nullptr, HD, k0.out1, M, nullptr, C, EPI_F16));
+                const int bn_ff2 = gemm_ln_emit_bn(dense_args(nullptr, 4 * C, k0.ff2, M, nullptr, C, EPI_F16));
+                ln_bn = bn_out ? bn_out : (bn_ff2 ? bn_ff2 : (bn_pin ? bn_pin : 160));
+                emit_pin = bn_pin == ln_bn; emit_out = bn_out == ln_bn; emit_ff2 = bn_ff2 == ln_bn;     // (one class for all three: same N, same tokens per stream)
+                const int np = C / ln_bn / 2;
+                GemmArgs cq = dense_args(nullptr, C, k0.qk1f, M, nullptr, 2 * HD, EPI_BF16); cq.ln_npair = np;
+                GemmArgs cv = vt_args(k0.v1f, nullptr, C, M, nullptr, M); cv.ln_npair = np;
+                GemmArgs c2 = dense_args(nullptr, C, k0.q2f, M, nullptr, HD, EPI_BF16); c2.ln_npair = np;
+                GemmArgs c3 = dense_args(nullptr, C, k0.ff1f, M, nullptr, 4 * C, EPI_GEGLU); c3.ln_npair = np;
                 fold1 = gemm_ln_fold_ok(cq) && gemm_ln_fold_ok(cv);
                 fold2 = gemm_ln_fold_ok(c2);
                 fold3 = gemm_ln_fold_ok(c3);
-                emit_pin = gemm_ln_emit_ok(dense_args(nullptr, C, t.pin, M, nullptr, C, EPI_F16));
-                emit_out = gemm_ln_emit_ok(dense_args(nullptr, HD, k0.out1, M, nullptr, C, EPI_F16));
-                emit_ff2 = gemm_ln_emit_ok(dense_args(nullptr, 4 * C, k0.ff2, M, nullptr, C, EPI_F16));
             }
+            const int npair = C / ln_bn / 2;
             // partials of the trunk as it stands, for the LayerNorm that follows: from the producer's epilogue (`em` was passed to it) or here
-            auto partials_after = [&](bool emitted) { if (!emitted && !dry()) launch_ln_partials(hcur, part, M, C, stream); };
-            LnFold em; em.emit = part;
+            auto partials_after = [&](bool emitted) { if (!emitted && !dry()) launch_ln_partials(hcur, xb, part, M, C, ln_bn, stream); };
+            LnFold em; em.emit = part; em.copy = xb;
             {
                 Scope s2(ws);
                 bf16_t* g = ws.b16((size_t)M * C);
@@ -617,9 +621,9 @@ struct rt_engine {
                 int nqk = 0;
                 for (int b = 0; b < B; ++b) nqk = std::max(nqk, in.qk_src[b] + 1);
                 if (fold1) {
-                    LnFold lq; lq.part = part; lq.npart = npart; lq.s = k.qk1s;
-                    LnFold lv; lv.part = part; lv.npart = npart; lv.s = k.v1s;
-                    gemm_qk_vt((const bf16_t*)hcur, C, k.qk1f, nqk * HW, qk, 2 * HD, k.v1f, M, vt, M, &lq, &lv);
+                    LnFold lq; lq.part = part; lq.npair = npair; lq.ld = M; lq.s = k.qk1s;
+                    LnFold lv; lv.part = part; lv.npair = npair; lv.ld = M; lv.s = k.v1s;
+                    gemm_qk_vt(xb, C, k.qk1f, nqk * HW, qk, 2 * HD, k.v1f, M, vt, M, &lq, &lv);
                 } else gemm_qk_vt(n, C, k.qk1, nqk * HW, qk, 2 * HD, k.v1, M, vt, M);
                 if (!dry()) {
                     AttnArgs a{}; a.Q = qk; a.ldq = 2 * HD; a.K = qk + HD; a.ldk = 2 * HD; a.VT = vt; a.ldvt = M; a.O = o; a.ldo = HD;
@@ -685,8 +689,8 @@ struct rt_engine {
                     }
                 } else {
                 if (fold2) {
-                    LnFold l2; l2.part = part; l2.npart = npart; l2.s = k.q2s;
-                    gemm((const bf16_t*)hcur, C, k.q2f, M, qk, HD, EPI_BF16, nullptr, 0, nullptr, 0, &l2);
+                    LnFold l2; l2.part = part; l2.npair = npair; l2.ld = M; l2.s = k.q2s;
+                    gemm(xb, C, k.q2f, M, qk, HD, EPI_BF16, nullptr, 0, nullptr, 0, &l2);
                 } else gemm(n, C, k.q2, M, qk, HD, EPI_BF16);
                 if (!dry()) {
                     AttnArgs a{}; a.Q = qk; a.ldq = HD; a.K = k.kcache; a.ldk = HD; a.VT = k.vtcache; a.ldvt = cfg.max_prompts * 96;
@@ -721,8 +725,8 @@ struct rt_engine {
                 // --- GEGLU feed-forward (attention.py:209-304)
                 bf16_t* gg = ws.b16((size_t)M * 4 * C);
                 if (fold3) {
-                    LnFold l3; l3.part = part; l3.npart = npart; l3.s = k.ff1s;
-                    gemm((const bf16_t*)hcur, C, k.ff1f, M, gg, 4 * C, EPI_GEGLU, nullptr, 0, nullptr, 0, &l3);
+                    LnFold l3; l3.part = part; l3.npair = npair; l3.ld = M; l3.s = k.ff1s;
+                    gemm(xb, C, k.ff1f, M, gg, 4 * C, EPI_GEGLU, nullptr, 0, nullptr, 0, &l3);
                 } else {
                     layernorm(hcur, k.ln3, n, M);
                     gemm(n, C, k.ff1, M, gg, 4 * C, EPI_GEGLU);
@@ -1321,48 +1325,54 @@ int rt_op_gemm(const void* A, const void* W, const float* bias, void* out, const
         launch_gemm(g, (hipStream_t)stream);
     })
 }
-int rt_op_ln_partials(const void* x_f16, float* partials, int rows, int C, void* stream) {
-    OP_TRY({ launch_ln_partials((const f16_t*)x_f16, partials, rows, C, (hipStream_t)stream); })
+int rt_op_ln_partials(const void* x_f16, void* xb_bf16, float* partials, int rows, int C, int tile_cols, void* stream) {
+    OP_TRY({ launch_ln_partials((const f16_t*)x_f16, (bf16_t*)xb_bf16, partials, rows, C, tile_cols, (hipStream_t)stream); })
 }
 int rt_op_gemm_emit_partials(const void* A, const void* W, const float* bias, void* out_f16, const void* res_f16, int M, int N, int K,
-                             int rows_per_stream, float* partials, void* stream) {
+                             int rows_per_stream, void* xb_bf16, float* partials, int* tile_cols, void* stream) {
     OP_TRY({
         GemmArgs g{}; g.A = (const bf16_t*)A; g.W = (const bf16_t*)W; g.bias = bias; g.out = out_f16; g.res = res_f16; g.zero = op_zero_page();
         g.mode = A_DENSE; g.epi = EPI_F16; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldo = N; g.ldres = N;
         g.rows_per_stream = rows_per_stream; if (rows_per_stream > 0) g.split_tiles = cdiv(rows_per_stream, 128) * cdiv(N, 128);
-        if (!gemm_ln_emit_ok(g)) throw rt_error(RT_E_UNSUPPORTED, "rt_op_gemm_emit_partials: this shape's route has no partial-emitting epilogue");
-        g.ln_emit = partials;
+        const int bn = gemm_ln_emit_bn(g);
+        if (!bn) throw rt_error(RT_E_UNSUPPORTED, "rt_op_gemm_emit_partials: this shape's route has no partial-emitting epilogue");
+        if (tile_cols) *tile_cols = bn;
+        g.ln_emit = partials; g.ln_copy = (bf16_t*)xb_bf16;
         launch_gemm(g, (hipStream_t)stream);
     })
 }
 int rt_op_ln_gemm(const void* x_f16, const float* gamma, const float* beta, const void* W_bf16, const float* bias, void* out, int tokens,
-                  int N, int C, int epi, int weights_on_rows, int rows_per_stream, const float* partials, void* stream) {
+                  int N, int C, int epi, int weights_on_rows, int rows_per_stream, const void* xb_bf16, const float* partials, int tile_cols, void* stream) {
     OP_TRY({
         RT_REQUIRE((C == 640 || C == 1280) && tokens > 0 && N > 0 && (epi == EPI_BF16 || epi == EPI_GEGLU) && !(weights_on_rows && epi != EPI_BF16), "rt_op_ln_gemm: shape");
+        RT_REQUIRE((xb_bf16 != nullptr) == (partials != nullptr) && (xb_bf16 || x_f16), "rt_op_ln_gemm: a producer's (xb, partials) pair, or the fp16 trunk");
+        RT_REQUIRE((tile_cols == 160 || tile_cols == 320) && C % (2 * tile_cols) == 0, "rt_op_ln_gemm: column tiles of 160 / 320, an even number per row");
         hipStream_t st = (hipStream_t)stream;
         GemmArgs g{}; g.zero = op_zero_page(); g.mode = A_DENSE; g.epi = epi; g.K = C; g.out = out;
         if (weights_on_rows) { g.M = N; g.N = tokens; g.lda = C; g.ldw = C; g.ldo = tokens; g.weights_on_rows = 1; }
         else { g.M = tokens; g.N = N; g.lda = C; g.ldw = C; g.ldo = epi == EPI_GEGLU ? N / 2 : N; }
         g.rows_per_stream = rows_per_stream;
         if (rows_per_stream > 0) g.split_tiles = weights_on_rows ? cdiv(N, 128) * cdiv(rows_per_stream, 128) : cdiv(rows_per_stream, 128) * cdiv(N, 128);
-        g.ln_npart = C / 80; g.ln_inv_c = 1.f / (float)C; g.ln_eps = 1e-5f;
+        g.ln_npair = C / tile_cols / 2; g.ln_ld = tokens; g.ln_inv_c = 1.f / (float)C; g.ln_eps = 1e-5f;
         if (!gemm_ln_fold_ok(g)) throw rt_error(RT_E_UNSUPPORTED, "rt_op_ln_gemm: this shape's route has no folded instantiation");
-        // scratch of the op (the engine keeps these in its own arenas): W', s, c, partials
-        f16_t* Wf = nullptr; float* sc = nullptr; float* part = nullptr;
+        // scratch of the op (the engine keeps these in its own arenas): W', (s, c), xb, partials
+        bf16_t* Wf = nullptr; float* sc = nullptr; float* part = nullptr; bf16_t* xb = nullptr;
         HIP_CHECK(hipMalloc((void**)&Wf, (size_t)N * C * 2));
         HIP_CHECK(hipMalloc((void**)&sc, (size_t)N * 8));
         try {
-            launch_ln_fold_derive((const bf16_t*)W_bf16, C, bias, gamma, beta, N, C, Wf, sc, sc + N, st);
+            launch_ln_fold_derive((const bf16_t*)W_bf16, C, bias, gamma, beta, N, C, Wf, sc, st);
             if (!partials) {
-                HIP_CHECK(hipMalloc((void**)&part, (size_t)tokens * (C / 80) * 8));
-                launch_ln_partials((const f16_t*)x_f16, part, tokens, C, st);
+                HIP_CHECK(hipMalloc((void**)&part, (size_t)tokens * 16 * 4));
+                HIP_CHECK(hipMalloc((void**)&xb, (size_t)tokens * C * 2));
+                launch_ln_partials((const f16_t*)x_f16, xb, part, tokens, C, tile_cols, st);
             }
-            g.ln_part = partials ? partials : part; g.ln_s = sc; g.bias = sc + N;
-            if (weights_on_rows) { g.A = (const bf16_t*)Wf; g.W = (const bf16_t*)x_f16; } else { g.A = (const bf16_t*)x_f16; g.W = (const bf16_t*)Wf; }
+            const bf16_t* xop = partials ? (const bf16_t*)xb_bf16 : xb;
+            g.ln_part = partials ? partials : part; g.ln_s = sc; g.bias = nullptr;
+            if (weights_on_rows) { g.A = Wf; g.W = xop; } else { g.A = xop; g.W = Wf; }
             launch_gemm(g, st);
             HIP_CHECK(hipStreamSynchronize(st));
-        } catch (...) { (void)hipFree(Wf); (void)hipFree(sc); (void)hipFree(part); throw; }
-        (void)hipFree(Wf); (void)hipFree(sc); (void)hipFree(part);
+        } catch (...) { (void)hipFree(Wf); (void)hipFree(sc); (void)hipFree(part); (void)hipFree(xb); throw; }
+        (void)hipFree(Wf); (void)hipFree(sc); (void)hipFree(part); (void)hipFree(xb);
     })
 }
 int rt_op_attention(const void* Q, int ldq, const void* K, int ldk, const void* VT, int ldvt, void* O, int ldo, const int* q_src,

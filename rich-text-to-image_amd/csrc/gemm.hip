@@ -1496,19 +1496,19 @@ int gemm_route16(const GemmArgs& a) {
     int wstat = 0;
     return gemm16_pick(a, a.weights_on_rows, &wstat);
 }
-bool gemm_ln_emit_ok(const GemmArgs& a_in) {
+int gemm_ln_emit_bn(const GemmArgs& a_in) {
     GemmArgs a = a_in; a.ln_part = nullptr; a.ln_emit = (float*)(uintptr_t)256;          // (any non-null value: host-side shape test only)
-    return a.epi == EPI_F16 && gemm16_ln_variant_ok(a, gemm_route16(a));
+    const int v = gemm_route16(a);
+    return a.epi == EPI_F16 && gemm16_ln_variant_ok(a, v) ? gemm16_variant_bn(v) : 0;
 }
 bool gemm_ln_fold_ok(const GemmArgs& a_in) {
     GemmArgs a = a_in; a.ln_emit = nullptr; a.ln_part = (const float*)(uintptr_t)256;
-    if (a.ln_npart != 8 && a.ln_npart != 16) return false;
     return gemm16_ln_variant_ok(a, gemm_route16(a));
 }
 
 void launch_gemm(const GemmArgs& a, hipStream_t st) {
     check_gemm_args(a);
-    if (a.ln_part || a.ln_emit) RT_REQUIRE(gemm16_ln_variant_ok(a, gemm_route16(a)), "gemm: LayerNorm fold asked of a route without it (gemm_ln_fold_ok / gemm_ln_emit_ok)");
+    if (a.ln_part || a.ln_emit) RT_REQUIRE(gemm16_ln_variant_ok(a, gemm_route16(a)), "gemm: LayerNorm fold asked of a route without it (gemm_ln_fold_ok / gemm_ln_emit_bn)");
     if (a.pair_lo) RT_REQUIRE(gemm_pair_output_ok(a) && a.ldo % 4 == 0 && ((uintptr_t)a.pair_lo & 7) == 0, "gemm: pair output is only built into the patch convolution (gemm_pair_output_ok)");
     // In-place residual (out == res) is safe: every element is read and written by the same thread.
     // split-K is a function of the shape only (not of a forced tile configuration, not of stream capture): the same problem

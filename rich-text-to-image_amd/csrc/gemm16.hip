@@ -46,24 +46,27 @@ __device__ long long g_g16_times[8192 * 8];
 
 // ---------------------------------------------------------------------------------------------- LNF: LayerNorm folded into the projections (round 6)
 // BasicTransformerBlock normalises the fp16 trunk three times per block (models/attention.py:150,168,181: norm1 -> attn1, norm2 -> attn2,
-// norm3 -> ff) and every LayerNorm was its own launch (210 per SDXL forward: 37 MB in, 37 MB out, 9.3 us + a kernel boundary each).
+// norm3 -> ff) and every LayerNorm was its own launch (210 per SDXL forward: 18 MB in, 18 MB out, 9.3 us + a kernel boundary each).
 //     LN(x) W^T + b = rstd_m (x (W diag(gamma))^T - mu_m s_n) + c_n,     s_n = sum_k gamma_k W_nk,   c_n = b_n + sum_k beta_k W_nk
-// so the consumer GEMM can read the RAW trunk: the trunk is fp16 in HBM and v_mfma_f32_16x16x32_f16 takes it as it is - the A operand
-// is exact (the LayerNorm launch rounded LN(x) to bf16: 2^-9 relative) - against W' = fp16(gamma W) derived once per checkpoint
-// (ln_fold_derive_kernel, norm.hip); the per-token (mu, rstd) come from per-row partial sums (sum x, sum x^2 over 80-column blocks)
-// that the PRODUCER of the trunk - the fp16-trunk epilogue of to_out / ff.net.2 / proj_in - leaves next to its output.
+// so the consumer GEMM can read the UN-normalised trunk against W' = bf16(gamma W) (derived once per checkpoint: ln_fold_derive_kernel,
+// norm.hip) and correct in its epilogue.  The PRODUCER of the trunk - the fp16-trunk epilogue of to_out / ff.net.2 / proj_in - leaves,
+// next to the fp16 trunk, xb = bf16(trunk value) (rounded from the same fp32 number: the MFMA operand) and per-row partial sums
+// (sum xb, sum xb^2 over 80-column blocks), from which every consumer workgroup tabulates (mu, rstd) of its tokens.
 //   LNF = 0  plain kernel (the measured binaries of rounds 3 - 5, unchanged)
-//   LNF = 1  consumer, tokens on the rows: f16 MFMA; every workgroup turns the partials of its 224 (...) token rows into an LDS table
-//            (mu, rstd) while its first K tiles are in flight; the epilogue applies rstd (acc - mu s_col) + c_col (GEGLU: in front of the gelu)
+//   LNF = 1  consumer, tokens on the rows: A = xb; the workgroup turns the partials of its 224 (...) token rows into an LDS table (mu, rstd)
+//            while its first K tiles are in flight; the epilogue applies rstd (acc - mu s_col) + c_col (GEGLU: in front of the gelu)
 //   LNF = 3  consumer, tokens on the COLUMNS (V^T = Wv X^T): the same with per-column statistics and per-row s, c
-//   LNF = 2  producer (EPI_F16 only): after rounding a 16 x 80 piece of the trunk to fp16 the wave reduces sum / sum of squares of the
-//            ROUNDED values per row in a fixed order (LDS scratch + quad DPP: deterministic) and stores [row][block] float2
-// var = E[x^2] - mu^2 in fp32 from 8 / 16 hierarchical partials: relative error of rstd ~ 1e-7 (1 + mu^2 / sigma^2).
-typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
-template <bool H16>
+//   LNF = 2  producer (EPI_F16 only): besides the fp16 trunk it stores xb and reduces sum / sum of squares of xb per row and 80-column
+//            block in a fixed order (v_dot2c_f32_bf16 per pair, LDS scratch + quad DPP across the items: deterministic)
+// Arithmetic: LN of the bf16-ROUNDED trunk, exactly (mu, rstd are the statistics of the numbers the MFMA multiplies); against the
+// LayerNorm launch (fp32 LN of the fp16 trunk, output rounded to bf16) the operand error moves from LN(x) to x: a row's error grows by
+// sqrt(1 + mu^2 / sigma^2) (measured: tests/test_lnfold_gpu.py).  var = E[x^2] - mu^2 in fp32 from 8 / 16 hierarchical partials.
+// (First built with the fp16 trunk itself as the operand of v_mfma_f32_16x16x32_f16 - exact operand, no copy: parity better than the
+//  LayerNorm launch, but the f16 MFMA runs the K loops 14 % slower on this chip (GEGLU 149 -> 171 us, same instruction stream:
+//  profiles/r6_lnfold_fp16_kernel_stats.txt), which cost more than the LayerNorm launches saved.)
+template <bool UNUSED>
 static __device__ __forceinline__ f32x4_t g16_mma(const bf16x8& b, const bf16x8& a, const f32x4_t& c) {
-    if constexpr (H16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, b), __builtin_bit_cast(f16x8_t, a), c, 0, 0, 0);
-    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, c, 0, 0, 0);
 }
 #define RT_LNF_NONE 0
 #define RT_LNF_ROWS 1
@@ -367,7 +370,7 @@ static bool ln_variant_ok(int epi, int v, int lnf) {
 static void launch_ln(const GemmArgs& a, int v, int wstat, int lnf, hipStream_t st) {
     RT_REQUIRE(a.mode == A_DENSE && ln_variant_ok(a.epi, v, lnf), "gemm16: no LayerNorm-fold instantiation of this variant / epilogue");
     if (lnf == RT_LNF_EMIT) {
-        RT_REQUIRE(a.N % RT_LN_BLOCK == 0 && a.ldo == a.N, "gemm16: partials are emitted per 80-column block of a dense output");
+        RT_REQUIRE(a.N % RT_LN_BLOCK == 0 && a.ldo == a.N && a.ln_copy && ((uintptr_t)a.ln_copy & 15) == 0, "gemm16: partials are emitted per 80-column block of a dense output, next to its bf16 copy");
         switch (v) {
             case 0: launch_v<A_DENSE, EPI_F16, 7, 5, 2, 2, 2, 3, RT_LNF_EMIT>(a, wstat, st); return;
             case 1: launch_v<A_DENSE, EPI_F16, 4, 5, 2, 2, 2, 3, RT_LNF_EMIT>(a, wstat, st); return;
@@ -378,7 +381,8 @@ static void launch_ln(const GemmArgs& a, int v, int wstat, int lnf, hipStream_t 
             default: launch_v<A_DENSE, EPI_F16, 2, 5, 2, 4, 1, 3, RT_LNF_EMIT>(a, wstat, st); return;
         }
     }
-    RT_REQUIRE(a.ln_part && a.ln_s && (a.ln_npart == 8 || a.ln_npart == 16) && a.ln_inv_c > 0.f, "gemm16: LayerNorm-fold consumer arguments (8 or 16 partials per token)");
+    RT_REQUIRE(a.ln_part && a.ln_s && (a.ln_npair == 1 || a.ln_npair == 2 || a.ln_npair == 4) && a.ln_inv_c > 0.f && a.ln_ld >= (a.weights_on_rows ? a.N : a.M) &&
+               ((uintptr_t)a.ln_part & 15) == 0 && ((uintptr_t)a.ln_s & 7) == 0, "gemm16: LayerNorm-fold consumer arguments (1, 2 or 4 tile pairs per token, pair-major with ln_ld >= tokens)");
     if (lnf == RT_LNF_COLS) {
         switch (v) {
             case 6: launch_v<A_DENSE, EPI_BF16, 5, 7, 2, 2, 2, 3, RT_LNF_COLS>(a, wstat, st); return;
@@ -406,10 +410,11 @@ static void launch_ln(const GemmArgs& a, int v, int wstat, int lnf, hipStream_t 
         default: launch_v<A_DENSE, EPI_BF16, 2, 5, 2, 4, 1, 3, RT_LNF_ROWS>(a, wstat, st); return;
     }
 }
+int gemm16_variant_bn(int v) { return v >= 0 && v < RT_G16_NVAR ? kVar[v].BN : 0; }
 bool gemm16_ln_variant_ok(const GemmArgs& a, int v) {
     if (a.mode != A_DENSE || v < 0) return false;
-    if (a.ln_part) return (a.ln_npart == 8 || a.ln_npart == 16) && ln_variant_ok(a.epi, v, a.weights_on_rows ? RT_LNF_COLS : RT_LNF_ROWS);
-    if (a.ln_emit) return a.N % (8 * RT_LN_BLOCK) == 0 && a.N / RT_LN_BLOCK <= 16 && a.ldo == a.N && ln_variant_ok(a.epi, v, RT_LNF_EMIT);
+    if (a.ln_part) return (a.ln_npair == 1 || a.ln_npair == 2 || a.ln_npair == 4) && ln_variant_ok(a.epi, v, a.weights_on_rows ? RT_LNF_COLS : RT_LNF_ROWS);
+    if (a.ln_emit) return a.N % (2 * kVar[v].BN) == 0 && a.N / kVar[v].BN <= 8 && a.ldo == a.N && ln_variant_ok(a.epi, v, RT_LNF_EMIT);
     return true;
 }
 
@@ -545,8 +550,8 @@ bool launch_gemm16_pair(const GemmArgs& a_in, const GemmArgs& b_in, hipStream_t 
     const int va = gemm16_pair_variant(a_in, b_in);
     if (va < 0) return false;
     if (a_in.ln_part) {
-        RT_REQUIRE(a_in.ln_s && b_in.ln_s && (a_in.ln_npart == 8 || a_in.ln_npart == 16) && b_in.ln_npart == a_in.ln_npart && a_in.ln_inv_c > 0.f,
-                   "gemm16 pair: LayerNorm-fold consumer arguments");
+        RT_REQUIRE(a_in.ln_s && b_in.ln_s && (a_in.ln_npair == 1 || a_in.ln_npair == 2 || a_in.ln_npair == 4) && b_in.ln_npair == a_in.ln_npair && a_in.ln_inv_c > 0.f &&
+                   a_in.ln_ld >= a_in.M && b_in.ln_ld >= b_in.N, "gemm16 pair: LayerNorm-fold consumer arguments");
         switch (va) {
             case 0: launch_dual_v<7, 5, 2, 5, 7, true>(a_in, b_in, st); break;
             case 1: launch_dual_v<7, 4, 2, 5, 7, true>(a_in, b_in, st); break;
@@ -620,6 +625,7 @@ int gemm16_pick(const GemmArgs& a, int weights_on_rows, int* wstat) {
         int best = -1; double bc = 1e300;
         for (auto& c : cand) {
             if (a.N % c[1] != 0) continue;
+            if (a.ln_emit && c[1] != 320) continue;                  // a producer of LayerNorm partials stays on the 80-column wave tiles (same class, same bits)
             const double cc = cost(c[0], c[1], c[0] == 128 ? 1.2 : 1.0);
             if (cc < bc) { bc = cc; best = c[2]; }
         }

@@ -52,31 +52,28 @@
     const int xa_prompt = EPI == EPI_XATTN ? p.xa_prompt[xa_b] : 0, xa_wset = EPI == EPI_XATTN ? p.xa_wset[xa_b] : -1;
     const int xa_head0 = n0 >> 6;
     // LNF consumers: thread t requests the partial sums of token row (column) t of the tile NOW, ahead of the prologue's LDS-DMA pieces
-    // (VMEM loads retire in order: the first counted wait of the prologue covers them); they become the (mu, rstd) table behind the
-    // first barrier.  ln_npart = C / 80 float2 partials per token, 8 or 16 (host-checked): four or eight 16-B loads.
-    float4 lnp[LNC ? 8 : 1];
+    // (VMEM loads retire in order: the first counted wait of the prologue covers them); they become the (-mu rstd, rstd) table behind
+    // the first barrier.  The producer leaves ONE (sum, sum of squares) per token and column TILE of its grid, two tiles per float4,
+    // pair-major [pair][token]: 1, 2 or 4 coalesced 16-B loads per thread (a token-major 16 x float2 layout held the prologue's pieces
+    // back by 2.1 k cycles per tile: every load instruction touched 64 lines; profiles/r6_lnfold_probe_v1.txt).
+    // ... and (s, c) of weight row t (V^T form: of the tile's weight rows; else: of its columns): staged in the same table, so that the
+    // epilogue needs no registers for them before the K-split exchange has freed half of the accumulators
+    float4 lnp[LNC ? 4 : 1];
+    constexpr int LN_NW = LNF == RT_LNF_COLS ? BM : BN;    // weight rows of the tile
+    float2 ln_scw = {0.f, 0.f};
     if constexpr (LNC) {
         int trow = (LNF == RT_LNF_COLS ? n0 : m0) + tid;
         const int lim = LNF == RT_LNF_COLS ? p.N : p.M;
         if (trow >= lim) trow = lim - 1;
-        const float4* pp = (const float4*)(p.ln_part + (size_t)trow * p.ln_npart * 2);
+        const float4* pp = (const float4*)p.ln_part + trow;
+        lnp[0] = pp[0];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) lnp[j] = pp[j];
-#pragma unroll
-        for (int j = 4; j < 8; ++j) lnp[j] = p.ln_npart > 8 ? pp[j] : float4{0.f, 0.f, 0.f, 0.f};
-    }
-    // ... and s / c of weight row (V^T form: of the tile's weight rows; else: of its columns) t: staged in the same table, so that the
-    // epilogue needs no registers for them before the K-split exchange has freed half of the accumulators
-    constexpr int LN_NW = LNF == RT_LNF_COLS ? BM : BN;    // weight rows of the tile
-    float ln_sw = 0.f, ln_cw = 0.f;
-    if constexpr (LNC) {
+        for (int j = 1; j < 4; ++j) lnp[j] = j < p.ln_npair ? pp[(size_t)j * p.ln_ld] : float4{0.f, 0.f, 0.f, 0.f};
         int wrow = (LNF == RT_LNF_COLS ? m0 : n0) + tid;
-        const int lim = LNF == RT_LNF_COLS ? p.M : p.N;
-        if (wrow >= lim) wrow = lim - 1;
-        ln_sw = p.ln_s[wrow];
-        ln_cw = p.bias ? p.bias[wrow] : 0.f;
+        const int wlim = LNF == RT_LNF_COLS ? p.M : p.N;
+        if (wrow >= wlim) wrow = wlim - 1;
+        ln_scw = ((const float2*)p.ln_s)[wrow];                          // (s, c) interleaved
     }
-
     // ---- loader: piece i of this wave copies 8-row group g = i*NW + wave of the (A rows | W rows) list.  Buffer-descriptor LDS-DMA
     // (buffer_load_dwordx4 ... offen lds, guide T8): per piece ONE 32-bit VGPR byte offset, the K-tile offset is a scalar (soffset)
     // and the operand base sits in an SGPR descriptor - the flat form kept a 64-bit address per piece alive and spilled in the loop.
@@ -194,17 +191,17 @@
         // i.e. wait for every ring slot in flight (LABNOTES R4.1).
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { s1 += lnp[j].x; s2 += lnp[j].y; s1 += lnp[j].z; s2 += lnp[j].w; }
+        for (int j = 0; j < 4; ++j) { s1 += lnp[j].x; s2 += lnp[j].y; s1 += lnp[j].z; s2 += lnp[j].w; }
         const float mu = s1 * p.ln_inv_c;
         const float var = fmaxf(s2 * p.ln_inv_c - mu * mu, 0.f);
         const float rs = rsqrtf(var + p.ln_eps);
         const unsigned tbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(smem + S * STAGE);
         if (tid < LN_NST) {
-            const unsigned long long w64 = ((unsigned long long)__float_as_uint(rs) << 32) | __float_as_uint(mu);
+            const unsigned long long w64 = ((unsigned long long)__float_as_uint(rs) << 32) | __float_as_uint(-mu * rs);     // (-mu rstd, rstd)
             asm volatile("ds_write_b64 %0, %1" ::"v"(tbase + (unsigned)tid * 8u), "v"(w64) : "memory");
         }
         if (tid < LN_NW) {
-            asm volatile("ds_write_b32 %0, %1 offset:2560\n\tds_write_b32 %0, %2 offset:3840" ::"v"(tbase + (unsigned)tid * 4u), "v"(ln_sw), "v"(ln_cw) : "memory");
+            asm volatile("ds_write_b32 %0, %1 offset:2560\n\tds_write_b32 %0, %2 offset:3840" ::"v"(tbase + (unsigned)tid * 4u), "v"(ln_scw.x), "v"(ln_scw.y) : "memory");
         }
     }
     bf16x8 fa[TMW], fb[2][TNW];
@@ -449,7 +446,9 @@
     char* slab = smem + (size_t)wave * 16 * RS;
     static_assert(LNF != RT_LNF_EMIT || (IPR == 10 && NW * 16 * RS + NW * 16 * IPR * 8 <= S * STAGE), "partials scratch behind the slabs");
     const unsigned ln_scr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(smem + NW * 16 * RS + wave * (16 * IPR * 8));
-    (void)ln_scr;
+    static_assert(LNF != RT_LNF_EMIT || (NW * 16 * RS + NW * 16 * IPR * 8 + BM * WN * 8 <= S * STAGE), "partials table of the workgroup behind the scratch");
+    const unsigned ln_wgt = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(smem + NW * 16 * RS + NW * (16 * IPR * 8));
+    (void)ln_scr; (void)ln_wgt;
     if constexpr (!BIAS_EARLY) load_bias();
 #ifdef RT_G16_TIMING
     { float bsum = 0.f; for (int t = 0; t < TNO; ++t) bsum += bias_v[t][0]; asm volatile("" ::"v"(bsum)); G16_T(5) }
@@ -458,16 +457,16 @@
     for (int i = 0; i < TMW; ++i) {
         if (!owned(i)) continue;
         // LNF consumers: (mu, rstd) of the lane's token row / s, c of its weight row, from the table
-        float ln_mu = 0.f, ln_rs = 1.f, ln_sr = 0.f, ln_cr = 0.f;
+        float ln_nm = 0.f, ln_rs = 1.f, ln_sr = 0.f, ln_cr = 0.f;
         if constexpr (LNF == RT_LNF_ROWS) {
             const float2 st = *(const float2*)(smem + S * STAGE + ((wm * TMW + i) * 16 + l15) * 8);
-            ln_mu = st.x; ln_rs = st.y;
+            ln_nm = st.x; ln_rs = st.y;                               // (the table holds -mu rstd)
         }
         if constexpr (LNF == RT_LNF_COLS) {
             ln_sr = *(const float*)(smem + S * STAGE + 2560 + ((wm * TMW + i) * 16 + l15) * 4);
             ln_cr = *(const float*)(smem + S * STAGE + 3840 + ((wm * TMW + i) * 16 + l15) * 4);
         }
-        (void)ln_mu; (void)ln_rs; (void)ln_sr; (void)ln_cr;
+        (void)ln_nm; (void)ln_rs; (void)ln_sr; (void)ln_cr;
         // registers -> slab
 #pragma unroll
         for (int t = 0; t < TNO; ++t) {
@@ -478,10 +477,13 @@
                 for (int e = 0; e < 4; e += 2) {                     // two gates per packed-fp32 issue slot
                     f32x2 gt, vl;
                     if constexpr (LNF == RT_LNF_ROWS) {              // LN(x) W^T + b = rstd (x W'^T - mu s) + c, in front of the gelu
-                        const float mu = ln_mu, rs = ln_rs;
+                        // rstd acc + (c - mu rstd s): two packed FMAs per pair of values
                         constexpr int tg = (LNF == RT_LNF_ROWS && EPI == EPI_GEGLU) ? 1 : 0;
-                        gt = f32x2{fmaf(rs, fmaf(-mu, lns_g[tg * t][e], acc[i][tv + 2][e]), bias_g[t][e]), fmaf(rs, fmaf(-mu, lns_g[tg * t][e + 1], acc[i][tv + 2][e + 1]), bias_g[t][e + 1])};
-                        vl = f32x2{fmaf(rs, fmaf(-mu, lns_v[t][e], acc[i][tv][e]), bias_v[t][e]), fmaf(rs, fmaf(-mu, lns_v[t][e + 1], acc[i][tv][e + 1]), bias_v[t][e + 1])};
+                        const f32x2 rs2 = {ln_rs, ln_rs}, nm2 = {ln_nm, ln_nm};
+                        gt = __builtin_elementwise_fma(rs2, f32x2{acc[i][tv + 2][e], acc[i][tv + 2][e + 1]},
+                                                       __builtin_elementwise_fma(nm2, f32x2{lns_g[tg * t][e], lns_g[tg * t][e + 1]}, f32x2{bias_g[t][e], bias_g[t][e + 1]}));
+                        vl = __builtin_elementwise_fma(rs2, f32x2{acc[i][tv][e], acc[i][tv][e + 1]},
+                                                       __builtin_elementwise_fma(nm2, f32x2{lns_v[t][e], lns_v[t][e + 1]}, f32x2{bias_v[t][e], bias_v[t][e + 1]}));
                     } else {
                         gt = f32x2{acc[i][tv + 2][e] + bias_g[t][e], acc[i][tv + 2][e + 1] + bias_g[t][e + 1]};
                         vl = f32x2{acc[i][tv][e] + bias_v[t][e], acc[i][tv][e + 1] + bias_v[t][e + 1]};
@@ -490,13 +492,19 @@
                     v[e] = o.x; v[e + 1] = o.y;
                 }
             } else if constexpr (LNF == RT_LNF_ROWS) {
+                const f32x2 rs2 = {ln_rs, ln_rs}, nm2 = {ln_nm, ln_nm};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaf(ln_rs, fmaf(-ln_mu, lns_v[LNF == RT_LNF_ROWS ? t : 0][e], acc[i][t][e]), bias_v[t][e]);
+                for (int e = 0; e < 4; e += 2) {
+                    constexpr int tr = LNF == RT_LNF_ROWS ? 1 : 0;
+                    const f32x2 o2 = __builtin_elementwise_fma(rs2, f32x2{acc[i][t][e], acc[i][t][e + 1]},
+                                                               __builtin_elementwise_fma(nm2, f32x2{lns_v[tr * t][e], lns_v[tr * t][e + 1]}, f32x2{bias_v[t][e], bias_v[t][e + 1]}));
+                    v[e] = o2.x; v[e + 1] = o2.y;
+                }
             } else if constexpr (LNF == RT_LNF_COLS) {
-                const float4 ca = *(const float4*)(smem + S * STAGE + (wn * TNW * 16 + t * 16 + 4 * q4) * 8);            // (mu, rstd) of columns 4 q4, 4 q4 + 1
+                const float4 ca = *(const float4*)(smem + S * STAGE + (wn * TNW * 16 + t * 16 + 4 * q4) * 8);            // (-mu rstd, rstd) of columns 4 q4, 4 q4 + 1
                 const float4 cb = *(const float4*)(smem + S * STAGE + (wn * TNW * 16 + t * 16 + 4 * q4) * 8 + 16);       // ... + 2, + 3
-                v[0] = fmaf(ca.y, fmaf(-ca.x, ln_sr, acc[i][t][0]), ln_cr); v[1] = fmaf(ca.w, fmaf(-ca.z, ln_sr, acc[i][t][1]), ln_cr);
-                v[2] = fmaf(cb.y, fmaf(-cb.x, ln_sr, acc[i][t][2]), ln_cr); v[3] = fmaf(cb.w, fmaf(-cb.z, ln_sr, acc[i][t][3]), ln_cr);
+                v[0] = fmaf(ca.y, acc[i][t][0], fmaf(ca.x, ln_sr, ln_cr)); v[1] = fmaf(ca.w, acc[i][t][1], fmaf(ca.z, ln_sr, ln_cr));
+                v[2] = fmaf(cb.y, acc[i][t][2], fmaf(cb.x, ln_sr, ln_cr)); v[3] = fmaf(cb.w, acc[i][t][3], fmaf(cb.z, ln_sr, ln_cr));
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][t][e] + bias_v[t][e];
@@ -544,12 +552,20 @@
                 for (int e = 0; e < 8; ++e) oh[e] = (f16_t)v[e];
                 *(uint4*)((f16_t*)p.out + (size_t)row * p.ldo + col) = o;
                 if constexpr (LNF == RT_LNF_EMIT) {
-                    // sum / sum of squares of the 8 ROUNDED trunk values of this item -> the wave's scratch [16 rows][10 items] behind the slabs.
-                    // Inline ds_write_b64 / ds_read_b64 below: compiler-visible LDS traffic behind a global store makes hipcc's waitcnt pass
-                    // wait for the store (vmcnt(0)); a wave's LDS operations execute in order, which is all that is needed here.
+                    // xb = bf16 of the same eight fp32 values -> the consumers' MFMA operand; sum / sum of squares of xb (one v_dot2c_f32_bf16
+                    // per pair and moment) -> the wave's scratch [16 rows][10 items] behind the slabs.  Inline asm for the LDS traffic:
+                    // compiler-visible LDS operations behind a global store make hipcc's waitcnt pass wait for the store (vmcnt(0)); a
+                    // wave's LDS operations execute in order, which is all that is needed here.
+                    g16_u4 cb;
+                    cb.x = pack_bf16x2(v[0], v[1]); cb.y = pack_bf16x2(v[2], v[3]); cb.z = pack_bf16x2(v[4], v[5]); cb.w = pack_bf16x2(v[6], v[7]);
+                    *(g16_u4*)(p.ln_copy + (size_t)row * p.ldo + col) = cb;
                     float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { const float x = (float)oh[e]; s1 += x; s2 = fmaf(x, x, s2); }
+                    asm volatile("v_dot2c_f32_bf16 %0, %2, %6\n\tv_dot2c_f32_bf16 %1, %2, %2\n\t"
+                                 "v_dot2c_f32_bf16 %0, %3, %6\n\tv_dot2c_f32_bf16 %1, %3, %3\n\t"
+                                 "v_dot2c_f32_bf16 %0, %4, %6\n\tv_dot2c_f32_bf16 %1, %4, %4\n\t"
+                                 "v_dot2c_f32_bf16 %0, %5, %6\n\tv_dot2c_f32_bf16 %1, %5, %5\n\t"
+                                 "s_nop 2"      /* a DOT result read by another VALU opcode needs 3 wait states, and hipcc's hazard recogniser does not look into asm */
+                                 : "+v"(s1), "+v"(s2) : "v"(cb.x), "v"(cb.y), "v"(cb.z), "v"(cb.w), "v"(0x3f803f80u));
                     const unsigned long long w64 = ((unsigned long long)__float_as_uint(s2) << 32) | __float_as_uint(s1);
                     asm volatile("ds_write_b64 %0, %1" ::"v"(ln_scr + (unsigned)idx * 8u), "v"(w64) : "memory");
                 }
@@ -568,8 +584,11 @@
                 a2 += __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(a2), 0xB1, 0xF, 0xF, true));
                 a1 += __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(a1), 0x4E, 0xF, 0xF, true));     // quad_perm [2, 3, 0, 1]
                 a2 += __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(a2), 0x4E, 0xF, 0xF, true));
-                if (jj == 0 && row0 + rr < p.M)
-                    *(float2*)(p.ln_emit + ((size_t)(row0 + rr) * (p.N / RT_LN_BLOCK) + ocol0 / RT_LN_BLOCK) * 2) = make_float2(a1, a2);
+                // -> the workgroup's table [BM rows][WN wave columns]; combined and stored once, behind the last tile
+                if (jj == 0) {
+                    const unsigned long long w64 = ((unsigned long long)__float_as_uint(a2) << 32) | __float_as_uint(a1);
+                    asm volatile("ds_write_b64 %0, %1" ::"v"(ln_wgt + (unsigned)((((wm * TMW + i) * 16 + rr) * WN + wn) * 8)), "v"(w64) : "memory");
+                }
             }
             // the window slot of this tile is free: request the residual of the owned tile RW positions further on
             const int s_own = i < H0 ? i : i - H0;                   // compile-time after unrolling
@@ -595,6 +614,19 @@
 #ifdef RT_G16_TIMING
         if (i == (WK == 2 && kh == 1 ? H0 : 0)) G16_T(6)
 #endif
+    }
+    if constexpr (LNF == RT_LNF_EMIT) {
+        // one (sum, sum of squares) per token row and column TILE: the WN wave columns added in order; two tiles share a float4 of the
+        // pair-major array [tile pair][row] the consumers read
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (tid < BM && m0 + tid < p.M) {
+            const float2* wt = (const float2*)(smem + NW * 16 * RS + NW * (16 * IPR * 8)) + tid * WN;
+            float a1 = wt[0].x, a2 = wt[0].y;
+#pragma unroll
+            for (int w = 1; w < WN; ++w) { a1 += wt[w].x; a2 += wt[w].y; }
+            *((float2*)p.ln_emit + ((size_t)(tn >> 1) * p.M + m0 + tid) * 2 + (tn & 1)) = make_float2(a1, a2);
+        }
     }
 #ifdef RT_G16_TIMING
     G16_T(7)

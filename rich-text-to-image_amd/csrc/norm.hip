@@ -427,20 +427,20 @@ void launch_layernorm(const void* x, int x_f16, const float* gamma, const float*
 }
 
 // ---------------------------------------------------------------------------------------------- LayerNorm fold (gemm16.hip, "LNF")
-// W' = fp16(gamma_k W_nk) from the packed bf16 weight, s_n = sum_k W'_nk (of the ROUNDED values: the correction must cancel what the
+// W' = bf16(gamma_k W_nk) from the packed bf16 weight, s_n = sum_k W'_nk (of the ROUNDED values: the correction must cancel what the
 // MFMA adds up), c_n = b_n + sum_k beta_k W_nk  (models/attention.py:150,168,181: norm1 -> attn1, norm2 -> attn2, norm3 -> ff).
 // One workgroup per weight row, fixed-order tree reduction: a pure function of the checkpoint (every rank derives the same bits).
 __global__ __launch_bounds__(256) void ln_fold_derive_kernel(const bf16_t* __restrict__ W, int ldw, const float* __restrict__ bias,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta, int K,
-                                                             f16_t* __restrict__ Wf, float* __restrict__ s_out, float* __restrict__ c_out) {
+                                                             bf16_t* __restrict__ Wf, float2* __restrict__ sc_out) {
     __shared__ float red[2][256];
     const int n = blockIdx.x, tid = threadIdx.x;
     float s = 0.f, c = 0.f;
     for (int k = tid; k < K; k += 256) {
         const float w = bf16_to_f32(W[(size_t)n * ldw + k]);
-        const f16_t wf = (f16_t)(gamma[k] * w);
+        const bf16_t wf = f32_to_bf16(gamma[k] * w);
         Wf[(size_t)n * ldw + k] = wf;
-        s += (float)wf;
+        s += bf16_to_f32(wf);
         c = fmaf(beta[k], w, c);
     }
     red[0][tid] = s; red[1][tid] = c;
@@ -449,43 +449,62 @@ __global__ __launch_bounds__(256) void ln_fold_derive_kernel(const bf16_t* __res
         if (tid < h) { red[0][tid] += red[0][tid + h]; red[1][tid] += red[1][tid + h]; }
         __syncthreads();
     }
-    if (tid == 0) { s_out[n] = red[0][0]; c_out[n] = red[1][0] + (bias ? bias[n] : 0.f); }
+    if (tid == 0) sc_out[n] = make_float2(red[0][0], red[1][0] + (bias ? bias[n] : 0.f));
 }
 void launch_ln_fold_derive(const bf16_t* W, int ldw, const float* bias, const float* gamma, const float* beta, int N, int K,
-                           f16_t* Wf, float* s, float* c, hipStream_t st) {
+                           bf16_t* Wf, float* sc, hipStream_t st) {
     RT_REQUIRE(N > 0 && K > 0 && ldw >= K, "ln_fold_derive: shape");
-    hipLaunchKernelGGL(ln_fold_derive_kernel, dim3(N), dim3(256), 0, st, W, ldw, bias, gamma, beta, K, Wf, s, c);
+    hipLaunchKernelGGL(ln_fold_derive_kernel, dim3(N), dim3(256), 0, st, W, ldw, bias, gamma, beta, K, Wf, (float2*)sc);
     HIP_CHECK(hipGetLastError());
 }
 
-// Stand-alone producer of the partials the fp16-trunk epilogues of gemm16.hip emit (LNF = 2): part[row][C / 80] = (sum, sum of squares)
-// of 80 consecutive trunk values, added in the SAME order as there (8-value items sequentially; items j, j + 4, j + 8 per quarter; the
-// quarters as (q0 + q1) + (q2 + q3)), so a trunk that some other kernel produced gives the consumer bit-identical statistics.
-__global__ __launch_bounds__(256) void ln_partials_kernel(const f16_t* __restrict__ x, float* __restrict__ part, int rows, int nblk) {
+// Stand-alone producer of what the fp16-trunk epilogues of gemm16.hip leave (LNF = 2) for a trunk some other kernel wrote: xb = bf16 of
+// the fp16 trunk values and one (sum, sum of squares) of xb per row and column tile of `bn` (160 / 320) columns, pair-major
+// [tile pair][row] float4 = two tiles, added in the same order as there (v_dot2c_f32_bf16 pair by pair inside an 8-value item; items
+// j, j + 4, j + 8 per quarter of an 80-column block; the quarters as (q0 + q1) + (q2 + q3); the blocks of a tile in ascending order).
+// (The epilogue rounds xb from the fp32 value it also rounds the trunk from; here only the fp16 trunk exists: same statistics of its own
+//  xb, not the same bits as an emitting producer - which of the two a layer uses is a function of its shape alone.)
+__global__ __launch_bounds__(256) void ln_partials_kernel(const f16_t* __restrict__ x, bf16_t* __restrict__ xb, float* __restrict__ part, int rows, int C, int bn) {
+    const int ntn = C / bn, nb = bn / 80;
     const long id = (long)blockIdx.x * 256 + threadIdx.x;
-    if (id >= (long)rows * nblk) return;
-    const f16_t* p = x + id * 80;                                     // rows are dense: row * C + blk * 80 = id * 80
-    float i1[10], i2[10];
+    if (id >= (long)rows * ntn) return;
+    const long row = id / ntn; const int tn = (int)(id - row * ntn);
+    float t1 = 0.f, t2 = 0.f;
+    for (int b = 0; b < nb; ++b) {
+        const long off = row * C + (long)tn * bn + b * 80;
+        const f16_t* p = x + off;
+        float i1[10], i2[10];
 #pragma unroll
-    for (int j = 0; j < 10; ++j) {
-        const uint4 v = *(const uint4*)(p + j * 8);
-        const f16_t* h = (const f16_t*)&v;
-        float s1 = 0.f, s2 = 0.f;
+        for (int j = 0; j < 10; ++j) {
+            const uint4 v = *(const uint4*)(p + j * 8);
+            const f16_t* h = (const f16_t*)&v;
+            uint4 cb;
+            cb.x = pack_bf16x2((float)h[0], (float)h[1]); cb.y = pack_bf16x2((float)h[2], (float)h[3]);
+            cb.z = pack_bf16x2((float)h[4], (float)h[5]); cb.w = pack_bf16x2((float)h[6], (float)h[7]);
+            *(uint4*)(xb + off + j * 8) = cb;
+            float s1 = 0.f, s2 = 0.f;
+            asm volatile("v_dot2c_f32_bf16 %0, %2, %6\n\tv_dot2c_f32_bf16 %1, %2, %2\n\t"
+                         "v_dot2c_f32_bf16 %0, %3, %6\n\tv_dot2c_f32_bf16 %1, %3, %3\n\t"
+                         "v_dot2c_f32_bf16 %0, %4, %6\n\tv_dot2c_f32_bf16 %1, %4, %4\n\t"
+                         "v_dot2c_f32_bf16 %0, %5, %6\n\tv_dot2c_f32_bf16 %1, %5, %5\n\t"
+                         "s_nop 2"      /* a DOT result read by another VALU opcode needs 3 wait states, and hipcc's hazard recogniser does not look into asm */
+                         : "+v"(s1), "+v"(s2) : "v"(cb.x), "v"(cb.y), "v"(cb.z), "v"(cb.w), "v"(0x3f803f80u));
+            i1[j] = s1; i2[j] = s2;
+        }
+        float q1[4], q2[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const float f = (float)h[e]; s1 += f; s2 = fmaf(f, f, s2); }
-        i1[j] = s1; i2[j] = s2;
+        for (int jj = 0; jj < 4; ++jj) {
+            q1[jj] = i1[jj] + i1[jj + 4]; q2[jj] = i2[jj] + i2[jj + 4];
+            if (jj < 2) { q1[jj] += i1[jj + 8]; q2[jj] += i2[jj + 8]; }
+        }
+        const float b1 = (q1[0] + q1[1]) + (q1[2] + q1[3]), b2 = (q2[0] + q2[1]) + (q2[2] + q2[3]);
+        if (b == 0) { t1 = b1; t2 = b2; } else { t1 += b1; t2 += b2; }
     }
-    float q1[4], q2[4];
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-        q1[jj] = i1[jj] + i1[jj + 4]; q2[jj] = i2[jj] + i2[jj + 4];
-        if (jj < 2) { q1[jj] += i1[jj + 8]; q2[jj] += i2[jj + 8]; }
-    }
-    *(float2*)(part + id * 2) = make_float2((q1[0] + q1[1]) + (q1[2] + q1[3]), (q2[0] + q2[1]) + (q2[2] + q2[3]));
+    *((float2*)part + ((long)(tn >> 1) * rows + row) * 2 + (tn & 1)) = make_float2(t1, t2);
 }
-void launch_ln_partials(const f16_t* x, float* part, int rows, int C, hipStream_t st) {
-    RT_REQUIRE(rows > 0 && C % 80 == 0, "ln_partials: C must be a multiple of 80");
-    const long n = (long)rows * (C / 80);
-    hipLaunchKernelGGL(ln_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, part, rows, C / 80);
+void launch_ln_partials(const f16_t* x, bf16_t* xb, float* part, int rows, int C, int bn, hipStream_t st) {
+    RT_REQUIRE(rows > 0 && (bn == 160 || bn == 320) && C % (2 * bn) == 0 && C / bn <= 8, "ln_partials: column tiles of 160 / 320, an even number (at most 8) per row");
+    const long n = (long)rows * (C / bn);
+    hipLaunchKernelGGL(ln_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, xb, part, rows, C, bn);
     HIP_CHECK(hipGetLastError());
 }
