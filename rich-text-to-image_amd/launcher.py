@@ -233,10 +233,45 @@ def split_region_step(engine, i, guidance_scale, inject_selfattn, inject_backgro
                                                                           elide=elide, defer_blend=defer_blend)
     ranges = split_ranges(n_streams, s_tref, inject, world)          # a function of the step alone: no collective needed to agree on it
     assert ranges[rank] == (first, count)
-    engine.synchronize()
+    engine.synchronize()                                            # this rank's slice is complete before any rank reads it
     eps, per = eps_tensor(engine)
     for r, (f, c) in enumerate(ranges):
         if c > 0:
             broadcast_tensor(eps[f * per:(f + c) * per], src=r)
+    # ORDERING CONTRACT: with RCCL dist.broadcast returns once the collective is ENQUEUED on the process group's stream; the engine's
+    # own HIP stream (rt_set_stream may have installed a non-blocking one, e.g. under graph capture) is not ordered behind it.  The
+    # epilogue below reads every rank's slice, so the received bytes must have landed: a device-wide synchronise (1.8 MB per step, the
+    # epilogue is a few microseconds: nothing worth overlapping).  broadcast_weights does the same after its collective.
+    _cuda_sync()
     engine.region_step_finish(i, guidance_scale, inject_selfattn, inject_background, xl, elide=elide, defer_blend=defer_blend)
     return ranges
+
+
+def assert_ranks_agree(tensor, what="state", every_rank_raises=True):
+    """--split_image relies on every rank holding bit-identical latents / masks (each rank computes the plain pass, the CPU clustering
+    and the guidance update itself).  A cheap guard: the int64 view of the tensor's bytes is summed with position weights and
+    compared across ranks (one 16-byte all_gather); any divergence - a different GPU SKU, library version or thread count per rank -
+    fails loudly instead of silently mixing inconsistent noise predictions into one image."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return True
+    t = tensor.detach().contiguous().view(-1)
+    raw = t.view(torch.uint8) if t.dtype != torch.uint8 else t
+    pad = (-raw.numel()) % 8
+    if pad:
+        raw = torch.cat([raw, raw.new_zeros(pad)])
+    words = raw.view(torch.int64)
+    w = torch.arange(1, words.numel() + 1, dtype=torch.int64, device=words.device)
+    digest = torch.stack([words.sum(), (words * w).sum()]).cpu()          # int64 wrap-around arithmetic: order-sensitive, exact
+    got = [torch.zeros(2, dtype=torch.int64) for _ in range(dist.get_world_size())]
+    if dist.get_backend() == "nccl":
+        dev = tensor.device if tensor.is_cuda else torch.device("cuda", torch.cuda.current_device())
+        gl = [g.to(dev) for g in got]
+        dist.all_gather(gl, digest.to(dev))
+        got = [g.cpu() for g in gl]
+    else:
+        dist.all_gather(got, digest)
+    same = all(torch.equal(g, got[0]) for g in got)
+    if not same and every_rank_raises:
+        raise RuntimeError(f"--split_image: ranks disagree on {what} (digests {[g.tolist() for g in got]}): the intra-image split needs "
+                           "homogeneous ranks (same GPU model, same library build, same host thread count)")
+    return same

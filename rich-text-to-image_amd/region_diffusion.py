@@ -90,7 +90,11 @@ class RegionDiffusion:
         eng.set_latents(latents.to(self.device))
         for i, t in enumerate(self.scheduler.timesteps):
             if getattr(self, "split_image", False):      # intra-image split over the ranks of the process group (launcher.split_region_step)
-                from .launcher import split_region_step
+                from .launcher import assert_ranks_agree, split_region_step
+                if i % 10 == 0:                          # every rank must hold the same masks / latents (homogeneous ranks): fail loudly otherwise
+                    if i == 0:
+                        assert_ranks_agree(torch.cat([m.reshape(-1).float().cpu() for m in self.masks]), "the region masks")
+                    assert_ranks_agree(eng.read_latents(latents.shape[-2], latents.shape[-1]), f"the latents before step {i}")
                 split_region_step(eng, i, guidance_scale, inject_selfattn, inject_background, False, elide=elide_dead_forwards, defer_blend=use_guidance)
             else:
                 eng.region_step(i, guidance_scale, inject_selfattn, inject_background, xl=False, elide=elide_dead_forwards,

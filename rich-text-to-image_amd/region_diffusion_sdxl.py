@@ -108,7 +108,11 @@ class RegionDiffusionXL:
                 if getattr(self, "split_image", False):
                     # intra-image split (launcher.split_region_step): the ranks of the process group share THIS image's step - each runs
                     # the forwards of its stream range, one exchange of the noise predictions, every rank finishes the step
-                    from .launcher import split_region_step
+                    from .launcher import assert_ranks_agree, split_region_step
+                    if i % 10 == 0:                      # every rank must hold the same masks / latents (homogeneous ranks): fail loudly otherwise
+                        if i == 0:
+                            assert_ranks_agree(torch.cat([m.reshape(-1).float().cpu() for m in self.masks]), "the region masks")
+                        assert_ranks_agree(eng.read_latents(h, w), f"the latents before step {i}")
                     split_region_step(eng, i, guidance_scale, inject_selfattn, inject_background, True, elide=elide_dead_forwards, defer_blend=use_guidance)
                 else:
                     eng.region_step(i, guidance_scale, inject_selfattn, inject_background, xl=True, elide=elide_dead_forwards,

@@ -34,39 +34,48 @@ class HipUNet2DConditionModel:
             self.max_streams, grow = min(16, max(streams, 2 * self.max_streams)), True
         if prompts and prompts > self.max_prompts:
             self.max_prompts, grow = max(prompts, 2 * self.max_prompts), True
-        donor = None
+        empty = isinstance(self._state_dict, str) and self._state_dict == "empty"
+        # A model built "empty" (ranks != 0 of a seed-parallel launch) holds weights that exist nowhere else on this rank: the packed
+        # arena it received by launcher.broadcast_weights.  Its layout is a function of the config alone (not of the stream / prompt
+        # capacity or the latent size), so a new engine - a grown one, or one for another latent size - takes it over device to
+        # device from ANY engine that is bound.  The donor stays registered until the copy has succeeded: if the
+        # allocation of the new engine fails, nothing is lost.
+        donor = next((e for e in self._engines.values() if e.weights_missing()[0] == 0), None) if empty else None
+        stale = dict(self._engines) if grow else {}
         if grow:
-            # A model built "empty" (ranks != 0 of a seed-parallel launch) holds weights that exist nowhere else on this rank: the
-            # packed arena it received by launcher.broadcast_weights.  Its layout is a function of the config alone (not of the
-            # stream / prompt capacity), so the rebuilt engine takes it over device to device.
-            if isinstance(self._state_dict, str) and self._state_dict == "empty":
-                donor = next((e for e in self._engines.values() if e.weights_missing()[0] == 0), None)
-            for e in self._engines.values():
-                if e is not donor:
-                    e.close()
             self._engines = {}
         key = (h, w)
         if key not in self._engines:
-            e = Engine(self.config_dict, h, w, device=self.device_index, max_streams=self.max_streams,
-                       max_prompts=self.max_prompts)
             if self._state_dict is None:
                 raise RuntimeError("HipUNet2DConditionModel: no weights loaded (call load_state_dict)")
-            if isinstance(self._state_dict, str) and self._state_dict == "empty":
-                if donor is not None:                                           # grown engine of a broadcast-fed rank
-                    from .launcher import arena_tensor
-                    src, dst = arena_tensor(donor), arena_tensor(e)
-                    if src.numel() != dst.numel():
-                        raise RuntimeError(f"weight arena layout changed with the engine capacity ({src.numel()} vs {dst.numel()} bytes)")
-                    dst.copy_(src)
-                    torch.cuda.synchronize(self.device_index)
-                    e.arena_mark_bound()
-                    donor.close()
-                # otherwise the packed arena arrives by launcher.broadcast_weights
-            elif isinstance(self._state_dict, str) and self._state_dict.startswith("random"):
-                e.init_random_weights(seed=int(self._state_dict[6:] or 0))      # "random<seed>": benchmarks without checkpoints
-            else:
-                e.load_state_dict(self._state_dict)
+            try:
+                e = Engine(self.config_dict, h, w, device=self.device_index, max_streams=self.max_streams,
+                           max_prompts=self.max_prompts)
+                try:
+                    if empty:
+                        if donor is not None:
+                            from .launcher import arena_tensor
+                            src, dst = arena_tensor(donor), arena_tensor(e)
+                            if src.numel() != dst.numel():
+                                raise RuntimeError(f"weight arena layout changed with the engine capacity ({src.numel()} vs {dst.numel()} bytes)")
+                            dst.copy_(src)
+                            torch.cuda.synchronize(self.device_index)
+                            e.arena_mark_bound()
+                        # otherwise the packed arena arrives by launcher.broadcast_weights
+                    elif isinstance(self._state_dict, str) and self._state_dict.startswith("random"):
+                        e.init_random_weights(seed=int(self._state_dict[6:] or 0))      # "random<seed>": benchmarks without checkpoints
+                    else:
+                        e.load_state_dict(self._state_dict)
+                except BaseException:
+                    e.close()
+                    raise
+            except BaseException:
+                if grow:                                   # the old engines (and the only copy of a broadcast-fed rank's weights) stay usable
+                    self._engines = stale
+                raise
             self._engines[key] = e
+        for old in stale.values():                         # the rebuilt engine is bound: the smaller ones can go
+            old.close()
         return self._engines[key]
 
     def __call__(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None, **kw):

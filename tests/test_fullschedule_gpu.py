@@ -8,6 +8,8 @@ reference loops by tests/test_oracle_vs_reference.py), generated in the build co
   * config3     RegionDiffusionXL.sample(rich)       xl.py:779-878,916-944   SDXL @ 1024x1024, R = 4, inject_selfattn 0.5, 10 Euler steps
   * config3_50  the same, the full 50-step schedule (the benched workload end to end)
   * config5     the same loop + colour guidance (xl.py:849-867) + background blend, CFG 7.5, 4 Euler steps @ 1024x1024
+  * round 6: config2_50 (51 PLMS iterations), config5_50 (50-step schedule, 10-segment Voronoi masks, first 30 iterations across the
+    blend at index 25), config3_unit (config3_50 from unit-variance latents: the update dominates the start noise)
 
 The weights are not committed: `oracle.unet.random_state_dict(cfg, seed)` draws them with torch's CPU generator, bit-identically
 here and in the build container (checked against the fingerprint in the file).  The HIP engine runs the same schedule through the
@@ -37,11 +39,21 @@ import fullschedule_check as fc  # noqa: E402
 # config5 8.2e-3 / 52.8 dB / 0.33 / 4; config3_50 (all 50 steps) 2.4e-3 / 58.7 dB / 0.09 / 1 - the error of one forward (7e-3 at CFG 1) does not compound over the schedule.
 TOL = {
     "config1": (1.5e-2, 46.0, 1.0, 8),
-    "config2": (2.5e-2, 44.0, 1.5, 12),
+    "config2": (1.5e-2, 46.0, 1.0, 8),
     "config3": (1.5e-2, 46.0, 1.0, 8),
     "config3_50": (1.5e-2, 46.0, 1.0, 8),
     "config5": (2.5e-2, 46.0, 1.0, 8),
+    # round 6: the cases at BASELINE's own lengths / mask shape, and the unit-variance start (see UPDATE_TOL)
+    "config2_50": (1.5e-2, 46.0, 1.0, 8),
+    "config5_50": (2.5e-2, 46.0, 1.0, 8),
+    "config3_unit": (2.5e-2, 40.0, 2.0, 16),
 }
+# The DISCRIMINATING bound: error relative to the accumulated update ||lat_k - lat_0|| of the oracle, at every recorded
+# iteration.  With seeded random weights the UNet does not denoise: in the sigma-scaled cases the latents stay ~95 % start noise
+# (||update|| / ||latents|| = 0.3 - 0.4), so the latent-relative figures above are 2.5 - 3x smaller than these; `config3_unit` starts
+# from unit-variance latents, where the update IS the latent (ratio ~1) and the two figures coincide.  One forward differs from the
+# fp32 oracle by 7e-3 (CFG 1); CFG multiplies that by the guidance scale relative to the difference of the two predictions.
+UPDATE_TOL = {"config1": 2.0e-2, "config2": 2.0e-2, "config3": 3.0e-2, "config3_50": 3.0e-2, "config5": 4.5e-2, "config2_50": 2.0e-2, "config5_50": 4.5e-2, "config3_unit": 3.0e-2}
 RESULTS = {}
 
 
@@ -55,12 +67,17 @@ def _check(name, mdl, fp):
     with open(os.path.join(out, "fullschedule_parity.json"), "w") as f:
         json.dump(RESULTS, f, indent=1)
     curve, pix, pix_dec = r["latent_rel_l2_by_iteration"], r["pixels_vs_oracle_image"], r["decoder_only"]
+    ucurve = r["latent_update_rel_l2_by_iteration"]
     print(f"{name}: latent rel-L2 by loop iteration: " + ", ".join(f"{k}: {v:.3e}" for k, v in curve.items()))
+    print(f"{name}: error relative to the accumulated UPDATE ||lat_k - lat_0||: " + ", ".join(f"{k}: {v:.3e}" for k, v in ucurve.items())
+          + f"   (||update|| / ||latents|| at the end {r['update_over_latents_final']:.2f}; latent std {r['latent_std_start_final'][0]:.2f} -> {r['latent_std_start_final'][1]:.2f};"
+          f" absolute rms error per element at the end {list(r['latent_abs_rms_by_iteration'].values())[-1]:.3e})")
     print(f"{name}: final image vs the oracle's image: PSNR {pix['psnr_db']:.2f} dB, mean |d| {pix['mean_abs']:.3f} / 255, max |d| {pix['max_abs']}, "
           f"within 1 / 2 / 8 levels {pix['within_1']:.4f} / {pix['within_2']:.4f} / {pix['within_8']:.4f}")
     print(f"{name}: decoder only (oracle latents through the engine's decoder): PSNR {pix_dec['psnr_db']:.2f} dB, mean |d| {pix_dec['mean_abs']:.4f}, max |d| {pix_dec['max_abs']}")
     t_lat, t_psnr, t_mean, t_max = TOL[name]
     assert max(curve.values()) < t_lat, curve
+    assert max(ucurve.values()) < UPDATE_TOL[name], ucurve
     assert pix["psnr_db"] > t_psnr and pix["mean_abs"] < t_mean and pix["max_abs"] <= t_max, pix
     assert pix_dec["psnr_db"] > 40.0, pix_dec
 
@@ -97,3 +114,21 @@ def test_config1_full_plms_schedule_latents_and_pixels(sd_model):
 
 def test_config2_guided_plms_schedule_latents_and_pixels(sd_model):
     _check("config2", *sd_model)
+
+
+def test_config2_full_fifty_step_guided_schedule_latents_and_pixels(sd_model):
+    """BASELINE config 2 at its own length: 50 requested steps = 51 PLMS iterations, 4 regions, colour guidance on 2 of them."""
+    _check("config2_50", *sd_model)
+
+
+def test_config5_fifty_step_schedule_voronoi_masks_across_the_blend(sdxl_model):
+    """BASELINE config 5 on its 50-step schedule with the 10-segment masks (10 Voronoi cells on 32 x 32 dealt to the 4 regions,
+    resized / normalised as attention_utils.py:322-327), footnote + colour guidance, CFG 7.5, recorded over the first 30 iterations:
+    across the background blend after loop index 25 (xl.py:870)."""
+    _check("config5_50", *sdxl_model)
+
+
+def test_config3_unit_variance_start_fifty_steps(sdxl_model):
+    """config3_50 started from unit-variance latents: the accumulated update dominates the start noise, so the latent-relative error
+    is the update-relative error - the regime a trained checkpoint ends in."""
+    _check("config3_unit", *sdxl_model)
