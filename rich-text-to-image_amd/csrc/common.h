@@ -102,7 +102,6 @@ static __device__ __forceinline__ void glds16_buf(const void* base, int voff_byt
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, range_bytes, 0x00020000);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff_bytes, soff_bytes, 0, 0);
 }
-
 // ---------------------------------------------------------------- GEMM / implicit-GEMM conv
 enum { A_DENSE = 0, A_CONV3 = 1, A_CONV3_S2 = 2, A_CONV3_UP2 = 3 };
 enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_BF16_TEMB = 2, EPI_GEGLU = 3, EPI_F16 = 4,   // EPI_F16: fp16 output (+ fp16 residual): the UNet trunk
@@ -269,6 +268,8 @@ struct GroupNormArgs {
                                        // itself (one launch fewer; `partial` keeps the RAW sums).  0: gn_finalize_kernel leaves
                                        // (mean, rstd) in chunk 0's slot, which the VAE backward reads.
     double fin_n;                      // set by launch_groupnorm: elements per group
+    int apply_rows;                    // set by launch_groupnorm: rows per workgroup of the apply kernel
+    float* stats; int stats_ld;        // set by launch_groupnorm: where the apply kernel finds (mean, rstd) per (batch entry, group) in the non-fused form
 };
 int groupnorm_rows_per_chunk(int HW);
 void launch_groupnorm(const GroupNormArgs& a, hipStream_t st);

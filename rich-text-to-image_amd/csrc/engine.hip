@@ -731,13 +731,16 @@ struct rt_engine {
                     layernorm(hcur, k.ln3, n, M);
                     gemm(n, C, k.ff1, M, gg, 4 * C, EPI_GEGLU);
                 }
-                const bool need1 = fold1 && !last;                   // the next block's norm1 reads what ff.net.2 leaves
-                gemm(gg, 4 * C, k.ff2, M, hcur, C, EPI_F16, hcur, C, nullptr, 0, need1 && emit_ff2 ? &em : nullptr);
+                // the next block's norm1 reads what ff.net.2 leaves; behind the LAST block proj_out reads the trunk as bf16 - which is
+                // exactly the xb an emitting ff.net.2 writes (the cast launch below is then not needed)
+                const bool need1 = fold1 && !last, copy_last = last && fold1 && emit_ff2;
+                gemm(gg, 4 * C, k.ff2, M, hcur, C, EPI_F16, hcur, C, nullptr, 0, (need1 || copy_last) && emit_ff2 ? &em : nullptr);
                 if (need1) partials_after(emit_ff2);
             }
+            const bool have_xb = fold1 && emit_ff2 && !t.blocks.empty();
             bf16_t* hb = ws.b16((size_t)M * C);
-            if (!dry()) launch_cast_f16_bf16(hcur, hb, (size_t)M * C, stream);
-            gemm(hb, C, t.pout, M, out, C, EPI_F16, x.p, C);
+            if (!dry() && !have_xb) launch_cast_f16_bf16(hcur, hb, (size_t)M * C, stream);
+            gemm(have_xb ? xb : hb, C, t.pout, M, out, C, EPI_F16, x.p, C);
         }
         return Tensor{out, C};
     }

@@ -134,6 +134,9 @@
             const int wk = MODE == A_CONV3 ? (is_tap * p.Cin + is_chunk * BK16) * 2 : (TRIPLE_DENSE ? d_kt : t) * (BK16 * 2);
             const void* base = pisA[i] ? (const void*)(TRIPLE_DENSE && d_pass == 1 ? p.A_lo : p.A)
                                        : (const void*)(((MODE == A_CONV3 && is_pass == 2) || (TRIPLE_DENSE && d_pass == 2)) ? p.W_lo : p.W);
+            // (round 6, measured and dropped: the activation pieces of the W-stationary GEGLU as non-temporal loads, so that the A stream
+            //  would not evict the XCD's 3.3 MB of W between rounds - the step got 1.8 ms SLOWER: the five column workgroups of a row panel
+            //  then fetch A from the fabric one by one instead of sharing it through L2; profiles/r6_ab_geglu_nt_activation_stream.txt)
             glds16_buf(base, voff[i], wk, smem + slot_off + ldst[i]);
         }
     };

@@ -31,6 +31,10 @@ __device__ __forceinline__ void load4(const void* x1, const void* x2, int C1, in
     }
 }
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
 // Thread decomposition shared by both kernels: nv = C/4 channel vectors per row; the block is tcols x nrl threads
 // (gn_block_shape): tcols = ceil(nv / ceil(nv/512)) vector columns, nrl = 512 / tcols row lanes; a thread owns the vectors
 // v0, v0 + tcols, ... and every nrl-th row.  (With a fixed 256-thread block 38 % of the threads idled at C = 640 / 1280.)
@@ -45,7 +49,7 @@ __host__ __device__ inline GnShape gn_block_shape(int nv) {
 // grid (nchunk, B); partial[b][chunk][g][2] = (sum, sumsq) over this chunk's rows
 template <int BF16IN>
 __global__ __launch_bounds__(512) void gn_stats_kernel(GroupNormArgs p) {
-    __shared__ float sh_s[GN_MAXC], sh_q[GN_MAXC];
+    __shared__ __attribute__((aligned(16))) float sh_s[GN_MAXC], sh_q[GN_MAXC];
     const int C = p.C1 + p.C2, cpg = C / p.G, nv = C >> 2;
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int r0 = chunk * p.rows_per_chunk;
@@ -76,17 +80,33 @@ __global__ __launch_bounds__(512) void gn_stats_kernel(GroupNormArgs p) {
                     for (int e = 0; e < 4; ++e) { const float t = ok ? v[u][e] : 0.f; s[e] += t; ss[e] += t * t; }
                 }
             }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { sh_s[rl * C + c + e] = s[e]; sh_q[rl * C + c + e] = ss[e]; }
+            // one 16-B store per array (four 4-B stores at a 16-B lane stride were 4-way bank conflicts: LDS conflict fraction 0.66 - 0.69 in
+            // profiles/r5_pmc_sq.json)
+            *(float4*)&sh_s[rl * C + c] = make_float4(s[0], s[1], s[2], s[3]);
+            *(float4*)&sh_q[rl * C + c] = make_float4(ss[0], ss[1], ss[2], ss[3]);
         }
     }
     __syncthreads();
-    if (threadIdx.x < p.G) {   // fixed summation order => deterministic
-        float s = 0.f, q = 0.f;
-        for (int k = 0; k < nrl; ++k)
-            for (int c = threadIdx.x * cpg; c < (threadIdx.x + 1) * cpg; ++c) { s += sh_s[k * C + c]; q += sh_q[k * C + c]; }
-        float* dst = p.partial + ((size_t)b * p.nchunk + chunk) * 2 * p.G + 2 * threadIdx.x;
-        dst[0] = s; dst[1] = q;
+    // Group sums by ALL 512 threads: 16 lanes per group, lane j adds the group's elements j, j + 16, ... of every row lane in a fixed
+    // order (consecutive lanes read consecutive floats: conflict-free), then a fixed 16-lane tree (quad DPP + two row rotations): deterministic.
+    // (Round 5: 32 threads walked cpg x nrl elements each at a stride of cpg floats - 8-way conflicts at 80 channels per group, and a serial
+    //  tail of ~160 LDS reads per block.)
+    {
+        const int nslot = blockDim.x >> 4, slot = threadIdx.x >> 4, j = threadIdx.x & 15;      // whole 16-lane DPP rows of the block (320 / 480 / 512 threads: 20 / 30 / 32)
+        for (int g0 = 0; g0 < p.G; g0 += nslot) {                                               // (uniform trip count: the DPP steps run converged)
+            const int g = g0 + slot;
+            float s = 0.f, q = 0.f;
+            if (slot < nslot && g < p.G) {
+                for (int k = 0; k < nrl; ++k)
+                    for (int c = g * cpg + j; c < (g + 1) * cpg; c += 16) { s += sh_s[k * C + c]; q += sh_q[k * C + c]; }
+            }
+            s = dpp_add<0xB1>(s); s = dpp_add<0x4E>(s); s = dpp_add<0x124>(s); s = dpp_add<0x128>(s);      // quad_perm [1,0,3,2], [2,3,0,1], row_ror 4, row_ror 8
+            q = dpp_add<0xB1>(q); q = dpp_add<0x4E>(q); q = dpp_add<0x124>(q); q = dpp_add<0x128>(q);
+            if (slot < nslot && g < p.G && j == 0) {
+                float* dst = p.partial + ((size_t)b * p.nchunk + chunk) * 2 * p.G + 2 * g;
+                dst[0] = s; dst[1] = q;
+            }
+        }
     }
 }
 
@@ -171,6 +191,24 @@ __global__ __launch_bounds__(512) void gn_apply_kernel(GroupNormArgs p) {
     __shared__ float mean[32], rstd[32];
     const int C = p.C1 + p.C2, cpg = C / p.G, nv = C / VW;
     const int b = blockIdx.y, chunk = blockIdx.x;
+    // the rows this thread starts with are requested BEFORE the statistics are finalized (they do not depend on them): the first
+    // memory round trip of the block runs beside the finalize below instead of behind it (round 6)
+    const int r0 = chunk * p.apply_rows;
+    const int r1 = min(r0 + p.apply_rows, p.HW);
+    const GnShape shp = gn_block_shape(nv);
+    const int nrl = shp.nrl, tcols = shp.tcols;
+    const int rl = threadIdx.x / tcols;
+    const int v0 = threadIdx.x - rl * tcols;
+    constexpr int RIF = 2;                                          // rows in flight per thread (round 6: 4 measured SLOWER: 31.6 -> 36.6 us at 7 x 1024 x 2560)
+    float vpre[RIF][VW];
+    const bool active = rl < nrl && v0 < nv && r0 + rl < r1;
+    if (active) {
+#pragma unroll
+        for (int u = 0; u < RIF; ++u) {
+            const int rr = r0 + rl + u * nrl < r1 ? r0 + rl + u * nrl : r0 + rl;
+            loadv<BF16IN, VW>(p.x1, p.x2, p.C1, p.C2, (size_t)b * p.HW + rr, v0 * VW, vpre[u]);
+        }
+    }
     if (p.fuse_finalize) {
         // raw per-chunk (sum, sumsq): 16 threads per group sum every 16th chunk in fp64, thread g adds the 16 pieces in a fixed
         // order => deterministic and independent of the batch size; same (mean, rstd) arithmetic as gn_finalize_kernel mode 0
@@ -178,10 +216,17 @@ __global__ __launch_bounds__(512) void gn_apply_kernel(GroupNormArgs p) {
         for (int idx = threadIdx.x; idx < p.G * 16; idx += blockDim.x) {
             const int g = idx >> 4, j = idx & 15;
             double s = 0.0, q = 0.0;
-            for (int k = j; k < p.nchunk; k += 16) {
-                const float2 sq = *(const float2*)(p.partial + ((size_t)b * p.nchunk + k) * 2 * p.G + 2 * g);
-                s += (double)sq.x; q += (double)sq.y;
+            // nchunk <= 128 (launch_groupnorm): at most 8 partials per thread, requested TOGETHER (the rolled loop was up to 8 dependent
+            // round trips in front of every block's first row), added in the same ascending order
+            float2 sq[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = j + 16 * u;
+                sq[u] = k < p.nchunk ? *(const float2*)(p.partial + ((size_t)b * p.nchunk + k) * 2 * p.G + 2 * g) : make_float2(0.f, 0.f);
             }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (j + 16 * u < p.nchunk) { s += (double)sq[u].x; q += (double)sq[u].y; }
             fs[idx] = s; fq[idx] = q;
         }
         __syncthreads();
@@ -193,33 +238,60 @@ __global__ __launch_bounds__(512) void gn_apply_kernel(GroupNormArgs p) {
             if (var < 0) var = 0;
             mean[threadIdx.x] = (float)mu; rstd[threadIdx.x] = (float)(1.0 / sqrt(var + (double)p.eps));
         }
-    } else if (threadIdx.x < p.G) {
-        mean[threadIdx.x] = p.partial[(size_t)b * p.nchunk * 2 * p.G + 2 * threadIdx.x];
-        rstd[threadIdx.x] = p.partial[(size_t)b * p.nchunk * 2 * p.G + 2 * threadIdx.x + 1];
+        __syncthreads();
     }
-    __syncthreads();
-    const int r0 = chunk * p.rows_per_chunk;
-    const int r1 = min(r0 + p.rows_per_chunk, p.HW);
-    const GnShape shp = gn_block_shape(nv);
-    const int nrl = shp.nrl, tcols = shp.tcols;
-    const int rl = threadIdx.x / tcols;
-    const int v0 = threadIdx.x - rl * tcols;
+    // finalized statistics (fuse_finalize == 0: (mean, rstd) of group g sit in p.stats[b][g] - left there by the statistics kernel's last
+    // workgroup or by gn_finalize_kernel): every thread reads the one or two groups its channels belong to itself - no LDS, no barrier
+    const float2* gstat = p.fuse_finalize ? nullptr : (const float2*)p.stats + (size_t)b * (p.stats_ld >> 1);
     if (rl >= nrl) return;
     for (int vec = v0; vec < nv; vec += tcols) {
         const int c = vec * VW;
         float sc[VW], sh[VW];                                      // y = x * sc + sh  ==  (x - mean) * rstd * gamma + beta
+        float gm[VW], bt[VW];
 #pragma unroll
-        for (int e = 0; e < VW; ++e) {
-            const int g = (c + e) / cpg;
-            sc[e] = rstd[g] * p.gamma[c + e]; sh[e] = p.beta[c + e] - mean[g] * sc[e];
+        for (int h = 0; h < VW / 4; ++h) {
+            const float4 g4 = *(const float4*)(p.gamma + c + 4 * h), b4 = *(const float4*)(p.beta + c + 4 * h);
+            gm[4 * h] = g4.x; gm[4 * h + 1] = g4.y; gm[4 * h + 2] = g4.z; gm[4 * h + 3] = g4.w;
+            bt[4 * h] = b4.x; bt[4 * h + 1] = b4.y; bt[4 * h + 2] = b4.z; bt[4 * h + 3] = b4.w;
         }
-        for (int r = r0 + rl; r < r1; r += 2 * nrl) {               // two rows in flight per thread
-            float v[2][VW];
+        if (cpg >= VW) {
+            const int g0 = c / cpg, split = (g0 + 1) * cpg - c;     // channels c .. c + split - 1 belong to group g0, the rest to g0 + 1
+            const int g1 = g0 + 1 < p.G ? g0 + 1 : g0;
+            float m0, r0s, m1, r1s;
+            if (p.fuse_finalize) { m0 = mean[g0]; r0s = rstd[g0]; m1 = mean[g1]; r1s = rstd[g1]; }
+            else { const float2 a0 = gstat[g0], a1 = gstat[g1]; m0 = a0.x; r0s = a0.y; m1 = a1.x; r1s = a1.y; }
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
-                if (r + u * nrl < r1) loadv<BF16IN, VW>(p.x1, p.x2, p.C1, p.C2, (size_t)b * p.HW + r + u * nrl, c, v[u]);
+            for (int e = 0; e < VW; ++e) {
+                const float mg = e < split ? m0 : m1, rg = e < split ? r0s : r1s;
+                sc[e] = rg * gm[e]; sh[e] = bt[e] - mg * sc[e];
+            }
+        } else {                                                   // narrow groups (tiny configurations): a vector spans several of them
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int e = 0; e < VW; ++e) {
+                const int g = (c + e) / cpg;
+                float mg, rg;
+                if (p.fuse_finalize) { mg = mean[g]; rg = rstd[g]; } else { const float2 a = gstat[g]; mg = a.x; rg = a.y; }
+                sc[e] = rg * gm[e]; sh[e] = bt[e] - mg * sc[e];
+            }
+        }
+        for (int r = r0 + rl; r < r1; r += RIF * nrl) {
+            float v[RIF][VW];
+            // rows past the end of the chunk re-read row r (clamped address, not branched around: a branch per load compiles to
+            // load ; s_waitcnt vmcnt(0) RIF times over) and are skipped below
+            if (vec == v0 && r == r0 + rl) {                        // the trip that was requested in front of the finalize
+#pragma unroll
+                for (int u = 0; u < RIF; ++u)
+#pragma unroll
+                    for (int e = 0; e < VW; ++e) v[u][e] = vpre[u][e];
+            } else {
+#pragma unroll
+                for (int u = 0; u < RIF; ++u) {
+                    const int rr = r + u * nrl < r1 ? r + u * nrl : r;
+                    loadv<BF16IN, VW>(p.x1, p.x2, p.C1, p.C2, (size_t)b * p.HW + rr, c, v[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < RIF; ++u) {
                 if (r + u * nrl >= r1) continue;
                 const size_t row = (size_t)b * p.HW + r + u * nrl;
                 float y[VW];
@@ -253,14 +325,19 @@ void launch_groupnorm(const GroupNormArgs& a, hipStream_t st) {
     const GnShape sh8 = gn_block_shape(C >> 3);
     dim3 block8(sh8.tcols * sh8.nrl);
     GroupNormArgs aa = a;
+    // (round 6, measured and dropped - profiles/r6_groupnorm_experiments.txt: a finer apply grid, four rows in flight, the finalize as its own
+    //  launch, and the statistics kernel's last workgroup finalizing behind a ticket counter)
     aa.fuse_finalize = a.fuse_finalize && a.nchunk <= 128;
     aa.fin_n = n;
+    aa.stats = a.partial; aa.stats_ld = a.nchunk * 2 * a.G;        // non-fused form: gn_finalize_kernel leaves (mean, rstd) in chunk 0's slot of every batch entry
+    aa.apply_rows = a.rows_per_chunk;
+    dim3 grid_apply(cdiv(a.HW, aa.apply_rows), a.B);
 #define RT_GN_LAUNCH(IT)                                                                                  \
     {                                                                                                         \
         hipLaunchKernelGGL(gn_stats_kernel<IT>, grid, block, 0, st, aa);                                      \
         if (!aa.fuse_finalize) launch_gn_finalize(a.partial, a.B, a.nchunk, a.G, n, a.eps, 0, st);            \
-        if (wide) hipLaunchKernelGGL((gn_apply_kernel<IT, 8>), grid, block8, 0, st, aa);                      \
-        else hipLaunchKernelGGL((gn_apply_kernel<IT, 4>), grid, block, 0, st, aa);                            \
+        if (wide) hipLaunchKernelGGL((gn_apply_kernel<IT, 8>), grid_apply, block8, 0, st, aa);                \
+        else hipLaunchKernelGGL((gn_apply_kernel<IT, 4>), grid_apply, block, 0, st, aa);                      \
     }
     if (a.in_bf16 == 1) RT_GN_LAUNCH(1) else if (a.in_bf16 == 2) RT_GN_LAUNCH(2) else RT_GN_LAUNCH(0)
 #undef RT_GN_LAUNCH
@@ -283,10 +360,6 @@ __device__ __forceinline__ void ln_load8(const void* xr, int c, float4 (&v)[2]) 
 }
 // wave-wide sum, result in every lane: four DPP steps inside each row of 16 lanes (quad_perm [1,0,3,2] / [2,3,0,1], row_ror 4 / 8),
 // then the two cross-row exchanges through ds_bpermute (six dependent LDS round trips per sum before)
-template <int CTRL>
-__device__ __forceinline__ float dpp_add(float v) {
-    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
-}
 __device__ __forceinline__ float wave_sum(float v) {
     v = dpp_add<0xB1>(v); v = dpp_add<0x4E>(v); v = dpp_add<0x124>(v); v = dpp_add<0x128>(v);
     v += __shfl_xor(v, 16);
