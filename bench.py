@@ -327,6 +327,7 @@ def dry_launch(args):
     rank, local_rank, world = launcher.init_distributed("gloo")
     if world != args.gpus:
         sys.exit(f"bench: --gpus {args.gpus} but the launch environment says WORLD_SIZE={world}")
+    check = launcher.collective_self_check(nbytes=1 << 20)                  # the same self-check every real N > 1 launch starts with (gloo here)
     arena = (torch.arange(1 << 16, dtype=torch.int64) % 251).to(torch.uint8) if rank == 0 else torch.zeros(1 << 16, dtype=torch.uint8)
     t0 = time.perf_counter()
     calls = launcher.broadcast_tensor(arena, src=0)
@@ -338,7 +339,7 @@ def dry_launch(args):
     if rank == 0:
         print(json.dumps({"metric": "denoising steps/sec (SDXL 1024^2, 50-step, 4 regions)", "value": None, "unit": "steps/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_launch": True, "scaling": "weak",
-                          "weight_broadcast_calls": calls, "weight_broadcast_s": bcast_s, "arena_received": ok,
+                          "weight_broadcast_calls": calls, "weight_broadcast_s": bcast_s, "arena_received": ok, "collective_check": check,
                           "max_over_ranks": dt, "requests_rank0": mine}), flush=True)
     if not ok:
         sys.exit("bench: dry launch: broadcast payload mismatch")
@@ -387,6 +388,10 @@ def main():
         sys.exit(f"bench: --gpus {args.gpus} but the launch environment says WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
+    # N > 1: prove the collective path (64 MB pattern broadcast on the real backend, verified on every rank) before 5 GB of weights move
+    collective_check = launcher.collective_self_check() if world > 1 else None
+    if collective_check is not None and rank == 0:
+        print(f"bench: collective self-check {collective_check}", file=sys.stderr, flush=True)
 
     R, hw, nsched, gs, isa, ibg = 4, 128, 50, 5.0, 0.5, 0.0
     eng = Engine(SDXL_CONFIG, hw, hw, device=local_rank, max_streams=8, max_prompts=8)
@@ -635,7 +640,7 @@ def main():
             "whole_step_tflops_per_gpu": None if args.roofline_only else step_tflop / (dt / args.steps),
             "whole_step_mfma_frac": None if args.roofline_only else step_tflop / (dt / args.steps) / PEAK_BF16_TFLOPS,
             "executed_flops_per_step": step_flops, "nominal_tflop_per_step": 7 * SDXL_FWD_GFLOP / 1e3,
-            "weight_broadcast_s": bcast_s, "weight_broadcast_calls": launcher.LAST_BROADCAST_CALLS, "finite": finite,
+            "weight_broadcast_s": bcast_s, "weight_broadcast_calls": launcher.LAST_BROADCAST_CALLS, "collective_check": collective_check, "finite": finite,
             "roofline": roof, "cpu_baseline": cpu, "parity": parity, "pixel_parity": pixels, "cross_attention_block": xblock, "elide_dead_forwards_timing": elided,
             "timed_schedule_indices": [sched_index(i, args.steps) for i in range(min(args.steps, nsched))],
         }

@@ -23,8 +23,53 @@ def init_distributed(backend=None):
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        import datetime
+        # a finite rendezvous / collective timeout: a mis-set IPC mode shows up as an error after minutes, not as a hang until the
+        # driver's own limit (RTDIFF_DIST_TIMEOUT_S overrides)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=int(os.environ.get("RTDIFF_DIST_TIMEOUT_S", "300"))))
     return rank, local_rank, world
+
+
+def collective_self_check(nbytes=64 << 20, device=None):
+    """Runs at the top of every N > 1 launch (bench.py --gpus N, sample.py --gpus N), BEFORE the 5 GB arena moves: rank 0 broadcasts a
+    position-dependent 64 MB pattern on the launch's real backend (RCCL on GPUs), every rank verifies every byte, the verdicts are
+    all-reduced, and rank 0 gets a record for the JSON line (backend, RCCL version, the IPC / debug environment, broadcast seconds).
+    The 2-rank RCCL path had never executed on hardware when this was written (1-GPU leases in every round): the first 8-GPU run must
+    fail LOUDLY - with the environment that matters in the message - instead of hanging or sampling from a half-received arena."""
+    import time
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return {"world": 1, "ok": True}
+    rank, world, backend = dist.get_rank(), dist.get_world_size(), dist.get_backend()
+    dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu"))
+    n = max(8, nbytes // 8)
+    idx = torch.arange(n, dtype=torch.int64, device=dev)
+    pattern = (idx * 2654435761 + 12345) ^ (idx >> 7)                       # position-dependent: a shifted or truncated payload cannot pass
+    buf = pattern.clone() if rank == 0 else torch.zeros(n, dtype=torch.int64, device=dev)
+    env = {k: os.environ.get(k) for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG", "NCCL_P2P_DISABLE", "RCCL_MSCCL_ENABLE", "HIP_VISIBLE_DEVICES")}
+    t0 = time.perf_counter()
+    try:
+        dist.broadcast(buf, src=0)
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+    except Exception as e:                                                  # noqa: BLE001 - re-raised with the context a 3 a.m. reader needs
+        raise RuntimeError(f"collective self-check: broadcast of {n * 8} bytes failed on rank {rank}/{world} (backend {backend}, env {env}): {e}") from e
+    dt = time.perf_counter() - t0
+    ok_local = bool(torch.equal(buf, pattern))
+    flag = torch.tensor([1 if ok_local else 0], dtype=torch.int64, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    ok = bool(flag.item() == 1)
+    ver = None
+    if backend == "nccl":
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:                                                   # noqa: BLE001
+            ver = "unknown"
+    rec = {"world": world, "backend": backend, "rccl_version": ver, "bytes": n * 8, "broadcast_s": dt, "ok": ok, "env": env}
+    if not ok:
+        raise RuntimeError(f"collective self-check: rank {rank}/{world} {'received a WRONG payload' if not ok_local else 'is fine but another rank is not'} "
+                           f"({rec}); for RCCL on this host driver HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC) is required")
+    return rec
 
 
 def free_port():
@@ -245,6 +290,25 @@ def split_region_step(engine, i, guidance_scale, inject_selfattn, inject_backgro
     _cuda_sync()
     engine.region_step_finish(i, guidance_scale, inject_selfattn, inject_background, xl, elide=elide, defer_blend=defer_blend)
     return ranges
+
+
+def guidance_from_rank0(engine, fn, h, w):
+    """--split_image: the colour-guidance VAE pass (82 ms at SDXL) changes ONLY the latents; rank 0 runs `fn()` and the others receive
+    the updated latents (64 KB at SDXL) instead of repeating the decoder forward + backward on every rank."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        fn()
+        return
+    if dist.get_rank() == 0:
+        fn()
+    engine.synchronize()
+    _cuda_sync()
+    if hasattr(engine, "latents_as_tensor"):                       # (CPU stand-ins of tests/test_distributed_cpu.py)
+        lat = engine.latents_as_tensor()
+    else:
+        lat_ptr, _ = engine.state_ptrs()
+        lat = torch.as_tensor(_DevicePointer(lat_ptr, 4 * h * w * 4), device=f"cuda:{engine.device}")     # latents [4, h, w] fp32
+    broadcast_tensor(lat.view(-1).view(torch.uint8), src=0)
+    _cuda_sync()                                                   # same ordering contract as split_region_step
 
 
 def assert_ranks_agree(tensor, what="state", every_rank_raises=True):

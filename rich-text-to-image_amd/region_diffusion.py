@@ -102,8 +102,15 @@ class RegionDiffusion:
             if use_guidance:
                 if t < tfd['guidance_start_step']:                           # rd.py:151
                     lat_ptr, eps_ptr = eng.state_ptrs()
-                    self.vae.color_guidance(lat_ptr, eps_ptr, float(self.scheduler.alphas_cumprod[int(t)]), h, w, tfd['color_obj_atten'],
-                                            tfd['target_RGB'], tfd['color_guidance_weight'], tfd['color_obj_atten_all'])
+
+                    def guide(lat_ptr=lat_ptr, eps_ptr=eps_ptr, t=t):
+                        self.vae.color_guidance(lat_ptr, eps_ptr, float(self.scheduler.alphas_cumprod[int(t)]), h, w, tfd['color_obj_atten'],
+                                                tfd['target_RGB'], tfd['color_guidance_weight'], tfd['color_obj_atten_all'])
+                    if getattr(self, "split_image", False):              # rank 0 runs the VAE pass, the others receive the updated latents
+                        from .launcher import guidance_from_rank0
+                        guidance_from_rank0(eng, guide, h, w)
+                    else:
+                        guide()
                 eng.background_blend()
         return eng.read_latents(h, w)
 

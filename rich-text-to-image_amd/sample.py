@@ -153,6 +153,11 @@ def build_model(a, rank=0, local_rank=0, world=1):
     return model, seconds
 
 
+def dist_backend_is_gloo():
+    import torch.distributed as dist
+    return dist.is_initialized() and dist.get_backend() == "gloo"
+
+
 def main(argv=None):
     """Flags of sample.py:118-133 (+ --load_path), and the seed-parallel form the reference does not have (BASELINE
     configs 4 / 5): `--gpus N` with several requests (`--rich_text_json A B ...`, `--seeds ...`, `--requests FILE`) re-executes itself
@@ -196,6 +201,11 @@ def main(argv=None):
         raise SystemExit(f"sample: {err}")
     # RTDIFF_DIST_BACKEND / RTDIFF_FORCE_DEVICE: tests that run two ranks on ONE GPU over gloo (RCCL cannot put two ranks on a device)
     rank, local_rank, world = launcher.init_distributed("gloo" if a.dry_launch else os.environ.get("RTDIFF_DIST_BACKEND"))
+    if world > 1:                     # prove the collective path before the pipeline's weights move (launcher.collective_self_check)
+        chk = launcher.collective_self_check(nbytes=(1 << 20) if a.dry_launch else (64 << 20),
+                                             device=torch.device("cpu") if (a.dry_launch or dist_backend_is_gloo()) else None)
+        if rank == 0:
+            print(f"sample: collective self-check {chk}", file=sys.stderr, flush=True)
     if "RTDIFF_FORCE_DEVICE" in os.environ:
         local_rank = int(os.environ["RTDIFF_FORCE_DEVICE"])
     if world != max(1, a.gpus) and "WORLD_SIZE" in os.environ:

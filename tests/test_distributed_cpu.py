@@ -162,3 +162,56 @@ def test_intra_image_split_keeps_injecting_streams_with_their_source():
             elif nparts > 1:
                 assert max(c for _, c in r) - min(c for _, c in r) <= 1
     assert split_ranges(7, 3, True, 2) == [(0, 3), (3, 4)]            # config 3: {uncond, base, uncond_ref} | {text_ref, 3 regions}
+
+
+def _worker_round6(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from rich_text_to_image_amd import launcher
+    launcher.init_distributed("gloo")
+    rec = launcher.collective_self_check(nbytes=1 << 20)
+
+    class StandIn:                                                 # what guidance_from_rank0 needs of an engine
+        device = 0
+
+        def __init__(self):
+            self.lat = torch.full((4, 8, 8), float(rank))
+
+        def synchronize(self):
+            pass
+
+        def latents_as_tensor(self):
+            return self.lat
+    eng = StandIn()
+    calls = []
+
+    def guide():
+        calls.append(rank)
+        eng.lat += 41.5                                            # the "VAE pass" changes the latents on the rank that runs it
+    launcher.guidance_from_rank0(eng, guide, 8, 8)
+    agree = launcher.assert_ranks_agree(eng.lat, "latents", every_rank_raises=False)
+    disagree = launcher.assert_ranks_agree(torch.full((5,), float(rank)), "a rank-dependent tensor", every_rank_raises=False)
+    q.put((rank, rec, calls, float(eng.lat[0, 0, 0]), agree, disagree))
+    torch.distributed.destroy_process_group()
+
+
+def test_collective_self_check_and_split_mode_guidance_handoff_world2_gloo():
+    """Round 6: every N > 1 launch starts with a pattern broadcast that every rank verifies (here over gloo); in
+    --split_image mode the colour-guidance pass runs on rank 0 only and the others receive the latents; the rank-agreement digest
+    tells identical from diverging state."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    from rich_text_to_image_amd import launcher
+    port = launcher.free_port()
+    procs = [ctx.Process(target=_worker_round6, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, rec, calls, lat00, agree, disagree in res:
+        assert rec["ok"] and rec["world"] == 2 and rec["backend"] == "gloo" and rec["bytes"] == 1 << 20
+        assert calls == ([0] if rank == 0 else [])                 # the guidance pass ran on rank 0 only ...
+        assert lat00 == 41.5                                       # ... and every rank holds ITS result (rank 1 started from 1.0)
+        assert agree is True and disagree is False
