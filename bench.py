@@ -267,16 +267,18 @@ def cross_attention_block(dev, F=7):
             ms3 = timed()
         finally:
             lib.rt_op_gemm_debug(flags)
-        lib.rt_op_gemm_debug(flags | 524288)          # round 4's form: to_q + attention fused (gemm16 EPI_XATTN) where the tiling allowed it
-        try:
-            ms4 = timed()
-        finally:
-            lib.rt_op_gemm_debug(flags)
+        probes = bool(lib.rt_op_probes_built())       # the fused / one-launch forms exist in `make PROBES=1` builds only (round 6)
         flops = F * (4.0 * N * Cc * H * DP + 4.0 * H * N * 77 * 64)
         out[name] = dict(ms=ms, tflops=flops / (ms * 1e-3) / 1e12, frac=flops / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
-                         three_launch_ms=ms3, three_launch_frac=flops / (ms3 * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
-                         round4_form_ms=ms4, round4_form_frac=flops / (ms4 * 1e-3) / 1e12 / PEAK_BF16_TFLOPS)
-        if Cc == 640:                                 # the one-launch register-chained form (xblock.hip; opt-in, NOT the engine's path: slower)
+                         three_launch_ms=ms3, three_launch_frac=flops / (ms3 * 1e-3) / 1e12 / PEAK_BF16_TFLOPS)
+        if probes:
+            lib.rt_op_gemm_debug(flags | 524288)      # round 4's form: to_q + attention fused (gemm16 EPI_XATTN) where the tiling allowed it
+            try:
+                ms4 = timed()
+            finally:
+                lib.rt_op_gemm_debug(flags)
+            out[name].update(round4_form_ms=ms4, round4_form_frac=flops / (ms4 * 1e-3) / 1e12 / PEAK_BF16_TFLOPS)
+        if probes and Cc == 640:                                 # the one-launch register-chained form (xblock.hip; opt-in, NOT the engine's path: slower)
             lib.rt_op_gemm_debug(flags | 65536)
             try:
                 ms1 = timed()
@@ -284,11 +286,12 @@ def cross_attention_block(dev, F=7):
                 lib.rt_op_gemm_debug(flags)
             out[name].update(one_launch_xblock_ms=ms1, one_launch_xblock_frac=flops / (ms1 * 1e-3) / 1e12 / PEAK_BF16_TFLOPS)
     out["note"] = ("rt_op_cross_attn_block: to_q + attention(77 keys, cached K/V, font-size softmax) + to_out(+bias, + fp16 trunk residual) "
-                   "for the 7 streams of a step, exactly the launches the engine issues - round 5: to_q GEMM, cross77_kernel (xblock.hip: the 77-key "
-                   "attention with K / V^T in LDS, 64 queries x 2 heads per workgroup), to_out GEMM; round4_form_* = to_q and the attention as one "
-                   "kernel where the tiling allowed it (gemm16.hip EPI_XATTN, shape B); one_launch_xblock_* (shape A) = the whole "
-                   "block as ONE launch with Q / P / O in registers (xblock.hip, round 5): built, parity-tested, slower, not the engine's path; "
-                   "three_launch_* = to_q GEMM, the generic attn_kernel<CROSS>, to_out GEMM (round 3); executed FLOPs")
+                   "for the 7 streams of a step on a LayerNorm'd bf16 input, as three launches: to_q GEMM, cross77_kernel (cross77.hip: the 77-key "
+                   "attention with K / V^T of one head in LDS, 64 or 128 queries per workgroup), to_out GEMM (in the engine the first and the "
+                   "last additionally carry the folded LayerNorm / its partial sums, round 6); three_launch_* = to_q GEMM, the generic "
+                   "attn_kernel<CROSS>, to_out GEMM (round 3); `make PROBES=1` builds add round4_form_* (to_q + attention as one kernel, "
+                   "gemm16.hip EPI_XATTN) and one_launch_xblock_* (the whole block as one launch, xblock.hip): built, parity-tested, slower; "
+                   "executed FLOPs")
     return out
 
 

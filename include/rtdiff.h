@@ -251,6 +251,8 @@ const char* rt_op_last_error(void);
 /* GEMM tile choice: -1 (default) = a pure function of the problem shape (csrc/gemm16.hip: 16x16x32-MFMA family, 224-row tiles;
  * csrc/gemm.hip: 32x32x16 family for everything else) - no timing, no per-process state; 0..8 = force one tile configuration of
  * gemm.hip (tests / micro-benchmarks; all of them give bit-identical results). */
+int rt_op_probes_built(void);      /* 1: the library was built with `make PROBES=1` and contains the measured-and-rejected kernels (xblock_kernel,
+                                    * EPI_XATTN, gemm16 variant 13) that rt_op_gemm_debug bits 16 / 4 and variant 13 select; 0: the shipped build */
 int rt_op_gemm_force_config(int cfg);
 /* A/B switches (benchmarks; the engine wrapper reads RTDIFF_DEBUG_FLAGS once at load): bit 0 patch-eligible 3x3 convs through the
  * implicit-GEMM kernels; bit 1 keep gemm16.hip out; bit 2 no split-K; bit 3 stride-1 3x3 convs stay on the patch kernel (not on the

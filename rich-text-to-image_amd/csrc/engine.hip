@@ -1311,6 +1311,13 @@ extern int g_store_legacy;
 extern int g_store_apply_v1;
 extern int g_c77_t1;
 int rt_op_gemm_debug(int d) { gemm_set_debug(d); g_store_own_stats = (d >> 17) & 1; g_store_apply_v1 = (d >> 18) & 1; g_c77_t1 = (d >> 20) & 3; g_store_legacy = ((d & 32) ? 1 : 0) | ((d & 64) ? 2 : 0); attention_set_prio(((d >> 14) & 1) ^ 1); return RT_OK; }
+int rt_op_probes_built(void) {
+#ifdef RT_PROBES
+    return 1;
+#else
+    return 0;
+#endif
+}
 int rt_op_gemm_force_config(int cfg) {
     if (cfg < -1 || cfg > 8) return RT_E_INVALID;
     gemm_force_config(cfg);

@@ -442,7 +442,9 @@ static void launch_e(const GemmArgs& a, int v, int wstat, hipStream_t st) {
                 case 10: launch_v<MODE, EPI, 4, 5, 2, 4, 1, 2>(a, wstat, st); return;
                 case 11: launch_v<MODE, EPI, 2, 5, 2, 4, 1, 3>(a, wstat, st); return;
                 case 12: launch_v<MODE, EPI, 5, 2, 2, 2, 2, 3>(a, wstat, st); return;
-                case 13: launch_v<MODE, EPI, 4, 5, 2, 2, 1, 2>(a, wstat, st); return;
+#ifdef RT_PROBES
+                case 13: launch_v<MODE, EPI, 4, 5, 2, 2, 1, 2>(a, wstat, st); return;      // (probe: two co-resident four-wave workgroups, LABNOTES R5.6b)
+#endif
                 default: break;
             }
         }
@@ -450,6 +452,7 @@ static void launch_e(const GemmArgs& a, int v, int wstat, hipStream_t st) {
     throw rt_error(RT_E_INVALID, "gemm16: variant cannot run this operand mode / epilogue");
 }
 
+#ifdef RT_PROBES
 bool xattn_fused_supported(int C, int H, int DP, int tokens) {
     if (!(DP == 64 && (H * 64) % 320 == 0 && tokens > 0 && tokens % 128 == 0 && C % BK16 == 0 && C >= 3 * BK16)) return false;
     // ... and only where the 128 x 320 tiles of a step's streams stay within one round of the chip: one stream may contribute at
@@ -472,6 +475,12 @@ void launch_xattn_fused(const GemmArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(cdiv(a.M, 128) * (a.N / 320)), dim3(512), XA_LDS, st, a, 0);
     HIP_CHECK(hipGetLastError());
 }
+#else      // the shipped library: the fused to_q + attention launch (measured neutral, LABNOTES R4.1) is a probe-build kernel
+bool xattn_fused_supported(int, int, int, int) { return false; }
+void launch_xattn_fused(const GemmArgs&, hipStream_t) { throw rt_error(RT_E_UNSUPPORTED, "EPI_XATTN is built with `make PROBES=1` only"); }
+bool xblock_supported(int, int, int, int) { return false; }
+void launch_xblock(const XBlockArgs&, hipStream_t) { throw rt_error(RT_E_UNSUPPORTED, "xblock_kernel is built with `make PROBES=1` only"); }
+#endif
 
 static bool conv16_geometry(const GemmArgs& a) {
     return a.mode == A_CONV3 && a.Hin == a.Hout && a.Win == a.Wout && a.Cin % BK16 == 0 && a.K == 9 * a.Cin && a.rows_per_batch == a.Hout * a.Wout &&

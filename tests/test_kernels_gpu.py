@@ -504,7 +504,7 @@ def test_cross_attention_fontsize(use_fs):
 
 @pytest.mark.parametrize("B,H,N", [(3, 4, 256), (7, 20, 1024), (2, 10, 4096), (2, 5, 320)])
 def test_cross77_kernel_against_reference_arithmetic_and_the_generic_kernel(B, H, N):
-    """cross77_kernel (csrc/xblock.hip: what the engine runs for attn2 at d = 64 - 64 queries x 2 heads per workgroup, K / V^T of the
+    """cross77_kernel (csrc/cross77.hip: what the engine runs for attn2 at d = 64 - 64 queries x 2 heads per workgroup, K / V^T of the
     cached 77 keys in LDS, key mask and |font size| as an additive log2 bias on the scores) through rt_op_attention: against the
     reference processor's arithmetic in fp32 (attention_processor.py:476-545, font-size softmax :386-401) with a NEGATIVE size, a ZERO
     size, the last valid key (76) and junk in the padded V rows, streams mixing prompts and plain / font-size softmax - and against
@@ -694,7 +694,10 @@ def test_cross_attn_block_fused_kernel_against_reference_arithmetic(B, N, Cc, H)
         return out.float().cpu(), o.float().cpu(), q
     # shapes of the 640-channel level can take xblock.hip (the whole block in ONE launch: neither Q nor O reaches HBM) - opt-in through
     # debug bit 16, because it measured slower than the separate launches (LABNOTES R5.2); its arithmetic stays pinned here
-    is_xblock = Cc == 640 and H == 10 and N % 128 == 0
+    # (both probe kernels live in `make PROBES=1` builds only since round 6: rt_op_probes_built(); the shipped library runs the engine's form
+    #  and the generic three launches)
+    probes = bool(lib.rt_op_probes_built())
+    is_xblock = probes and Cc == 640 and H == 10 and N % 128 == 0
     if is_xblock:
         lib.rt_op_gemm_debug(65536)
         try:
@@ -706,12 +709,14 @@ def test_cross_attn_block_fused_kernel_against_reference_arithmetic(B, N, Cc, H)
     engine_form, o_engine, q_engine = run()
     if N % 64 == 0:                                                        # cross77's shapes (d = 64, whole 64-query blocks)
         assert float(q_engine.float().abs().max()) > 0.0
-    lib.rt_op_gemm_debug(524288)                                           # bit 19: round 4's forms - EPI_XATTN where the tiling allows it
-    try:
-        fused, o_fused, q_fused = run()
-    finally:
-        lib.rt_op_gemm_debug(0)
-    assert float(q_fused.float().abs().max()) == 0.0, "the fused path must not write Q to HBM"
+    fused = o_fused = None
+    if probes:
+        lib.rt_op_gemm_debug(524288)                                       # bit 19: round 4's forms - EPI_XATTN where the tiling allows it
+        try:
+            fused, o_fused, q_fused = run()
+        finally:
+            lib.rt_op_gemm_debug(0)
+        assert float(q_fused.float().abs().max()) == 0.0, "the fused path must not write Q to HBM"
     lib.rt_op_gemm_debug(16 | 524288)                                      # to_q GEMM -> attn_kernel<CROSS> -> to_out GEMM
     try:
         three, o_three, q_three = run()
@@ -724,11 +729,14 @@ def test_cross_attn_block_fused_kernel_against_reference_arithmetic(B, N, Cc, H)
     ref_o = torch.empty(B, N, H * d)
     for b in range(B):
         ref_o[b], _ = _ref_attention(xq.reshape(B, N, -1)[b:b + 1], kr[prompt[b]][None], vr[prompt[b]][None], H, (wp, fs) if wset[b] >= 0 else None)
-    report(f"fused attention output O B{B} N{N} C{Cc}", o_fused, ref_o.reshape(B * N, -1), atol=2e-2, rtol=2e-2)
     ref = ref_o.reshape(B * N, -1).to(torch.bfloat16).float() @ wo.float().cpu().t() + bo.cpu() + trunk.float().cpu()
-    report(f"rt_op_cross_attn_block fused B{B} N{N} C{Cc}", fused, ref, atol=3e-2, rtol=2e-2)
-    report("fused vs three-launch form", fused, three, atol=3e-2, rtol=2e-2)
-    report("fused O vs three-launch O", o_fused, o_three, atol=2e-2, rtol=2e-2)
+    if probes:
+        report(f"fused attention output O B{B} N{N} C{Cc}", o_fused, ref_o.reshape(B * N, -1), atol=2e-2, rtol=2e-2)
+        report(f"rt_op_cross_attn_block fused B{B} N{N} C{Cc}", fused, ref, atol=3e-2, rtol=2e-2)
+        report("fused vs three-launch form", fused, three, atol=3e-2, rtol=2e-2)
+        report("fused O vs three-launch O", o_fused, o_three, atol=2e-2, rtol=2e-2)
+    report(f"three-launch form O B{B} N{N} C{Cc}", o_three, ref_o.reshape(B * N, -1), atol=2e-2, rtol=2e-2)
+    report("engine form vs three-launch form", engine_form, three, atol=3e-2, rtol=2e-2)
     report(f"engine form (to_q -> cross77 -> to_out) O B{B} N{N} C{Cc}", o_engine, ref_o.reshape(B * N, -1), atol=2e-2, rtol=2e-2)
     report(f"rt_op_cross_attn_block engine form B{B} N{N} C{Cc}", engine_form, ref, atol=3e-2, rtol=2e-2)
     if is_xblock:

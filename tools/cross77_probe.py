@@ -1,4 +1,4 @@
-"""cross77_kernel (csrc/xblock.hip) against attn_kernel<CROSS> (debug bit 19) through rt_op_attention at the two SDXL shapes - GPU box."""
+"""cross77_kernel (csrc/cross77.hip) against attn_kernel<CROSS> (debug bit 19) through rt_op_attention at the two SDXL shapes - GPU box."""
 import ctypes as C
 import os
 import sys
