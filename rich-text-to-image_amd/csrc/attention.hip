@@ -22,6 +22,11 @@
 // measured and is slower here: 376-423 vs 700 TFLOP/s).  Built with -amdgpu-mfma-vgpr-form (Makefile).
 #include "common.h"
 #include <math.h>
+#include <type_traits>
+#include <utility>
+
+template <int... Is, class F>
+static __device__ __forceinline__ void att_unroll(std::integer_sequence<int, Is...>, F& f) { (f(std::integral_constant<int, Is>{}), ...); }
 
 #ifdef RT_ATTN_TIMING
 __device__ long long g_attn_times[4 * 8];
@@ -39,12 +44,18 @@ __device__ long long g_attn_times[4 * 8];
 // s - m and the 32 v_sub per tile and wave disappear from the VALU stream that bounds this kernel (LABNOTES 4.3).  m is kept
 // bf16-representable (softmax is invariant to the reference; it only has to stay within 2^8 of the true running maximum), so the
 // product 1 * (-m) is exact.
-template <int DP, int KT, bool CROSS, bool RAGGED = false, int NW = 4, bool FOLD = !CROSS, int PRIO = 0>
-__global__ __launch_bounds__(NW * 64, (CROSS && DP <= 64) ? 3 : 1) void attn_kernel(AttnArgs p) {
+// G > 1 (round 6, self-attention of an INJECTED step): the streams of a unit attend with the SAME (Q, K) - text_ref and the region streams
+// that take its probabilities (attention_processor.py:522-524: the reference does not recompute softmax(QK^T) for them either) - and differ
+// in V only.  The workgroup computes S^T and P^T ONCE per key tile and runs O_g^T += V_g^T P^T for every member g < G: per member the
+// same MFMA sequence on the same operands as the one-stream kernel, i.e. bit-identical outputs, for 1 / G of the softmax VALU work (which
+// bounds this kernel) and (1 + G) / 2 G of the MFMAs.  The V^T tiles of the members sit behind the K tile in each stage.
+template <int DP, int KT, bool CROSS, bool RAGGED, int NW, bool FOLD, int PRIO, int G>
+static __device__ __forceinline__ void attn_tile(const AttnArgs& p, const int b, const int h, const int q0) {
+    static_assert(G == 1 || (!CROSS && !RAGGED && NW == 4), "shared-probability units: plain self-attention");
     constexpr int NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE = KT * DP * 2;          // bytes of one K (or V^T) tile
-    constexpr int STAGE = 2 * TILE;
+    constexpr int STAGE = (1 + G) * TILE;
     constexpr int NCH = KT * DP / 8;           // 16-B chunks per tile
     constexpr int NJ = KT / 32;                // key sub-tiles
     constexpr int ND = DP / 32;                // d sub-tiles
@@ -56,21 +67,14 @@ __global__ __launch_bounds__(NW * 64, (CROSS && DP <= 64) ? 3 : 1) void attn_ker
         else if (wave == 2) __builtin_amdgcn_s_setprio(2);
         else if (wave == 3) __builtin_amdgcn_s_setprio(3);
     }
-    // XCD-aware work mapping.  Workgroups are dealt to the 8 XCDs round-robin by linear id; the query blocks of one (batch entry,
-    // head) all stream the same K / V^T, so they must share an L2: give every XCD a contiguous run of the (h, b, query block)
-    // space, query block fastest (bijective for any grid size).  Before this the 8 query blocks of a 1024-token head sat on 8
-    // different XCDs and every XCD fetched every head's K/V: 4.2x the algorithmic HBM traffic (profiles/r1_pmc_traffic.json).
-    int b, h, q0;
-    {
-        const int nwg = gridDim.x;
-        int bid = blockIdx.x;
-        const int qq = nwg >> 3, rr = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
-        const int qb = bid % p.nqb; bid /= p.nqb;          // order (head, batch entry, query block): streams that attend with the
-        b = bid % p.B; h = bid / p.B;                          // same Q/K source (injection) are neighbours and share K in L2 too
-        q0 = qb * (32 * NW);
-    }
-    const int qb = p.q_src[b], kb = p.k_src[b], vb = p.v_src[b];
+    const int qb = p.q_src[b], kb = p.k_src[b];
+    // members of the unit: V^T source and output batch entry of member g (one-stream launches: the unit IS batch entry b)
+    // (the member count is the template parameter, not a run-time bound: behind a run-time `g < ng` every member's two V^T fragment reads,
+    //  their wait and their two MFMAs became a basic block of their own - the LDS latency of every pair exposed, the shared kernel no faster
+    //  than four one-stream passes; profiles/r6_attn_units_bench_v1.txt)
+    int vb[G], ob[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) { vb[g] = p.gvs[b][g]; ob[g] = p.gob[b][g]; }
 
     float* wl = (float*)(smem + 2 * STAGE);    // cross: [2][KT] multipliers
     // wset[b] < 0: plain softmax over the nk_valid keys - no multiplier tables (6 of the 7 streams of a rich-text step); the 48
@@ -93,7 +97,9 @@ __global__ __launch_bounds__(NW * 64, (CROSS && DP <= 64) ? 3 : 1) void attn_ker
     for (int ks = 0; ks < DP / 16; ++ks) qf[ks] = *(const bf16x8*)(qptr + ks * 16);
 
     const bf16_t* kbase = p.K + (size_t)kb * p.NK * p.ldk + h * DP;
-    const bf16_t* vbase = p.VT + (size_t)h * DP * p.ldvt + (size_t)vb * p.NK;
+    const bf16_t* vbase[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) vbase[g] = p.VT + (size_t)h * DP * p.ldvt + (size_t)vb[g] * p.NK;
 
     auto stage = [&](int s, int key0) {
         char* ks_ = smem + s * STAGE;
@@ -113,17 +119,20 @@ __global__ __launch_bounds__(NW * 64, (CROSS && DP <= 64) ? 3 : 1) void attn_ker
                     const int sub = rl / DP, row = rl - sub * DP;
                     const int ls = ps ^ ((row >> 2) & 3);
                     int kc = key0 + sub * 32 + ls * 8; if (RAGGED && kc > p.NK - 8) kc = p.NK - 8;
-                    glds16(vbase + (size_t)row * p.ldvt + kc, vs_ + (c0 + wave * 64) * 16);
+#pragma unroll
+                    for (int g = 0; g < G; ++g) glds16(vbase[g] + (size_t)row * p.ldvt + kc, vs_ + g * TILE + (c0 + wave * 64) * 16);
                 }
             }
         }
     };
 
-    f32x16 o[ND];
+    f32x16 o[G][ND];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
 #pragma unroll
     for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+        for (int r = 0; r < 16; ++r) o[g][dt][r] = 0.f;
     float m = FOLD ? 0.f : -1e30f, l = 0.f;
     bf16x8 ka, qm;                                                  // FOLD: the constant key-side fragment and the query-side (-m) fragment
 #pragma unroll
@@ -201,9 +210,11 @@ __global__ __launch_bounds__(NW * 64, (CROSS && DP <= 64) ? 3 : 1) void attn_ker
                     const float alpha = __builtin_amdgcn_exp2f(-delta);
                     l *= alpha;
 #pragma unroll
+                    for (int g = 0; g < G; ++g)
+#pragma unroll
                     for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+                        for (int r = 0; r < 16; ++r) o[g][dt][r] *= alpha;
                 }
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
@@ -215,9 +226,11 @@ __global__ __launch_bounds__(NW * 64, (CROSS && DP <= 64) ? 3 : 1) void attn_ker
             m = mx;
             l *= alpha;
 #pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
             for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[g][dt][r] *= alpha;
         }
         float rs = 0.f;
         if (CROSS && !plain) {                                       // font-size stream: e_k = exp(s_k - max) |fs_k|, p_k = sign(fs_k) e_k / sum e
@@ -246,19 +259,58 @@ __global__ __launch_bounds__(NW * 64, (CROSS && DP <= 64) ? 3 : 1) void attn_ker
         // ---- O^T += V^T P^T
         if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(2);
         if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(0);
+        if constexpr (G == 1) {
 #pragma unroll
-        for (int kk = 0; kk < KT / 16; ++kk) {
-            const int j = kk >> 1, hh = kk & 1;
-            bf16x8 pf;
+            for (int kk = 0; kk < KT / 16; ++kk) {
+                const int j = kk >> 1, hh = kk & 1;
+                bf16x8 pf;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) pf[e] = (__bf16)s[j][8 * hh + e];
+                for (int e = 0; e < 8; ++e) pf[e] = (__bf16)s[j][8 * hh + e];
 #pragma unroll
-            for (int dt = 0; dt < ND; ++dt) {
-                const int row = dt * 32 + l31;
-                const int key = (row >> 2) & 3;
-                const bf16x8 vf = *(const bf16x8*)(vs_ + (j * DP + row) * 64 + (((2 * hh + hi) ^ key) << 4));
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+                for (int dt = 0; dt < ND; ++dt) {
+                    const int row = dt * 32 + l31;
+                    const int key = (row >> 2) & 3;
+                    const bf16x8 vf = *(const bf16x8*)(vs_ + (j * DP + row) * 64 + (((2 * hh + hi) ^ key) << 4));
+                    o[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[0][dt], 0, 0, 0);
+                }
             }
+        } else {
+            // (16-key chunk kk, member g) steps in kk-major order; the two V^T fragments of step i + 1 are requested in front of step i's MFMAs.
+            // Inline asm for the reads and their counted waits: as compiler-visible loads hipcc sinks every pair of reads to its two MFMAs
+            // (one fragment set, s_waitcnt lgkmcnt(0) in front of every pair - the LDS latency of all 16 steps of a key tile exposed) whatever
+            // the source order or the scheduling barriers say.  The waits name the fragments as in / out operands, which ties the MFMAs to them.
+            static_assert(ND == 2 && DP == 64 && KT == 64, "shared-probability units: d = 64, 64-key tiles");
+            constexpr int NP = (KT / 16) * G;
+            const int vkey = (l31 >> 2) & 3;
+            const unsigned vs_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)vs_;
+            const unsigned va0 = vs_lds + l31 * 64 + ((hi ^ vkey) << 4), va1 = vs_lds + l31 * 64 + (((2 + hi) ^ vkey) << 4);
+            bf16x8 vfb[2][ND];
+#define ATT_LDV(I_, DST_)                                                                                                      \
+            {                                                                                                                  \
+                constexpr int kk_ = (I_) / G, g_ = (I_) - kk_ * G, j_ = kk_ >> 1, hh_ = kk_ & 1;                               \
+                asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"                                  \
+                             : "=&v"(DST_[0]), "=&v"(DST_[1]) : "v"(hh_ ? va1 : va0), "n"(g_ * TILE + j_ * DP * 64), "n"(g_ * TILE + j_ * DP * 64 + 2048)); \
+            }
+            ATT_LDV(0, vfb[0])
+            bf16x8 pf;
+            auto step = [&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int kk = i / G, g = i - kk * G, j = kk >> 1, hh = kk & 1;
+                if constexpr (i + 1 < NP) {
+                    ATT_LDV(i + 1, vfb[(i + 1) & 1])
+                    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(vfb[i & 1][0]), "+v"(vfb[i & 1][1]));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vfb[i & 1][0]), "+v"(vfb[i & 1][1]));
+                }
+                if constexpr (g == 0) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pf[e] = (__bf16)s[j][8 * hh + e];
+                }
+#pragma unroll
+                for (int dt = 0; dt < ND; ++dt) o[g][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfb[i & 1][dt], pf, o[g][dt], 0, 0, 0);
+            };
+            att_unroll(std::make_integer_sequence<int, NP>{}, step);
+#undef ATT_LDV
         }
         if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0);
         AT_T(3)
@@ -275,7 +327,7 @@ __global__ __launch_bounds__(NW * 64, (CROSS && DP <= 64) ? 3 : 1) void attn_ker
     const float inv = 1.f / l;
     if constexpr (!CROSS) {
         // token-map capture (plain pass): P(q, k) = exp2(s - m) / l for every key of this head - the deferred rescale keeps m and l consistent
-        if (p.stats != nullptr && b == p.stats_b && hi == 0 && q < p.N)
+        if (p.stats != nullptr && ob[0] == p.stats_b && hi == 0 && q < p.N)
             ((float2*)p.stats)[(size_t)h * p.N + q] = make_float2(m, inv / (float)p.H);
     }
     // Epilogue through LDS: in the accumulator layout a lane owns ONE query row and 4-element runs of d, so direct stores touch
@@ -286,47 +338,79 @@ __global__ __launch_bounds__(NW * 64, (CROSS && DP <= 64) ? 3 : 1) void attn_ker
         constexpr int CPR = DP * 2 / 16;                          // 16-B chunks per row
         char* slab = smem + wave * 32 * RS;
 #pragma unroll
-        for (int dt = 0; dt < ND; ++dt)
+        for (int g = 0; g < G; ++g) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint2 v;
-                v.x = pack_bf16x2(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv);
-                v.y = pack_bf16x2(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
-                *(uint2*)(slab + l31 * RS + (dt * 32 + 8 * g + 4 * hi) * 2) = v;
+            for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) {
+                    uint2 v;
+                    v.x = pack_bf16x2(o[g][dt][4 * gg + 0] * inv, o[g][dt][4 * gg + 1] * inv);
+                    v.y = pack_bf16x2(o[g][dt][4 * gg + 2] * inv, o[g][dt][4 * gg + 3] * inv);
+                    *(uint2*)(slab + l31 * RS + (dt * 32 + 8 * gg + 4 * hi) * 2) = v;
+                }
+            // LDS operations of one wave execute in order: no barrier between the slab write and read (nor before the next member's write)
+#pragma unroll
+            for (int idx0 = 0; idx0 < 32 * CPR; idx0 += 64) {
+                const int idx = idx0 + lane;
+                const int r = idx / CPR, ch = idx - r * CPR;
+                const int qq = q0 + wave * 32 + r;
+                if (r < 32 && qq < p.N)
+                    *(uint4*)(p.O + ((size_t)ob[g] * p.N + qq) * p.ldo + h * DP + ch * 8) = *(const uint4*)(slab + r * RS + ch * 16);
             }
-        // LDS operations of one wave execute in order: no barrier between the slab write and read
-#pragma unroll
-        for (int idx0 = 0; idx0 < 32 * CPR; idx0 += 64) {
-            const int idx = idx0 + lane;
-            const int r = idx / CPR, ch = idx - r * CPR;
-            const int qq = q0 + wave * 32 + r;
-            if (r < 32 && qq < p.N)
-                *(uint4*)(p.O + ((size_t)b * p.N + qq) * p.ldo + h * DP + ch * 8) = *(const uint4*)(slab + r * RS + ch * 16);
         }
     }
+}
+
+// The kernel: G = 1 - the one-stream launches of rounds 1 - 5; G > 1 - a launch that mixes shared units of exactly G members (ng[b] == G)
+// with one-stream units (ng[b] == 1), so that the few heavy workgroups of the shared units run beside the light ones instead of leaving
+// CUs idle in a launch of their own (one unit of four at 1024 tokens x 20 heads is 160 workgroups for 256 CUs).  Registers and LDS are
+// those of the G-member body: 3 (G = 2) or 2 (G >= 3) workgroups per CU; the one-stream body measured the same at 3 and 8 - 10 % slower
+// at 2 (profiles/r6_attn_units_bench_v2.txt).
+// XCD-aware work mapping.  Workgroups are dealt to the 8 XCDs round-robin by linear id; the query blocks of one (batch entry,
+// head) all stream the same K / V^T, so they must share an L2: give every XCD a contiguous run of the (h, b, query block)
+// space, query block fastest (bijective for any grid size).  Before this the 8 query blocks of a 1024-token head sat on 8
+// different XCDs and every XCD fetched every head's K/V: 4.2x the algorithmic HBM traffic (profiles/r1_pmc_traffic.json).
+template <int DP, int KT, bool CROSS, bool RAGGED = false, int NW = 4, bool FOLD = !CROSS, int PRIO = 0, int G = 1>
+__global__ __launch_bounds__(NW * 64, G >= 3 ? 2 : (G == 2 || (CROSS && DP <= 64)) ? 3 : 1) void attn_kernel(AttnArgs p) {
+    int b, h, q0;
+    {
+        const int nwg = gridDim.x;
+        int bid = blockIdx.x;
+        const int qq = nwg >> 3, rr = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+        const int qb = bid % p.nqb; bid /= p.nqb;          // order (head, batch entry, query block): streams that attend with the
+        b = bid % p.B; h = bid / p.B;                          // same Q/K source (injection) are neighbours and share K in L2 too
+        q0 = qb * (32 * NW);
+    }
+    if constexpr (G == 1) attn_tile<DP, KT, CROSS, RAGGED, NW, FOLD, PRIO, 1>(p, b, h, q0);
+    else if (p.ng[b] == G) attn_tile<DP, KT, CROSS, RAGGED, NW, FOLD, PRIO, G>(p, b, h, q0);      // workgroup-uniform
+    else attn_tile<DP, KT, CROSS, RAGGED, NW, FOLD, PRIO, 1>(p, b, h, q0);
 }
 
 // s_setprio 2 in the MFMA phases / 0 in the softmax (PRIO = 1): 942 -> 950 TFLOP/s at 4096 tokens, 716 -> 732 at 1024 stand-alone, the
 // self-attention class of a step 13.19 -> 12.75 ms per two steps (profiles/r4_attn_probe_setprio.txt, r4_ab_attn_setprio.jsonl).  The
 // opposite assignment (softmax first) measured 915 / 699, a fixed priority per wave 800 / 568.  rt_op_gemm_debug bit 14 switches it off.
 int g_attn_prio = 1;
+extern int g_attn_units;
 void attention_set_prio(int on) { g_attn_prio = on ? 1 : 0; }
-template <int DP, int KT, bool CROSS, bool RAGGED, int NW, bool FOLD, int PRIO>
+template <int DP, int KT, bool CROSS, bool RAGGED, int NW, bool FOLD, int PRIO, int G = 1>
 static void launch_tp(const AttnArgs& a, hipStream_t st) {
     // K / V^T double buffer (+ the cross-attention multipliers); the epilogue reuses it as NW slabs of 32 x (DP*2 + 16) bytes
-    size_t lds = 4 * (size_t)KT * DP * 2 + (CROSS ? 2 * KT * sizeof(float) : 0);
+    size_t lds = 2 * (1 + G) * (size_t)KT * DP * 2 + (CROSS ? 2 * KT * sizeof(float) : 0);
     const size_t slabs = (size_t)NW * 32 * (DP * 2 + 16);
     if (slabs > lds) lds = slabs;
-    static bool attr = false;
-    if (!attr) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)attn_kernel<DP, KT, CROSS, RAGGED, NW, FOLD, PRIO>,
+    if (G == 1 && !CROSS && g_attn_units == 6) lds = 80 * 1024;      // (probe) the one-stream kernel at two workgroups per CU
+    if (G == 1 && !CROSS && g_attn_units == 7) lds = 48 * 1024;      // (probe) ... at three
+    static size_t attr = 0;
+    if (attr < lds) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)attn_kernel<DP, KT, CROSS, RAGGED, NW, FOLD, PRIO, G>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
+        attr = lds;
     }
     AttnArgs aa = a;
     aa.nqb = cdiv(a.N, 32 * NW);
     dim3 grid(aa.nqb * a.H * a.B), block(NW * 64);
-    hipLaunchKernelGGL((attn_kernel<DP, KT, CROSS, RAGGED, NW, FOLD, PRIO>), grid, block, lds, st, aa);
+    hipLaunchKernelGGL((attn_kernel<DP, KT, CROSS, RAGGED, NW, FOLD, PRIO, G>), grid, block, lds, st, aa);
     HIP_CHECK(hipGetLastError());
 }
 template <int DP, int KT, bool CROSS, bool RAGGED = false, int NW = 4, bool FOLD = !CROSS>
@@ -338,13 +422,64 @@ static void launch_t(const AttnArgs& a, hipStream_t st) {
     if (g_attn_prio) launch_tp<DP, KT, CROSS, RAGGED, NW, FOLD, 1>(a, st);
     else launch_tp<DP, KT, CROSS, RAGGED, NW, FOLD, 0>(a, st);
 }
-
-#ifdef RT_PROBE
-int g_attn_nw = 0;          // probe override: 4 or 8 waves per workgroup for the d = 64 self-attention kernel
-int g_attn_nofold = 0;      // probe override: the round-2 form (v_sub in the softmax) for A/B timing
-#endif
-
-void launch_attention(const AttnArgs& a, hipStream_t st) {
+// shared-probability units (attn_kernel, "G > 1"): d = 64 self-attention, whole key tiles
+template <int G>
+static void launch_units(const AttnArgs& a, hipStream_t st) {
+    if (g_attn_prio) launch_tp<64, 64, false, false, 4, true, 1, G>(a, st);
+    else launch_tp<64, 64, false, false, 4, true, 0, G>(a, st);
+}
+// Self-attention launches in which several batch entries attend with the same (Q, K) source - an injected rich-text step: text_ref and the
+// region streams, models/region_diffusion_sdxl.py:1018-1106 - are re-expressed as UNITS: the members of a source are dealt G at a time
+// into shared units (G = 4, or the size of the largest source group when that is 2 or 3), what is left over and every other entry is a
+// one-stream unit; ONE launch of the G-member kernel runs both kinds, the shared units first within every head.  Bit-identical per stream
+// with the one-stream launches (tests/test_kernels_gpu.py); the partition depends on the launch's own source indices only.
+//   mode 1: never (the launches of rounds 1 - 5);  2: as above;  3: shared units of two only;  4 / 5: as 2 / 3 with the one-stream units
+//   in a launch of their own (measured: profiles/r6_attn_units_bench_v2.txt).  rt_op_gemm_debug bits 24 - 26 (0 = default).
+int g_attn_units = 0;
+void attention_set_units(int mode) { g_attn_units = mode; }
+// Default (measured on the two SDXL levels of an injected config-3 step, profiles/r6_attn_units_bench_v3.txt: 7 x 1024 tokens x 20 heads
+// 54 -> 50 us with pairs in one launch, 54 / 57 with units of four; 7 x 4096 x 10 heads 314 -> 279 us with units of four + the one-stream
+// units in their own launch, 287 in one launch, 294 / 280 with pairs): short sequences take pairs beside the one-stream units - a unit of
+// four there is 160 heavy workgroups -, long ones units of four in their own launch.  A function of the launch's own shape.
+static bool launch_attention_units(const AttnArgs& a, hipStream_t st) {
+    const int mode = g_attn_units ? g_attn_units : (a.N >= 2048 ? 4 : 3);
+    if (mode <= 1 || mode >= 6 || a.cross || a.DP != 64 || a.NK % 64 != 0 || a.stats != nullptr) return false;
+    const bool split = mode >= 4;
+    // source groups in batch order
+    int grp[RT_MAXB][RT_MAXB], gn[RT_MAXB], ngrp = 0, largest = 0;
+    bool taken[RT_MAXB] = {};
+    for (int b = 0; b < a.B; ++b) {
+        if (taken[b]) continue;
+        int nm = 0;
+        for (int c = b; c < a.B; ++c)
+            if (!taken[c] && a.q_src[c] == a.q_src[b] && a.k_src[c] == a.k_src[b]) { grp[ngrp][nm++] = c; taken[c] = true; }
+        gn[ngrp++] = nm;
+        if (nm > largest) largest = nm;
+    }
+    if (largest < 2) return false;
+    const int G = (mode == 3 || mode == 5) ? 2 : (largest >= 4 ? 4 : largest);
+    AttnArgs u = a, s1 = a;
+    int nu = 0, n1 = 0;
+    auto put = [&](AttnArgs& d, int& k, int src, const int* mem, int n) {
+        d.q_src[k] = a.q_src[src]; d.k_src[k] = a.k_src[src]; d.ng[k] = (unsigned char)n;
+        for (int g = 0; g < 4; ++g) { const int c = mem[g < n ? g : 0]; d.gvs[k][g] = (unsigned char)a.v_src[c]; d.gob[k][g] = (unsigned char)c; }
+        ++k;
+    };
+    for (int i = 0; i < ngrp; ++i)                                   // the shared units: the heavy workgroups first
+        for (int i0 = 0; i0 + G <= gn[i]; i0 += G) put(u, nu, grp[i][0], &grp[i][i0], G);
+    for (int i = 0; i < ngrp; ++i)                                   // what is left of every group: one-stream units
+        for (int i0 = gn[i] - gn[i] % G; i0 < gn[i]; ++i0) put(split ? s1 : u, split ? n1 : nu, grp[i][0], &grp[i][i0], 1);
+    u.B = nu; s1.B = n1;
+    if (G == 4) launch_units<4>(u, st); else if (G == 3) launch_units<3>(u, st); else launch_units<2>(u, st);
+    if (n1 > 0) launch_t<64, 64, false>(s1, st);
+    return true;
+}
+void launch_attention(const AttnArgs& a_in, hipStream_t st) {
+    AttnArgs a = a_in;
+    for (int b = 0; b < RT_MAXB; ++b) {                              // one-stream launches: the unit is the batch entry
+        a.ng[b] = 1;
+        for (int g = 0; g < 4; ++g) { a.gvs[b][g] = (unsigned char)(b < a.B ? a.v_src[b] : 0); a.gob[b][g] = (unsigned char)b; }
+    }
     RT_REQUIRE(a.B >= 1 && a.B <= RT_MAXB, "attention: batch must be in [1,16]");
     RT_REQUIRE(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldvt % 8 == 0 && a.ldo % 8 == 0, "attention: leading dims");
     RT_REQUIRE(((uintptr_t)a.Q & 15) == 0 && ((uintptr_t)a.K & 15) == 0 && ((uintptr_t)a.VT & 15) == 0 &&
@@ -360,6 +495,7 @@ void launch_attention(const AttnArgs& a, hipStream_t st) {
         }
     } else {
         RT_REQUIRE(a.NK % 8 == 0 && a.NK >= 8, "self-attention: key count must be a multiple of 8");
+        if (launch_attention_units(a, st)) return;
         const bool ragged = a.NK % 64 != 0;
         // 256-query workgroups (NW = 8) halve the LDS-DMA pieces per query but measured 751 vs 802 TFLOP/s in the engine and
         // 908 vs 941 / 642 vs 694 stand-alone (N = 4096 / 1024): the kernel is bound by its softmax VALU work, not by the K / V^T

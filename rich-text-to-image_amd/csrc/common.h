@@ -216,6 +216,10 @@ struct AttnArgs {
     const bf16_t* VT; int ldvt;  // [H*DP, ldvt] row (h*DP + d), column (v_src[b]*NK + key)
     bf16_t* O;        int ldo;   // [B*N, ldo] row (b*N + n), head h at column h*DP
     int q_src[RT_MAXB], k_src[RT_MAXB], v_src[RT_MAXB], wset[RT_MAXB];
+    // filled by launch_attention (attn_kernel only): a launch runs B UNITS; unit b attends with (q_src[b], k_src[b]) and has ng[b] members
+    // that share its probabilities - member g reads V^T of batch entry gvs[b][g] and writes the output rows of batch entry gob[b][g]
+    // (one-stream launches: ng = 1, gvs = v_src[b], gob = b)
+    unsigned char ng[RT_MAXB], gvs[RT_MAXB][4], gob[RT_MAXB][4];
     const float* wabs;           // cross: [nsets, NK] |font size| multiplier per key; null => plain softmax
     const float* wsgn;           // cross: [nsets, NK] sign multiplier per key
     int B, H, N;                 // queries per batch entry
@@ -234,6 +238,7 @@ void launch_attention(const AttnArgs& a, hipStream_t st);
 bool cross77_supported(int H, int DP, int tokens, int NK, int nk_valid);
 void launch_cross77(const AttnArgs& a, hipStream_t st);
 bool gemm_cross77_enabled();      // debug bit 19 clear
+void attention_set_units(int mode);  // shared-probability units of the self-attention launches (attention.hip, launch_attention_units; rt_op_gemm_debug bits 24 - 26)
 void attention_set_prio(int on);   // s_setprio around the MFMA phases of attn_kernel (default on; rt_op_gemm_debug bit 14 clears it)
 
 // head-averaged probabilities of one stream, accumulated over calls (token-map producer)

@@ -1310,7 +1310,7 @@ int rt_op_split_range(int n_streams, int text_ref_stream, int inject, int part, 
 extern int g_store_legacy;
 extern int g_store_apply_v1;
 extern int g_c77_t1;
-int rt_op_gemm_debug(int d) { gemm_set_debug(d); g_store_own_stats = (d >> 17) & 1; g_store_apply_v1 = (d >> 18) & 1; g_c77_t1 = (d >> 20) & 3; g_store_legacy = ((d & 32) ? 1 : 0) | ((d & 64) ? 2 : 0); attention_set_prio(((d >> 14) & 1) ^ 1); return RT_OK; }
+int rt_op_gemm_debug(int d) { gemm_set_debug(d); g_store_own_stats = (d >> 17) & 1; g_store_apply_v1 = (d >> 18) & 1; g_c77_t1 = (d >> 20) & 3; g_store_legacy = ((d & 32) ? 1 : 0) | ((d & 64) ? 2 : 0); attention_set_prio(((d >> 14) & 1) ^ 1); attention_set_units((d >> 24) & 7); return RT_OK; }
 int rt_op_probes_built(void) {
 #ifdef RT_PROBES
     return 1;

@@ -440,6 +440,44 @@ def test_self_attention_injection_equals_injected_probs():
     report("self_attn untouched stream", out.float().reshape(B, N, -1)[2], own[0], atol=1.5e-2, rtol=1.5e-2)
 
 
+@pytest.mark.parametrize("B,H,N,src", [(7, 20, 1024, [0, 1, 2, 3, 3, 3, 3]),        # config 3, injected step, 1280-channel level
+                                       (7, 3, 4096, [0, 1, 2, 3, 3, 3, 3]),         # ... 640-channel level (3 of its 10 heads)
+                                       (5, 4, 256, [0, 1, 2, 3, 3]),                # R = 2: text_ref + one region
+                                       (6, 4, 256, [0, 1, 2, 3, 3, 3]),             # R = 3
+                                       (9, 2, 512, [0, 1, 2, 3, 3, 3, 3, 3, 3]),    # R = 6: six members = a unit of four + a unit of two
+                                       (6, 2, 320, [0, 0, 2, 3, 3, 3]),             # two shared groups in one launch
+                                       (4, 2, 256, [0, 1, 2, 3])])                  # nothing shared: the launch of rounds 1 - 5
+def test_self_attention_shared_probability_units_are_bit_identical(B, H, N, src):
+    """Round 6: streams that attend with the same (Q, K) source - text_ref and the injected region streams - share ONE softmax per key
+    tile (attn_kernel G > 1): per stream the same MFMA sequence, so every mode of launch_attention_units gives the bits of the
+    one-stream launches (rt_op_gemm_debug bits 24 - 26: 1 = never, 2 = shared units of G = 4 (or the largest group's 2 / 3) members and the one-stream units in
+    ONE launch, 3 = the same with units of two, 4 / 5 = the one-stream units in a launch of their own)."""
+    from rich_text_to_image_amd.engine import load_library
+    lib = load_library()
+    d = DP = 64
+    q, k, v = rnd(B, N, H * d, seed=43), rnd(B, N, H * d, seed=44), rnd(B, N, H * d, seed=45)
+    k[:, 5] *= 6.0                                                  # a few dominant keys: the deferred rescale fires in some tiles
+    qs = d ** -0.5 * math.log2(math.e)
+    Q, K, V = (_pack_heads(t.reshape(B * N, -1), H, d, DP, s) for t, s in ((q, qs), (k, 1.0), (v, 1.0)))
+    VT = V.t().contiguous()
+    outs = {}
+    try:
+        for mode in (1, 0, 2, 3, 4, 5):
+            lib.rt_op_gemm_debug(mode << 24)
+            outs[mode] = attention(Q, K, VT, B, H, N, N, DP, q_src=src, k_src=src, v_src=list(range(B))).clone()
+    finally:
+        lib.rt_op_gemm_debug(0)
+    for mode in (0, 2, 3, 4, 5):
+        assert torch.equal(outs[mode], outs[1]), f"mode {mode} differs from the one-stream launches: {(outs[mode].float() - outs[1].float()).abs().max()}"
+    # ... and the one-stream launches against the reference arithmetic: stream b = softmax(Q_src K_src^T) V_b
+    qr, kr, vr = Q.float().reshape(B, N, -1) / qs, K.float().reshape(B, N, -1), V.float().reshape(B, N, -1)
+    b = B - 1
+    _, p_ref = _ref_attention(qr[src[b]:src[b] + 1].to(DEV), kr[src[b]:src[b] + 1].to(DEV), vr[:1].to(DEV), H)
+    vh = vr[b:b + 1].to(DEV).reshape(1, N, H, d).permute(0, 2, 1, 3).reshape(H, N, d)
+    inj = torch.bmm(p_ref, vh).reshape(1, H, N, d).permute(0, 2, 1, 3).reshape(N, H * d)
+    report(f"self_attn shared unit, stream {b}", outs[0].float().reshape(B, N, -1)[b], inj, atol=1.5e-2, rtol=1.5e-2)
+
+
 def test_online_softmax_rescale_branch_with_spiked_keys():
     """Force the running-max rescale: one key per later tile dominates (guide 5.4 rule 26)."""
     B, H, N, d, DP = 1, 1, 256, 64, 64
