@@ -492,16 +492,18 @@ def main():
         traffic = None
         tfile = None
         try:
-            tfile = next(f for f in ("r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            tfile = next(f for f in ("r6_pmc_traffic.json", "r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
             tj = json.load(open(os.path.join(ROOT, "profiles", tfile)))
             cls = {"gemm_kernel<A_DENSE>": "gemm_dense", "gemm_kernel<A_CONV3*>": "gemm_conv", "attn_kernel<self>": "attn_self",
                    "attn_kernel<cross>": "attn_cross", "gemm16_kernel<EPI_XATTN> (to_q + cross-attention)": "xattn_fused"}[dom]
             traffic = tj["classes"][cls]["hbm_bytes_per_launch"]
+            traffic_us = tj["classes"][cls].get("avg_us")          # the class's average launch duration IN THE COUNTER PASSES (counters perturb: not avg_launch_us below)
         except Exception:
-            pass
+            traffic_us = None
         roof = dict(bound="mfma", kernel=dom + " (dense GEMM launches: gemm16_kernel<A_DENSE> / gemm_kernel<A_DENSE>)" if dom == "gemm_kernel<A_DENSE>" else dom,
                     achieved=achieved, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
                     frac=achieved / PEAK_BF16_TFLOPS, traffic=traffic, traffic_source=f"profiles/{tfile} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py --roofline-only`, the dispatches of the two profiled steps; gfx950 x2 FETCH correction)" if traffic else None,
+                    traffic_avg_launch_us=traffic_us if traffic else None,
                     launches=p["launches"],
                     avg_launch_us=p["total_ms"] * 1e3 / max(1, p["launches"]),
                     flops_per_launch=p["total_flops"] / max(1, p["launches"]),
