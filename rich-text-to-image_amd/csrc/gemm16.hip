@@ -316,6 +316,59 @@ __global__ __launch_bounds__(512) void gemm16_dual_kernel(GemmArgs pa, GemmArgs 
     else gemm16_tile<A_DENSE, EPI_BF16, TMW_B, TNW_B, 2, 2, 2, 3, LN ? RT_LNF_COLS : 0>(pb, 0, blockIdx.x - (unsigned)nwg_a);
 }
 
+#ifdef RT_PROBE
+// ---------------------------------------------------------------------------------------------- probe only: the chained panel form (LABNOTES R6.5)
+// VERDICT r5 item 1, form (i), in its smallest instance: attn1.to_out (fp16 trunk + residual, producer of the LayerNorm partials) and the
+// attn2.to_q that consumes it (LayerNorm-folded) as the two phases of ONE launch of 256 workgroups.  Both problems are 7168 x 1280 x 1280 on the
+// same 224 x 160 K-split tile; a to_q tile reads the 224-row panel of xb + its partial sums, i.e. the outputs of the 8 column tiles of its row
+// panel - which the default tile map places on ONE XCD (4 panels x 8 column tiles = one XCD's contiguous run of 32).  Hand-off per panel:
+// every wave drains its stores (vmcnt(0)), workgroup barrier, one relaxed agent-scope arrival on the panel's counter; consumers poll the
+// counter from one lane with s_sleep, barrier, `buffer_inv sc1` (the CU's vector L1 may hold lines of xb from an earlier layer), then the
+// unchanged tile body.  NOT for the product: visibility of plain stores through the shared L2 relies on the producer and the consumer
+// sitting on one XCD (a placement, not a guarantee), and the spin is bounded (a launch that is not fully resident falls through with wrong
+// results instead of hanging the box).  mode bit 0: no wait at all (wrong results: prices the phases without the seam); bit 1: no L1 invalidate; bit 2: `buffer_inv sc0`.
+__device__ unsigned g_chain_flags[64];
+__device__ long long g_chain_times[256 * 4];
+template <int MODE_UNUSED>
+__global__ __launch_bounds__(512, 1) void gemm16_chain_kernel(GemmArgs pa, GemmArgs pb, unsigned target, int mode) {
+    const int tid = threadIdx.x;
+    if (tid == 0) g_chain_times[blockIdx.x * 4 + 0] = __builtin_readcyclecounter();
+    gemm16_tile<A_DENSE, EPI_F16, 7, 5, 2, 2, 2, 3, RT_LNF_EMIT>(pa, 0, blockIdx.x);
+    // the tile map of the body (default order): XCD-aware bijective remap + groups of 4 tile rows x all tile columns
+    const int ntn = (pa.N + 159) / 160, ntm = (pa.M + 223) / 224, nwg = ntm * ntn;
+    int bid = blockIdx.x;
+    { const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3; bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx; }
+    const int gsz = 4 * ntn, first_m = (bid / gsz) * 4, gm = (ntm - first_m) < 4 ? (ntm - first_m) : 4;
+    const int tm = first_m + (bid % gsz) % gm;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's stores have left for L2
+    __syncthreads();
+    if (tid == 0) {
+        g_chain_times[blockIdx.x * 4 + 1] = __builtin_readcyclecounter();
+        __hip_atomic_fetch_add(&g_chain_flags[tm], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((mode & 1) == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(&g_chain_flags[tm], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < (1 << 18)) __builtin_amdgcn_s_sleep(2);
+        }
+        g_chain_times[blockIdx.x * 4 + 2] = __builtin_readcyclecounter();
+    }
+    __syncthreads();
+    if ((mode & 6) == 0) asm volatile("buffer_inv sc1" ::: "memory");
+    else if (mode & 4) asm volatile("buffer_inv sc0" ::: "memory");                    // (mode & 2: no invalidate at all - prices the instruction)
+    gemm16_tile<A_DENSE, EPI_BF16, 7, 5, 2, 2, 2, 3, RT_LNF_ROWS>(pb, 0, blockIdx.x);
+    if (tid == 0) g_chain_times[blockIdx.x * 4 + 3] = __builtin_readcyclecounter();
+}
+void launch_gemm16_chain(const GemmArgs& a, const GemmArgs& b, unsigned target, int mode, hipStream_t st) {
+    constexpr int LDS = 3 * (224 + 160) * 128 + RT_LN_TAB;
+    static bool attr = false;
+    if (!attr) { HIP_CHECK(hipFuncSetAttribute((const void*)gemm16_chain_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; }
+    RT_REQUIRE(a.M == b.M && a.N == 1280 && b.N == 1280 && a.M % 224 == 0 && (a.M / 224) * 8 == 256, "chain probe: 7168 x 1280 projections (256 workgroups, all resident)");
+    hipLaunchKernelGGL(gemm16_chain_kernel<0>, dim3(256), dim3(512), LDS, st, a, b, target, mode);
+    HIP_CHECK(hipGetLastError());
+}
+void gemm16_chain_read_times(long long* dst) { HIP_CHECK(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_chain_times), sizeof(long long) * 256 * 4)); }
+void gemm16_chain_reset() { unsigned z[64] = {}; HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_chain_flags), z, sizeof(z))); }
+#endif
+
 // ---------------------------------------------------------------------------------------------- launch
 struct G16Var { int BM, BN, WK, S, geglu_ok; };
 // variant ids (probe / tests).  Within a class (A: WK = 1, B: WK = 2) all variants are bit-identical per output element.
