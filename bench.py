@@ -146,7 +146,12 @@ def physical_cores():
     return threads
 
 
-PIXEL_TOL = {"config1": (1.5e-2, 46.0, 8), "config2": (2.5e-2, 44.0, 12), "config3": (1.5e-2, 46.0, 8), "config3_50": (1.5e-2, 46.0, 8), "config5": (2.5e-2, 46.0, 8)}     # tests/test_fullschedule_gpu.py
+# (latents rel-L2 at any recorded iteration, min PSNR [dB], max |d| in uint8 levels, error RELATIVE TO THE ACCUMULATED UPDATE ||lat_k - lat_0|| at any
+#  recorded iteration) - the tolerances of tests/test_fullschedule_gpu.py (TOL / UPDATE_TOL).  The update-relative bound is the discriminating
+#  one: with seeded random weights the sigma-scaled SDXL latents stay ~95 % start noise, so the latent-relative figure flatters by 2.5 - 3x.
+PIXEL_TOL = {"config1": (1.5e-2, 46.0, 8, 2.0e-2), "config2": (1.5e-2, 46.0, 8, 2.0e-2), "config2_50": (1.5e-2, 46.0, 8, 2.0e-2),
+             "config3": (1.5e-2, 46.0, 8, 3.0e-2), "config3_50": (1.5e-2, 46.0, 8, 3.0e-2), "config3_unit": (2.5e-2, 40.0, 16, 3.0e-2),
+             "config5": (2.5e-2, 46.0, 8, 4.5e-2), "config5_50": (2.5e-2, 46.0, 8, 4.5e-2)}
 
 
 def pixel_parity(case, also=()):
@@ -162,16 +167,19 @@ def pixel_parity(case, also=()):
 
     def one(name):
         r = fc.compare(name, mdl, fp)
-        t_lat, t_psnr, t_max = PIXEL_TOL[name]
+        t_lat, t_psnr, t_max, t_upd = PIXEL_TOL[name]
         curve, pix = r["latent_rel_l2_by_iteration"], r["pixels_vs_oracle_image"]
+        ucurve = r["latent_update_rel_l2_by_iteration"]
         c = r["case"]
         return dict(case=name, schedule=f"{c['model']} latent {c['hw']}x{c['hw']}, R={c['R']}, {c['steps']} scheduler steps = {max(curve)} loop iterations, CFG {c['gs']}, "
                                          f"inject_selfattn {c['isa']}, inject_background {c['ibg']}, colour guidance {c['guided']}",
                     latent_rel_l2_by_iteration={str(k): v for k, v in curve.items()}, latent_rel_l2_final=curve[max(curve)],
+                    update_rel_l2_by_iteration={str(k): v for k, v in ucurve.items()}, update_rel_l2_final=ucurve[max(ucurve)], update_rel_l2_max=max(ucurve.values()),
+                    update_over_latents_final=r["update_over_latents_final"], latent_abs_rms_final=list(r["latent_abs_rms_by_iteration"].values())[-1],
                     psnr_db=pix["psnr_db"], mean_abs_u8=pix["mean_abs"], max_abs_u8=pix["max_abs"], within_1_level=pix["within_1"],
                     decoder_only_psnr_db=r["decoder_only"]["psnr_db"],
-                    tol=dict(latent_rel_l2=t_lat, psnr_db=t_psnr, max_abs_u8=t_max),
-                    ok=bool(max(curve.values()) < t_lat and pix["psnr_db"] > t_psnr and pix["max_abs"] <= t_max),
+                    tol=dict(latent_rel_l2=t_lat, psnr_db=t_psnr, max_abs_u8=t_max, update_rel_l2=t_upd),
+                    ok=bool(max(curve.values()) < t_lat and max(ucurve.values()) < t_upd and pix["psnr_db"] > t_psnr and pix["max_abs"] <= t_max),
                     reference="fp32 CPU oracle trajectory + oracle VAE decode (oracle/region_loop.py, pinned to the unmodified reference loops)")
     try:
         out = one(case)
@@ -295,6 +303,14 @@ def cross_attention_block(dev, F=7):
     return out
 
 
+def _config_parity(cfg):
+    full = {1: "config1", 2: "config2_50", 5: "config5_50"}[cfg]
+    short = {1: None, 2: "config2", 5: "config5"}[cfg]
+    if not os.path.exists(os.path.join(ROOT, "tests", "golden", "fullschedule", full + ".pt")):
+        full, short = short, None
+    return pixel_parity(full, also=(short,) if short else ())
+
+
 def other_config(args):
     """BASELINE.json configs 1, 2 and 5 (SURVEY 8d numbering) through the drop-in facade classes (tools/bench_configs.py holds the
     workloads): same JSON contract, N = 1 only.  `--steps K` = K scheduler steps of the named loop (PLMS runs K+1 iterations)."""
@@ -315,7 +331,9 @@ def other_config(args):
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_BF16_TFLOPS, "traffic": None},
             "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline_other(args.config),
             # the full schedule of the committed oracle trajectory of this configuration, latents and pixels (tests/test_fullschedule_gpu.py asserts the same)
-            "parity": None if args.no_cpu_baseline else pixel_parity({1: "config1", 2: "config2", 5: "config5"}[args.config]),
+            # round 6: configs 2 / 5 at BASELINE's own length / mask shape (51 PLMS iterations; 50-step schedule with 10 Voronoi cells, 30 iterations
+            # across the blend), the short trajectories of round 5 under "also"
+            "parity": None if args.no_cpu_baseline else _config_parity(args.config),
             "parity_tests": {1: "tests/test_fullsize_gpu.py::test_sd15_config1_rich_loop_matches_oracle (SD-v1.5 full architecture, PLMS loop vs the fp32 oracle)",
                              2: "tests/test_fullsize_gpu.py::test_sd15_full_architecture_stream_modes_match_oracle + test_full_width_vae_decode_and_guidance_gradient_match_oracle",
                              5: "tests/test_fullsize_gpu.py::test_sdxl_config3_rich_step_matches_oracle + test_full_width_vae_decode_and_guidance_gradient_match_oracle"}[args.config]}
@@ -557,7 +575,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.roofline_only:
         try:
             # the benched workload's own 50-step schedule (+ the 10-step one that crosses the injection boundary between two checkpoints)
-            pixels = pixel_parity("config3_50", also=("config3",)) if os.path.exists(os.path.join(ROOT, "tests", "golden", "fullschedule", "config3_50.pt")) else pixel_parity("config3")
+            pixels = pixel_parity("config3_50", also=("config3", "config3_unit")) if os.path.exists(os.path.join(ROOT, "tests", "golden", "fullschedule", "config3_50.pt")) else pixel_parity("config3")
         except Exception as ex:          # the headline line must still print
             pixels = {"error": repr(ex)}
 
