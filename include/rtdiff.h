@@ -166,6 +166,13 @@ int rt_op_attention(const void* Q, int ldq, const void* K, int ldk, const void* 
                     const int* q_src_host, const int* k_src_host, const int* v_src_host, const int* wset_host,
                     const float* wabs, const float* wsgn, int B, int H, int N, int NK, int nk_valid, int DP, int cross,
                     void* stream);
+/* Host-only (no GPU): the partition of a self-attention launch into shared-probability units (round 6; csrc/attention.hip).  Streams that
+ * attend with the same (q_src, k_src) - text_ref and the region streams that take its probabilities, attention_processor.py:522-524 - are dealt
+ * G at a time into units that compute softmax(QK^T) once; mode 0 = the shape rule (tokens >= 2048: units of four in their own launch, else
+ * pairs beside the one-stream units), 1 = never, 2 - 5 as rt_op_gemm_debug bits 24 - 26.  Per batch entry: launch_of (0 = the G-member
+ * kernel's launch, 1 = the separate one-stream launch; 1 for every entry when nothing is shared), unit_of, members_of.  Returns G (0: no sharing),
+ * -1 on bad arguments. */
+int rt_op_attention_units_plan(const int* q_src, const int* k_src, int B, int tokens, int DP, int mode, int* launch_of, int* unit_of, int* members_of);
 /* Host-only query of the shape rule of csrc/gemm16.hip (no device needed; tests/test_gemm16_pick.py): the tile variant a problem of `streams`
  * streams x rows_per_stream rows takes (ids below; -1: not in the family / stays on gemm.hip or the patch convolution; -2: conv3x3 query
  * with a non-square map).  conv3x3 = 1: stride-1 3x3 convolution with Cin = K_or_Cin input channels on a square map of rows_per_stream

@@ -441,9 +441,12 @@ void attention_set_units(int mode) { g_attn_units = mode; }
 // 54 -> 50 us with pairs in one launch, 54 / 57 with units of four; 7 x 4096 x 10 heads 314 -> 279 us with units of four + the one-stream
 // units in their own launch, 287 in one launch, 294 / 280 with pairs): short sequences take pairs beside the one-stream units - a unit of
 // four there is 160 heavy workgroups -, long ones units of four in their own launch.  A function of the launch's own shape.
-static bool launch_attention_units(const AttnArgs& a, hipStream_t st) {
-    const int mode = g_attn_units ? g_attn_units : (a.N >= 2048 ? 4 : 3);
-    if (mode <= 1 || mode >= 6 || a.cross || a.DP != 64 || a.NK % 64 != 0 || a.stats != nullptr) return false;
+// The plan, host-only (also behind rt_op_attention_units_plan: the rule is testable without a GPU).  Fills `u` (the launch of the G-member
+// kernel: shared units first, then - unless `split` - the one-stream units) and `s1` (the one-stream launch of a split plan); returns G, or 0
+// when the launch has nothing to share / is outside the shared kernel's domain (d = 64 self-attention on whole 64-key tiles, no statistics).
+static int attention_units_plan(const AttnArgs& a, int mode_in, AttnArgs& u, AttnArgs& s1) {
+    const int mode = mode_in ? mode_in : (a.N >= 2048 ? 4 : 3);
+    if (mode <= 1 || mode >= 6 || a.cross || a.DP != 64 || a.NK % 64 != 0 || a.stats != nullptr) return 0;
     const bool split = mode >= 4;
     // source groups in batch order
     int grp[RT_MAXB][RT_MAXB], gn[RT_MAXB], ngrp = 0, largest = 0;
@@ -456,9 +459,9 @@ static bool launch_attention_units(const AttnArgs& a, hipStream_t st) {
         gn[ngrp++] = nm;
         if (nm > largest) largest = nm;
     }
-    if (largest < 2) return false;
+    if (largest < 2) return 0;
     const int G = (mode == 3 || mode == 5) ? 2 : (largest >= 4 ? 4 : largest);
-    AttnArgs u = a, s1 = a;
+    u = a; s1 = a;
     int nu = 0, n1 = 0;
     auto put = [&](AttnArgs& d, int& k, int src, const int* mem, int n) {
         d.q_src[k] = a.q_src[src]; d.k_src[k] = a.k_src[src]; d.ng[k] = (unsigned char)n;
@@ -470,9 +473,31 @@ static bool launch_attention_units(const AttnArgs& a, hipStream_t st) {
     for (int i = 0; i < ngrp; ++i)                                   // what is left of every group: one-stream units
         for (int i0 = gn[i] - gn[i] % G; i0 < gn[i]; ++i0) put(split ? s1 : u, split ? n1 : nu, grp[i][0], &grp[i][i0], 1);
     u.B = nu; s1.B = n1;
+    return G;
+}
+static bool launch_attention_units(const AttnArgs& a, hipStream_t st) {
+    AttnArgs u, s1;
+    const int G = attention_units_plan(a, g_attn_units, u, s1);
+    if (G == 0) return false;
     if (G == 4) launch_units<4>(u, st); else if (G == 3) launch_units<3>(u, st); else launch_units<2>(u, st);
-    if (n1 > 0) launch_t<64, 64, false>(s1, st);
+    if (s1.B > 0) launch_t<64, 64, false>(s1, st);
     return true;
+}
+// Host-only view of the plan (include/rtdiff.h, rt_op_attention_units_plan): per batch entry the launch (0 = the G-member kernel, 1 = the
+// one-stream launch of a split plan), the unit inside that launch and the unit's member count.
+int attention_units_plan_host(const int* q_src, const int* k_src, int B, int N, int DP, int mode, int* launch_of, int* unit_of, int* members_of) {
+    AttnArgs a{}, u, s1;
+    a.B = B; a.N = N; a.NK = N; a.DP = DP; a.cross = 0; a.stats = nullptr;
+    for (int b = 0; b < B; ++b) { a.q_src[b] = q_src[b]; a.k_src[b] = k_src[b]; a.v_src[b] = b; }
+    const int G = attention_units_plan(a, mode, u, s1);
+    for (int b = 0; b < B; ++b) { launch_of[b] = G ? -1 : 1; unit_of[b] = b; members_of[b] = 1; }
+    if (G == 0) return 0;
+    for (int l = 0; l < 2; ++l) {
+        const AttnArgs& d = l ? s1 : u;
+        for (int k = 0; k < d.B; ++k)
+            for (int g = 0; g < d.ng[k]; ++g) { const int b = d.gob[k][g]; launch_of[b] = l; unit_of[b] = k; members_of[b] = d.ng[k]; }
+    }
+    return G;
 }
 void launch_attention(const AttnArgs& a_in, hipStream_t st) {
     AttnArgs a = a_in;
