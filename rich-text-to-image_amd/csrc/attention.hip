@@ -101,9 +101,35 @@ static __device__ __forceinline__ void attn_tile(const AttnArgs& p, const int b,
 #pragma unroll
     for (int g = 0; g < G; ++g) vbase[g] = p.VT + (size_t)h * DP * p.ldvt + (size_t)vb[g] * p.NK;
 
+    // Self-attention on whole key tiles: the pieces go through a buffer descriptor (buffer_load ... offen lds) - per piece ONE 32-bit VGPR
+    // byte offset computed here, once, and a SCALAR offset that advances with the key tile, instead of a 64-bit address rebuilt per piece
+    // and tile (35 of the ~170 VALU / SALU instructions of a key tile; round 6).
+    constexpr bool BUFST = !RAGGED && !CROSS;
+    constexpr int NIT = (NCH + NT - 1) / NT;
+    int kvoff[BUFST ? NIT : 1], vvoff[BUFST ? NIT : 1];
+    if constexpr (BUFST) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = it * NT + tid, rl = idx >> 2, ps = idx & 3;
+            { const int sub = rl / KT, row = rl - sub * KT, ls = ps ^ ((row >> 2) & 3); kvoff[it] = (row * p.ldk + sub * 32 + ls * 8) * 2; }
+            { const int sub = rl / DP, row = rl - sub * DP, ls = ps ^ ((row >> 2) & 3); vvoff[it] = (row * p.ldvt + sub * 32 + ls * 8) * 2; }
+        }
+    }
     auto stage = [&](int s, int key0) {
         char* ks_ = smem + s * STAGE;
         char* vs_ = ks_ + TILE;
+        if constexpr (BUFST) {
+            const int ksoff = key0 * p.ldk * 2, vsoff = key0 * 2;      // scalars
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                if (it * NT + tid < NCH) {   // wave-uniform: NCH % 64 == 0
+                    glds16_buf(kbase, kvoff[it], ksoff, ks_ + (it * NT + wave * 64) * 16);
+#pragma unroll
+                    for (int g = 0; g < G; ++g) glds16_buf(vbase[g], vvoff[it], vsoff, vs_ + g * TILE + (it * NT + wave * 64) * 16);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int c0 = 0; c0 < NCH; c0 += NT) {
             const int idx = c0 + tid;
