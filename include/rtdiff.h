@@ -121,6 +121,12 @@ int rt_eps_info(rt_engine* e, void** dev_ptr, unsigned long long* bytes_per_stre
 int rt_op_split_range(int n_streams, int text_ref_stream, int inject, int part, int nparts, int* first_stream, int* n_streams_out);
 /* one iteration of the plain-text loop (rd.py:200-214 / xl.py:880-905): batch-2 forward, CFG, step */
 int rt_plain_step(rt_engine* e, int step_index, float guidance_scale);
+/* The same step shared by the ranks of a process group (round 6; sample.py --gpus N --split_image): part 0 runs the unconditional forward,
+ * part 1 the text forward - and is the rank whose engine records the token maps -, further parts none ([first, first + count) of the
+ * stream list [uncond, text]); the ranks exchange their slots of the eps buffer (rt_eps_info) and every rank calls rt_plain_step_finish
+ * (CFG + scheduler step).  Bit-identical with rt_plain_step on one GPU. */
+int rt_plain_step_part(rt_engine* e, int step_index, int part, int nparts, int* first_stream, int* n_streams);
+int rt_plain_step_finish(rt_engine* e, int step_index, float guidance_scale);
 
 /* token-map attention store (hooks rd.py:397-443, xl.py:959-1016): head-averaged softmax(QK^T) of the
  * CONDITIONAL stream of rt_plain_step, recorded for the named attention modules (reference module names such as

@@ -956,6 +956,9 @@ struct rt_engine {
     void region_step_finish(int i, float g, double isa, double ibg, bool xl, bool elide, bool defer_blend);
     bool pending_blend = false;
     void plain_step(int i, float g);
+    void plain_forward(int i, int first, int count);
+    void plain_finish(int i, float g);
+    void plain_step_part(int i, int part, int nparts, int* first, int* count);
 };
 
 #include "step_driver.inl"
@@ -1178,6 +1181,10 @@ int rt_background_blend(rt_engine* e) {
     })
 }
 int rt_plain_step(rt_engine* e, int i, float g) { RT_TRY(e, { need_device(e); e->plain_step(i, g); }) }
+int rt_plain_step_part(rt_engine* e, int i, int part, int nparts, int* first, int* count) {
+    RT_TRY(e, { need_device(e); RT_REQUIRE(first && count, "rt_plain_step_part: null outputs"); e->plain_step_part(i, part, nparts, first, count); })
+}
+int rt_plain_step_finish(rt_engine* e, int i, float g) { RT_TRY(e, { need_device(e); e->plain_finish(i, g); }) }
 
 int rt_unet_forward(rt_engine* e, const float* x, int B, int h, int w, float t, const float* in_scale, const int* prompt,
                     const int* fontsize, const int* qk_src, const int* res_src, float* out) {

@@ -155,17 +155,25 @@ void rt_engine::region_step_finish(int i, float g, double isa, double ibg, bool 
     region_finish(i, a, blend_deferred);
 }
 
-void rt_engine::plain_step(int i, float g) {
+// The plain-text step (rd.py:200-214 / xl.py:880-905) in the same three pieces as the rich-text step: the forwards of a contiguous range of
+// its two streams [uncond, text], and the epilogue on both.  `first < 0`: both streams (the one-GPU step).
+void rt_engine::plain_forward(int i, int first, int count) {
     require_bound();
     const int n = (int)timesteps.size();
     RT_REQUIRE(i >= 0 && i < n, "plain_step: step index out of range");
     RT_REQUIRE(n_prompts >= 2, "plain_step: need [negative, text] prompts");
+    RT_REQUIRE(first >= 0 && count >= 1 && first + count <= 2, "plain_step: stream range");
     const bool xl = sched_kind == RT_SCHED_EULER;
-    FwdIn in{}; in.h = lat_h; in.w = lat_w; in.t = timesteps[i]; in.eps_out = eps; in.B = 2;
+    FwdIn in{}; in.h = lat_h; in.w = lat_w; in.t = timesteps[i]; in.B = count;
+    in.eps_out = eps + (size_t)first * lat_h * lat_w * 4;            // a stream's prediction lands in its own slot of the eps buffer
     const float scale = xl ? 1.f / std::sqrt(table[i] * table[i] + 1.f) : 1.f;
-    for (int b = 0; b < 2; ++b) { in.x[b] = lat; in.scale[b] = scale; in.prompt[b] = b; in.fontsize[b] = 0; in.qk_src[b] = b; in.res_src[b] = -1; }
-    if (any_store()) in.store_stream = 1;     // hooks keep the conditional half: out[1][0][1:2] (rd.py:417,425 / xl.py:980,991)
+    for (int b = 0; b < count; ++b) { in.x[b] = lat; in.scale[b] = scale; in.prompt[b] = first + b; in.fontsize[b] = 0; in.qk_src[b] = b; in.res_src[b] = -1; }
+    // hooks keep the conditional half: out[1][0][1:2] (rd.py:417,425 / xl.py:980,991) - recorded by the rank that runs the text stream
+    if (any_store() && first <= 1 && first + count > 1) in.store_stream = 1 - first;
     unet_forward(in);
+}
+void rt_engine::plain_finish(int i, float g) {
+    const bool xl = sched_kind == RT_SCHED_EULER;
     StepArgs a{};
     a.eps = eps; a.masks = masks; a.lat = lat; a.lat_ref = lat_ref; a.HW = lat_h * lat_w; a.R = 0; a.g = g; a.plain = 1;
     a.s_uncond = 0; a.s_base = 1; a.s_uref = a.s_tref = -1; a.sched = sched_kind; a.step_ref = 0; a.blend = 0;
@@ -173,4 +181,17 @@ void rt_engine::plain_step(int i, float g) {
     else pndm_coeffs(this, i, a);
     launch_step_epilogue(a, stream);
     steps_done++;
+}
+void rt_engine::plain_step(int i, float g) {
+    plain_forward(i, 0, 2);
+    plain_finish(i, g);
+}
+// Intra-image split of the plain pass (round 6): part 0 runs the unconditional stream, part 1 the text stream (and records the token maps),
+// further parts run nothing; one exchange of the two noise predictions, then rt_plain_step_finish on every rank.
+void rt_engine::plain_step_part(int i, int part, int nparts, int* first, int* count) {
+    RT_REQUIRE(nparts >= 1 && part >= 0 && part < nparts, "plain_step_part: part index");
+    if (nparts == 1) { *first = 0; *count = 2; }
+    else { *first = part < 2 ? part : 2; *count = part < 2 ? 1 : 0; }
+    if (*count > 0) plain_forward(i, *first, *count);
+    else { require_bound(); RT_REQUIRE(i >= 0 && i < (int)timesteps.size(), "plain_step: step index out of range"); }
 }

@@ -73,6 +73,7 @@ _SYMBOLS = [
     "rt_op_cross_attn_block", "rt_op_gemm16_variant", "rt_op_gemm16_pick", "rt_profile_read2", "rt_op_gemm_qk_vt", "rt_op_gemm_pair_pick",
     "rt_region_step_part", "rt_region_step_finish", "rt_eps_info", "rt_op_split_range",
     "rt_op_ln_gemm", "rt_op_gemm_emit_partials", "rt_op_ln_partials", "rt_op_probes_built", "rt_op_attention_units_plan",
+    "rt_plain_step_part", "rt_plain_step_finish",
 ]
 
 
@@ -371,6 +372,15 @@ class Engine:
 
     def plain_step(self, i, guidance_scale):
         self._chk(self.lib.rt_plain_step(self.h, i, C.c_float(guidance_scale)))
+
+    def plain_step_part(self, i, part, nparts):
+        """The forwards of this rank's range of the plain step's streams [uncond, text] (launcher.split_plain_step); returns (first, count)."""
+        first, count = C.c_int(0), C.c_int(0)
+        self._chk(self.lib.rt_plain_step_part(self.h, i, part, nparts, C.byref(first), C.byref(count)))
+        return first.value, count.value
+
+    def plain_step_finish(self, i, guidance_scale):
+        self._chk(self.lib.rt_plain_step_finish(self.h, i, C.c_float(guidance_scale)))
 
     def unet_forward(self, x, timestep, prompt_idx, in_scale=None, fontsize=None, qk_src=None, res_src=None):
         import torch

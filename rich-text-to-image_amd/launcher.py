@@ -292,6 +292,45 @@ def split_region_step(engine, i, guidance_scale, inject_selfattn, inject_backgro
     return ranges
 
 
+def plain_capture_rank():
+    """--split_image: the rank whose engine runs the TEXT stream of the plain pass and therefore records the token maps (rank 1 of >= 2)."""
+    return 1 if dist.is_initialized() and dist.get_world_size() > 1 else 0
+
+
+def split_plain_step(engine, i, guidance_scale):
+    """ONE plain-text step (rd.py:200-214 / xl.py:880-905) of ONE image on all ranks: rank 0 runs the unconditional forward, rank 1 the
+    text forward (and records the token maps: plain_capture_rank), further ranks none; two broadcasts of one noise prediction each
+    (256 KB at SDXL), then CFG + scheduler step on every rank.  Bit-identical with engine.plain_step on one GPU."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    if world == 1:
+        engine.plain_step(i, guidance_scale)
+        return [(0, 2)]
+    first, count = engine.plain_step_part(i, rank, world)
+    ranges = [(r, 1) if r < 2 else (2, 0) for r in range(world)]     # the rule of csrc/step_driver.inl::plain_step_part
+    assert ranges[rank] == (first, count), (ranges[rank], first, count)
+    engine.synchronize()
+    eps, per = eps_tensor(engine) if not hasattr(engine, "eps_as_tensor") else engine.eps_as_tensor()
+    for r, (f, c) in enumerate(ranges):
+        if c > 0:
+            broadcast_tensor(eps[f * per:(f + c) * per], src=r)
+    _cuda_sync()                                                     # ordering contract: see split_region_step
+    engine.plain_step_finish(i, guidance_scale)
+    return ranges
+
+
+def broadcast_objects(objs, src):
+    """Small Python objects (the region masks the capture rank derived from its token maps) from `src` to every rank."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return objs
+    box = [objs if dist.get_rank() == src else None]
+    if dist.get_backend() == "nccl":
+        dist.broadcast_object_list(box, src=src, device=torch.device("cuda", torch.cuda.current_device()))
+    else:
+        dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
 def guidance_from_rank0(engine, fn, h, w):
     """--split_image: the colour-guidance VAE pass (82 ms at SDXL) changes ONLY the latents; rank 0 runs `fn()` and the others receive
     the updated latents (64 KB at SDXL) instead of repeating the decoder forward + backward on every rank."""

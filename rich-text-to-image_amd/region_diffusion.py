@@ -143,7 +143,11 @@ class RegionDiffusion:
         if hooks:
             self._store_begin(eng)
         for i in range(len(self.scheduler.timesteps)):
-            eng.plain_step(i, guidance_scale)
+            if getattr(self, "split_image", False):                      # one stream per rank, the text stream's rank records the maps
+                from .launcher import split_plain_step
+                split_plain_step(eng, i, guidance_scale)
+            else:
+                eng.plain_step(i, guidance_scale)
         if hooks:
             self._store_end(eng, len(self.scheduler.timesteps))
         return eng.read_latents(h, w)

@@ -138,7 +138,11 @@ class RegionDiffusionXL:
             if hooks:
                 self._store_begin(eng)
             for i in range(n):
-                eng.plain_step(i, guidance_scale)
+                if getattr(self, "split_image", False):                  # one stream per rank, the text stream's rank records the maps
+                    from .launcher import split_plain_step
+                    split_plain_step(eng, i, guidance_scale)
+                else:
+                    eng.plain_step(i, guidance_scale)
             if hooks:
                 self._store_end(eng, n)
         latents = eng.read_latents(h, w)

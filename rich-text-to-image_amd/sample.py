@@ -55,19 +55,39 @@ def generate(model, param, model_type='SD', run_dir=None, color_guidance_weight=
 
     t0 = time.time()
     seed_everything(seed)
-    seg_cache = {}       # both calls cluster the same recorded maps with the same seed: the second reuses the first's segmentation
-    color_obj_masks = get_token_maps(model.selfattn_maps, model.crossattn_maps, model.n_maps, run_dir, height // 8, width // 8,
-                                     color_target_token_ids[:-1], seed, base_tokens, segment_threshold=segment_threshold,
-                                     num_segments=num_segments, cache=seg_cache)
+    split = bool(getattr(model, 'split_image', False))
+    capture_rank, my_rank = 0, 0
+    if split:
+        # --split_image: the plain pass ran one stream per rank (launcher.split_plain_step), so only the rank of the TEXT stream holds the
+        # recorded maps: it derives the masks and hands them to the others (a few hundred KB) - every rank then holds identical masks by
+        # construction (the rich pass still digests them, region_diffusion*.py: assert_ranks_agree)
+        import torch.distributed as dist
+        from .launcher import broadcast_objects, plain_capture_rank
+        capture_rank, my_rank = plain_capture_rank(), (dist.get_rank() if dist.is_initialized() else 0)
+    if my_rank == capture_rank:
+        seg_cache = {}       # both calls cluster the same recorded maps with the same seed: the second reuses the first's segmentation
+        color_obj_masks = get_token_maps(model.selfattn_maps, model.crossattn_maps, model.n_maps, run_dir, height // 8, width // 8,
+                                         color_target_token_ids[:-1], seed, base_tokens, segment_threshold=segment_threshold,
+                                         num_segments=num_segments, cache=seg_cache)
+        seed_everything(seed)
+        region_masks = get_token_maps(model.selfattn_maps, model.crossattn_maps, model.n_maps, run_dir, height // 8, width // 8,
+                                      region_target_token_ids[:-1], seed, base_tokens, segment_threshold=segment_threshold,
+                                      num_segments=num_segments, cache=seg_cache)
+    else:
+        color_obj_masks = region_masks = None
+    if split:
+        dev = None if color_obj_masks is None else color_obj_masks[-1].device
+        packed = None if color_obj_masks is None else ([m.cpu() for m in color_obj_masks], [m.cpu() for m in region_masks])
+        color_obj_masks, region_masks = broadcast_objects(packed, capture_rank)
+        dev = dev if dev is not None else getattr(model, 'device', 'cpu')
+        color_obj_masks, region_masks = [m.to(dev) for m in color_obj_masks], [m.to(dev) for m in region_masks]
     color_obj_atten_all = torch.zeros_like(color_obj_masks[-1])
     for m in color_obj_masks[:-1]:
         color_obj_atten_all += m
     text_format_dict['color_obj_atten'] = [_resize_bicubic_aa(m, height, width) for m in color_obj_masks]
     text_format_dict['color_obj_atten_all'] = color_obj_atten_all
     seed_everything(seed)
-    model.masks = get_token_maps(model.selfattn_maps, model.crossattn_maps, model.n_maps, run_dir, height // 8, width // 8,
-                                 region_target_token_ids[:-1], seed, base_tokens, segment_threshold=segment_threshold,
-                                 num_segments=num_segments, cache=seg_cache)
+    model.masks = region_masks
     model.remove_tokenmap_hooks()
     timings['token_maps'] = time.time() - t0
 

@@ -2,6 +2,7 @@
 import os
 import sys
 
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -215,3 +216,66 @@ def test_collective_self_check_and_split_mode_guidance_handoff_world2_gloo():
         assert calls == ([0] if rank == 0 else [])                 # the guidance pass ran on rank 0 only ...
         assert lat00 == 41.5                                       # ... and every rank holds ITS result (rank 1 started from 1.0)
         assert agree is True and disagree is False
+
+
+def _worker_plain_split(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from rich_text_to_image_amd import launcher
+    launcher.init_distributed("gloo")
+
+    class StandIn:
+        """What split_plain_step needs of an engine: the part / finish calls and the eps buffer (two slots of 16 bytes)."""
+        device = 0
+
+        def __init__(self):
+            self.eps = torch.zeros(3 * 16, dtype=torch.uint8)
+            self.ran, self.finished = [], []
+
+        def plain_step_part(self, i, part, nparts):
+            first, count = (part, 1) if part < 2 else (2, 0)
+            if nparts == 1:
+                first, count = 0, 2
+            for s_ in range(first, first + count):                    # "forward" of stream s_: its slot gets a stream- and step-dependent value
+                self.eps[s_ * 16:(s_ + 1) * 16] = 10 * (i + 1) + s_ + 1
+                self.ran.append(s_)
+            return first, count
+
+        def plain_step_finish(self, i, g):
+            self.finished.append((i, g, self.eps[:32].clone()))
+
+        def synchronize(self):
+            pass
+
+        def eps_as_tensor(self):
+            return self.eps, 16
+    eng = StandIn()
+    ranges = [launcher.split_plain_step(eng, i, 7.5) for i in range(2)]
+    masks = launcher.broadcast_objects([torch.full((2, 2), 3.0)] if rank == launcher.plain_capture_rank() else None, launcher.plain_capture_rank())
+    q.put((rank, ranges, eng.ran, [(i, g, e.tolist()) for i, g, e in eng.finished], launcher.plain_capture_rank(), float(masks[0].sum())))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_split_mode_plain_pass_one_stream_per_rank_gloo(world):
+    """Round 6 (VERDICT r5 next #6b): in --split_image mode the plain pass is shared too - rank 0 runs the unconditional forward, rank 1 the
+    text forward (and is the rank that records the token maps and derives the masks), further ranks none; every rank finishes the step on
+    BOTH predictions; the masks travel from the capture rank as one object broadcast."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    from rich_text_to_image_amd import launcher
+    port = launcher.free_port()
+    procs = [ctx.Process(target=_worker_plain_split, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ranges, ran, finished, cap, msum in got:
+        assert ranges == [[(r, 1) if r < 2 else (2, 0) for r in range(world)]] * 2
+        assert ran == ([rank, rank] if rank < 2 else [])                  # its own stream, once per step
+        assert cap == 1 and msum == 12.0
+        for i, g, eps in finished:                                        # every rank saw BOTH predictions before its epilogue
+            assert g == 7.5 and eps == [10 * (i + 1) + 1] * 16 + [10 * (i + 1) + 2] * 16
+    assert len({tuple(map(str, f)) for _, _, _, f, _, _ in got}) == 1
