@@ -150,7 +150,7 @@ def physical_cores():
 #  recorded iteration) - the tolerances of tests/test_fullschedule_gpu.py (TOL / UPDATE_TOL).  The update-relative bound is the discriminating
 #  one: with seeded random weights the sigma-scaled SDXL latents stay ~95 % start noise, so the latent-relative figure flatters by 2.5 - 3x.
 PIXEL_TOL = {"config1": (1.5e-2, 46.0, 8, 2.0e-2), "config2": (1.5e-2, 46.0, 8, 2.0e-2), "config2_50": (1.5e-2, 46.0, 8, 2.0e-2),
-             "config3": (1.5e-2, 46.0, 8, 3.0e-2), "config3_50": (1.5e-2, 46.0, 8, 3.0e-2), "config3_unit": (2.5e-2, 40.0, 16, 3.0e-2),
+             "config3": (1.5e-2, 46.0, 8, 3.0e-2), "config3_50": (1.5e-2, 46.0, 8, 3.0e-2), "config3_unit": (8.0e-2, 34.0, 96, 8.0e-2),
              "config5": (2.5e-2, 46.0, 8, 4.5e-2), "config5_50": (2.5e-2, 46.0, 8, 4.5e-2)}
 
 

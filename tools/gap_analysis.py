@@ -30,6 +30,16 @@ def main(db_path, lo=0.45, hi=0.7):
             a = where.setdefault(k, [0, 0]); a[0] += 1; a[1] += g
     for (a_, b_), (c, t) in sorted(where.items(), key=lambda kv: -kv[1][1])[:8]:
         print(f"   {c:4d} gaps {t / 1e6:8.2f} ms  after [{a_}]  before [{b_}]")
+    # in-step boundaries (3 - 20 us): which predecessor leaves the longest idle behind it (dirty-line write-back, dispatch ramp of the successor)
+    mid = {}
+    tot_mid = 0
+    for i in range(len(rows) - 1):
+        g = rows[i + 1][0] - rows[i][1]
+        if 3000 < g <= 20000:
+            a = mid.setdefault((rows[i][2][:60], rows[i + 1][2][:40]), [0, 0]); a[0] += 1; a[1] += g; tot_mid += g
+    print(f"gaps of 3 - 20 us: {sum(c for c, _ in mid.values())} totalling {tot_mid / 1e6:.2f} ms; gaps <= 3 us total {sum(g for g in gaps if g <= 3000) / 1e6:.2f} ms")
+    for (a_, b_), (c, t) in sorted(mid.items(), key=lambda kv: -kv[1][1])[:10]:
+        print(f"   {c:4d} gaps avg {t / c / 1e3:6.1f} us  after [{a_}]  before [{b_}]")
     print(f"kernels {len(rows)}  span {span / 1e6:.2f} ms  busy {busy / 1e6:.2f} ms ({100.0 * busy / span:.1f} %)  "
           f"gap total {sum(gaps) / 1e6:.2f} ms  median {gaps[n // 2] / 1e3:.2f} us  p90 {gaps[int(n * 0.9)] / 1e3:.2f} us  max {gaps[-1] / 1e3:.1f} us")
 
