@@ -369,6 +369,8 @@ void gemm16_chain_read_times(long long* dst) { HIP_CHECK(hipMemcpyFromSymbol(dst
 void gemm16_chain_reset() { unsigned z[64] = {}; HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_chain_flags), z, sizeof(z))); }
 #endif
 
+int g_g16_tall = 0;            // (A/B, rt_op_gemm_debug bit 27) GEGLU launches that cannot take the W-stationary order run groups of 8 tile rows
+void gemm16_set_tall(int on) { g_g16_tall = on; }
 // ---------------------------------------------------------------------------------------------- launch
 struct G16Var { int BM, BN, WK, S, geglu_ok; };
 // variant ids (probe / tests).  Within a class (A: WK = 1, B: WK = 2) all variants are bit-identical per output element.
@@ -402,7 +404,7 @@ static void launch_v(const GemmArgs& a, int wstat, hipStream_t st) {
         attr = true;
     }
     const int ntn = cdiv(a.N, BN), ntm = cdiv(a.M, BM);
-    if (wstat && (ntn % 8 != 0)) wstat = 0;
+    if (wstat == 1 && (ntn % 8 != 0)) wstat = 0;
     hipLaunchKernelGGL((gemm16_kernel<MODE, EPI, TMW, TNW, WM, WN, WK, S, LNF>), dim3(ntm * ntn), dim3(WM * WN * WK * 64), LDS, st, a, wstat);
     HIP_CHECK(hipGetLastError());
 }
@@ -673,7 +675,7 @@ int gemm16_pick(const GemmArgs& a, int weights_on_rows, int* wstat) {
     }
     if (a.epi == EPI_GEGLU) {
         if (a.N % 256 != 0) return -1;
-        *wstat = (a.N / 256) % 8 == 0;
+        *wstat = (a.N / 256) % 8 == 0 ? 1 : (g_g16_tall ? 2 : 0);
         const double c2 = cost(224, 256, 1.0), c3 = cost(256, 256, 1.0), c8 = cost(128, 256, 1.2);
         return c2 <= c3 && c2 <= c8 ? 2 : (c3 <= c8 ? 3 : 8);
     }

@@ -33,14 +33,14 @@
     // 4 MiB L2 for the whole launch and W is fetched from HBM exactly once (the grouped order re-fetched the 26 MB GEGLU weight 7 x).
     const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM, nwg = ntm * ntn;
     int tm, tn;
-    if (wstat) {
+    if (wstat == 1) {
         const int cpx = ntn >> 3, xcd = bid_in & 7, idx = bid_in >> 3;           // host guarantees ntn % 8 == 0
         tn = xcd * cpx + idx % cpx; tm = idx / cpx;
     } else {
         int bid = bid_in;
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        constexpr int GRP = 4;
+        const int GRP = wstat == 2 ? 8 : 4;                         // (wstat 2, round 6 A/B: groups of 8 tile rows - the group's W panels are re-fetched half as often)
         const int gsz = GRP * ntn;
         const int first_m = (bid / gsz) * GRP;
         const int gm = (ntm - first_m) < GRP ? (ntm - first_m) : GRP;
