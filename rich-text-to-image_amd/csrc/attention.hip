@@ -525,6 +525,11 @@ int attention_units_plan_host(const int* q_src, const int* k_src, int B, int N, 
     }
     return G;
 }
+#ifdef RT_PROBE
+int g_attn_nw = 0;          // probe override: 4 or 8 waves per workgroup for the d = 64 self-attention kernel
+int g_attn_nofold = 0;      // probe override: the round-2 form (v_sub in the softmax) for A/B timing
+#endif
+
 void launch_attention(const AttnArgs& a_in, hipStream_t st) {
     AttnArgs a = a_in;
     for (int b = 0; b < RT_MAXB; ++b) {                              // one-stream launches: the unit is the batch entry
