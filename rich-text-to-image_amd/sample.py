@@ -7,6 +7,7 @@ tokenizer and text encoders are the caller's: none are available offline, SURVEY
 import argparse
 import json
 import os
+import sys
 import time
 
 import torch
@@ -303,9 +304,12 @@ def _dry_launch(a, rank, world, reqs, mine):
     ref = _StandInEncoder(True)
     ok = bool((unet.t == 0xA5).all() and (vae.t == 0x3C).all() and unet.bound and vae.bound and
               all(torch.equal(x, y) for e in encs for x, y in zip(e.p, ref.p)))
-    print(json.dumps({"rank": rank, "world": world, "requests_total": len(reqs), "requests_mine": [r["index"] for r in mine],
-                      "seeds_mine": [r["seed"] for r in mine], "pipeline_received": ok, "broadcast_collectives": launcher.LAST_BROADCAST_CALLS,
-                      "broadcast_s": seconds}), flush=True)
+    # ONE write per rank (line + newline together): the ranks share the launcher's stdout pipe, and print()'s separate newline write let two
+    # ranks' lines run into each other once in ~25 runs
+    sys.stdout.write(json.dumps({"rank": rank, "world": world, "requests_total": len(reqs), "requests_mine": [r["index"] for r in mine],
+                                 "seeds_mine": [r["seed"] for r in mine], "pipeline_received": ok, "broadcast_collectives": launcher.LAST_BROADCAST_CALLS,
+                                 "broadcast_s": seconds}) + "\n")
+    sys.stdout.flush()
     launcher.barrier()
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -87,6 +87,22 @@ def test_bench_reports_missing_gpus_clearly():
     assert line["value"] is None and "need 8 GPUs" in line["error"] and "need 8 GPUs" in out.stderr
 
 
+def _json_objects(text):
+    """Every JSON object in the ranks' shared stdout, also when two ranks' lines ran into each other (they share one pipe)."""
+    import json
+    dec, out, i = json.JSONDecoder(), [], 0
+    while True:
+        i = text.find("{", i)
+        if i < 0:
+            return out
+        try:
+            obj, end = dec.raw_decode(text, i)
+            out.append(obj)
+            i = end
+        except json.JSONDecodeError:
+            i += 1
+
+
 def test_sample_cli_gpus2_shards_requests_and_broadcasts_the_whole_pipeline(tmp_path):
     """BASELINE configs 4 / 5 as ONE command: `python -m rich_text_to_image_amd.sample --gpus 2 --rich_text_json A B --seeds ...`
     re-executes itself as 2 ranks under torch.distributed.run (launcher.self_launch, module form), deals the (JSON, seed) requests
@@ -102,7 +118,7 @@ def test_sample_cli_gpus2_shards_requests_and_broadcasts_the_whole_pipeline(tmp_
     out = subprocess.run([sys.executable, "-m", "rich_text_to_image_amd.sample", "--model", "SDXL", "--gpus", "2", "--dry_launch",
                           "--rich_text_json", str(a), "--seeds", "0", "1", "2", "3", "4"], env=env, capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = sorted((json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")), key=lambda d: d["rank"])
+    lines = sorted(_json_objects(out.stdout), key=lambda d: d["rank"])
     assert [l["rank"] for l in lines] == [0, 1] and all(l["world"] == 2 and l["requests_total"] == 5 for l in lines)
     assert lines[0]["requests_mine"] == [0, 2, 4] and lines[1]["requests_mine"] == [1, 3] and lines[1]["seeds_mine"] == [1, 3]
     assert all(l["pipeline_received"] and l["broadcast_collectives"] == 3 for l in lines)
