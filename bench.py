@@ -327,6 +327,7 @@ def other_config(args):
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": r["workload"], "baseline_config": args.config, "iterations_timed": r["iterations"]},
             "finite": r["finite"],
+            **({"one_pass_guidance": r["one_pass_guidance"]} if "one_pass_guidance" in r else {}),
             "roofline": {"bound": "mfma", "kernel": "whole step (UNet forwards + VAE guidance where configured)", "achieved": tf,
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_BF16_TFLOPS, "traffic": None},
             "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline_other(args.config),

@@ -166,6 +166,16 @@ def resolve_checkpoint(name_or_path, kind="SD"):
                             f". Pass a local directory (unet/, vae/, tokenizer*/, text_encoder*/) or set ${ENV_OVERRIDE[kind]}.")
 
 
+def load_guidance_vae(load_path, kind, device=0, latent_hw=None):
+    """A ONE-PASS bf16 VaeDecoder on the checkpoint's VAE weights, for `RegionDiffusionXL.guidance_vae` (sample.py --guidance_precision bf16):
+    the colour-guidance pass alone in one bf16 MFMA pass while the final decode stays on the precise engine."""
+    from .engine import SD_VAE_CONFIG, SDXL_VAE_CONFIG, VaeDecoder
+    vae_sd = load_state_dict_dir(os.path.join(load_path, "vae"))
+    vae_cfg = vae_config(os.path.join(load_path, "vae"), SD_VAE_CONFIG if kind == "SD" else SDXL_VAE_CONFIG)
+    hw = latent_hw or ((64, 64) if kind == "SD" else (128, 128))
+    return VaeDecoder(vae_cfg, hw[0], hw[1], device=device, state_dict=vae_sd, precise=False)
+
+
 def load_components(load_path, kind="SD", device=0, latent_hw=None, lora_path=None, lora_scale=1.0, weights=True):
     """Everything the facade constructors need from a diffusers-layout directory (unet/, vae/, tokenizer[_2]/, text_encoder[_2]/) as
     keyword arguments of RegionDiffusion / RegionDiffusionXL.  `latent_hw` sizes the VAE plan (default: the model's native size).

@@ -33,6 +33,11 @@ class RegionDiffusionXL:
             vae_scaling_factor = comp["vae_scaling_factor"]
         self.unet = HipUNet2DConditionModel(config or SDXL_CONFIG, unet_state_dict, self.device_index)
         self.vae = vae
+        # Optional (round 6): a second VaeDecoder used ONLY for the colour-guidance pass (xl.py:849-867).  The reference runs the SDXL VAE in
+        # fp32 because it overflows in fp16 (xl.py:856), and `vae` (precise = three bf16 MFMA passes) follows it.  A one-pass bf16 engine has
+        # fp32's range; over the 50-step guided schedule it leaves the latents where the precise engine leaves them (update-relative error
+        # against the fp32 oracle 3.05e-2 -> 1.16e-2 either way, LABNOTES R6.6) for 37 instead of 80 ms per step.  None: `vae` guides too.
+        self.guidance_vae = None
         self.text_encoders = text_encoders
         self.vae_scaling_factor = vae_scaling_factor
         self.vae_scale_factor = 8
@@ -123,7 +128,7 @@ class RegionDiffusionXL:
                         lat_ptr, eps_ptr = eng.state_ptrs()
 
                         def guide(lat_ptr=lat_ptr, eps_ptr=eps_ptr, t=t):
-                            self.vae.color_guidance(lat_ptr, eps_ptr, float(self.scheduler.alphas_cumprod[int(t)]), h, w, tfd['color_obj_atten'],
+                            (self.guidance_vae or self.vae).color_guidance(lat_ptr, eps_ptr, float(self.scheduler.alphas_cumprod[int(t)]), h, w, tfd['color_obj_atten'],
                                                     tfd['target_RGB'], tfd['color_guidance_weight'], tfd['color_obj_atten_all'])
                         if getattr(self, "split_image", False):          # rank 0 runs the VAE pass, the others receive the updated latents
                             from .launcher import guidance_from_rank0

@@ -156,8 +156,12 @@ def build_model(a, rank=0, local_rank=0, world=1):
     if world == 1:
         if a.model == 'SD':
             return RegionDiffusion(torch.device('cuda'), load_path=a.load_path, latent_hw=hw), 0.0
-        return RegionDiffusionXL(load_path=a.load_path or ("stabilityai/stable-diffusion-xl-base-1.0" if a.model == 'SDXL' else "Linaqruf/animagine-xl"),
-                                 latent_hw=hw), 0.0
+        xl_path = a.load_path or ("stabilityai/stable-diffusion-xl-base-1.0" if a.model == 'SDXL' else "Linaqruf/animagine-xl")
+        model = RegionDiffusionXL(load_path=xl_path, latent_hw=hw)
+        if getattr(a, 'guidance_precision', 'fp32') == 'bf16':
+            from .checkpoint import load_guidance_vae, resolve_checkpoint
+            model.guidance_vae = load_guidance_vae(resolve_checkpoint(xl_path, 'SDXL'), 'SDXL', 0, hw)
+        return model, 0.0
     from . import launcher
     from .checkpoint import load_components, resolve_checkpoint
     kind = 'SD' if a.model == 'SD' else 'SDXL'
@@ -200,6 +204,10 @@ def main(argv=None):
     p.add_argument('--segment_threshold', type=float, default=0.3)
     p.add_argument('--num_segments', type=int, default=9)
     p.add_argument('--inject_background', type=float, default=0.)
+    p.add_argument('--guidance_precision', type=str, default='fp32', choices=['fp32', 'bf16'],
+                   help='SDXL colour guidance: fp32 = the fp32-class VAE the reference guides with (xl.py:856; default), bf16 = the guidance pass '
+                        'alone on a one-pass bf16 VAE engine (same trajectory within the bf16 noise of the UNet, 37 instead of 80 ms per step); '
+                        'the final decode stays fp32-class either way')
     p.add_argument('--load_path', type=str, default=None,
                    help='diffusers-layout checkpoint directory; default: the hub ids of sample.py:26-30 resolved locally '
                         '(checkpoint.resolve_checkpoint: $RTDIFF_SD_PATH / $RTDIFF_SDXL_PATH / the Hugging Face hub cache)')

@@ -164,3 +164,30 @@ def test_distance_from_the_oracle_is_the_rounding_order_noise_floor(sdxl_model, 
         worst = max(worst, d_oracle / floor)
         assert d_oracle < 1.5 * floor + 2e-3, (k, d_oracle, floor)
     print(f"{name}: worst ratio (distance from the oracle) / (distance between two summation orders) = {worst:.2f}")
+
+
+def test_one_pass_guidance_vae_leaves_the_guided_trajectory_where_the_precise_one_does(sdxl_model):
+    """Round 6 option `RegionDiffusionXL.guidance_vae` (sample.py --guidance_precision bf16): the colour-guidance pass (xl.py:849-867) on a
+    one-pass bf16 VaeDecoder while the final decode stays on the precise engine.  Over config 5's guided schedule the latents must stay within
+    the SAME tolerances against the fp32 oracle, and within a hair of the precise-guidance run; the image (decoded precisely) keeps its bounds."""
+    from oracle import make_fullsize_golden as mg
+    from oracle.vae import SDXL_VAE_CONFIG
+    from rich_text_to_image_amd.engine import VaeDecoder
+    name = "config5"
+    mdl, fp = sdxl_model
+    base = RESULTS.get(name) or fc.compare(name, mdl, fp)
+    c = mg.CASES[name]
+    fast = VaeDecoder(SDXL_VAE_CONFIG, c["hw"], c["hw"], device=0, state_dict=mg.vae_weights(name), precise=False)
+    mdl.guidance_vae = fast
+    try:
+        r = fc.compare(name, mdl, fp)
+    finally:
+        mdl.guidance_vae = None
+        fast.close()
+    t_lat, t_psnr, t_mean, t_max = TOL[name]
+    u, ub = r["latent_update_rel_l2_by_iteration"], base["latent_update_rel_l2_by_iteration"]
+    print(f"{name}: update-relative error with one-pass guidance {dict((k, round(v, 5)) for k, v in u.items())} | precise {dict((k, round(v, 5)) for k, v in ub.items())}")
+    assert max(r["latent_rel_l2_by_iteration"].values()) < t_lat and max(u.values()) < UPDATE_TOL[name]
+    assert all(abs(u[k] - ub[k]) < 0.1 * ub[k] + 1e-3 for k in u), (u, ub)
+    pix = r["pixels_vs_oracle_image"]
+    assert pix["psnr_db"] > t_psnr and pix["max_abs"] <= t_max, pix

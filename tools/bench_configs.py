@@ -105,7 +105,15 @@ def config5():
                              negative_pooled_prompt_embeds=pooled[:1], output_type="latent", run_rich_text=True, text_format_dict=tfd,
                              use_guidance=True, inject_selfattn=0.0, inject_background=0.5).images
     out, dt = timed(lambda: run(steps), lambda: run(WARM_STEPS))
-    return dict(config=5, workload=f"SDXL 1024^2, R=4 (footnote+style+colour+base), {steps}-step Euler, CFG 7.5, colour guidance on 1 region through the fp32-class (precise) VAE, inject_background=0.5, 7 forwards/step",
+    # informational (round 6): the same loop with the guidance pass alone on a one-pass bf16 VAE engine (RegionDiffusionXL.guidance_vae);
+    # NOT the line's value - the reference guides through an fp32 VAE (xl.py:856)
+    m.guidance_vae = random_vae(SDXL_VAE_CONFIG, hw, hw, precise=False)
+    out2, dt2 = timed(lambda: run(steps), lambda: run(WARM_STEPS))
+    m.guidance_vae.close(); m.guidance_vae = None
+    fastg = dict(value=steps / dt2, unit="steps/s", finite=bool(torch.isfinite(out2).all()),
+                 latent_rel_l2_vs_precise_guidance=float(((out2 - out).float().norm() / out.float().norm()).item()),
+                 note="colour guidance on a one-pass bf16 VaeDecoder (sample.py --guidance_precision bf16), final decode unchanged; informational")
+    return dict(config=5, one_pass_guidance=fastg, workload=f"SDXL 1024^2, R=4 (footnote+style+colour+base), {steps}-step Euler, CFG 7.5, colour guidance on 1 region through the fp32-class (precise) VAE, inject_background=0.5, 7 forwards/step",
                 iterations=steps, seconds=dt, value=steps / dt, unit="steps/s", tflop_per_iteration=7 * 6.7612 + 21.2, finite=bool(torch.isfinite(out).all()))
 
 
