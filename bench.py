@@ -641,7 +641,9 @@ def main():
         legs = [("intra_image_split_estimate", split_estimate), ("graph_replay", graph_replay),
                 ("batched_2_requests", lambda: e2e.two_requests(eng, lambda sd_: synth_inputs(sd_, R, hw, dev), hw, nsched, args.steps, gs, isa, sched_index, ts, sig, init_sigma)),
                 ("plain_pass", lambda: e2e.plain_pass(eng, inp, hw)),
-                ("end_to_end", lambda: e2e.end_to_end(eng, hw))]
+                ("end_to_end", lambda: e2e.end_to_end(eng, hw)),
+                # informational: the same image with the colour-guidance pass on a one-pass bf16 VAE engine (opt-in, sample.py --guidance_precision bf16)
+                ("end_to_end_one_pass_guidance", lambda: e2e.end_to_end(eng, hw, one_pass_guidance=True))]
         for name, fn in legs:
             try:
                 extras[name] = fn()

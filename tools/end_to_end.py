@@ -133,7 +133,7 @@ RICH_TEXT = {"ops": [{"insert": "a "}, {"attributes": {"font": "slabo"}, "insert
                      {"attributes": {"link": "a wooden fence covered in snow"}, "insert": "fence"}, {"insert": "\n"}]}
 
 
-def end_to_end(eng, hw=128, steps=41, seed=6, inject_selfattn=0.5, num_segments=9, use_guidance=True):
+def end_to_end(eng, hw=128, steps=41, seed=6, inject_selfattn=0.5, num_segments=9, use_guidance=True, one_pass_guidance=False):
     """sample.generate on the full SDXL architecture (the bench engine is handed to the facade: same weights, no second arena)."""
     import sys
     import os
@@ -149,6 +149,8 @@ def end_to_end(eng, hw=128, steps=41, seed=6, inject_selfattn=0.5, num_segments=
     m = RegionDiffusionXL(device=eng.device, unet_state_dict="random0", config=SDXL_CONFIG, vae=vae, vae_scaling_factor=SDXL_VAE_CONFIG["scaling_factor"],
                           tokenizer=_WordTokenizer(), text_encoders=_synthetic_text_encoders(dev))
     m.unet._engines[(hw, hw)] = eng
+    if one_pass_guidance:                                            # opt-in: the guidance pass alone on a one-pass bf16 engine (LABNOTES R6.6)
+        m.guidance_vae = random_vae(SDXL_VAE_CONFIG, hw, hw, precise=False)
     param = {"text_input": RICH_TEXT, "height": 8 * hw, "width": 8 * hw, "guidance_weight": 5.0, "steps": steps, "noise_index": seed, "negative_prompt": ""}
     # time the clustering inside get_token_maps separately (is it worth a GPU kernel? VERDICT r3 item 3)
     import sklearn.cluster as skc
@@ -181,7 +183,9 @@ def end_to_end(eng, hw=128, steps=41, seed=6, inject_selfattn=0.5, num_segments=
     fin = bool(np.isfinite(np.asarray(rich.images[0], dtype=np.float32)).all())
     n_regions = len(m.masks) if m.masks is not None else None
     m.unet._engines = {}                                             # the engine belongs to the caller
-    return dict(seconds_total=total, plain_pass_s=t["plain"], token_maps_x2_s=t["token_maps"], rich_pass_s=t["rich"],
+    if m.guidance_vae is not None:
+        m.guidance_vae.close(); m.guidance_vae = None
+    return dict(seconds_total=total, one_pass_guidance=bool(one_pass_guidance), plain_pass_s=t["plain"], token_maps_x2_s=t["token_maps"], rich_pass_s=t["rich"],
                 spectral_clustering_s=spent["spectral_s"], spectral_clustering_calls=spent["calls"], vae_decode_s=t_dec,
                 steps=steps, regions=n_regions, finite=fin,
                 workload=f"sample.generate (sample.py:56-113): SDXL 1024^2, {steps} steps, CFG 5.0, inject_selfattn={inject_selfattn}, "
