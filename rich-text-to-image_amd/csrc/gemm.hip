@@ -1384,6 +1384,10 @@ static int splitk_slices(const GemmArgs& a) {
     const long tiles = a.split_tiles > 0 ? 4L * a.split_tiles : (long)cdiv(a.M, 128) * cdiv(a.N, 128);
     const int nk = cdiv(a.K, BK);
     if (tiles > 96 || nk < 8) return 1;
+    // Round 6 (tools/small_gemm_bench.py): at 256 tokens per stream a K <= 1280 projection is better off unsplit on the 64-row tiles of the
+    // 16x16x32 family than as three K slices + a reduction launch (3 x 256 x 1280 x 1280: 9.3 - 9.8 us against 16.8 - 17.1; the 64-token level
+    // keeps the slices: 12.0 against 15.9 us at 3 streams).  A function of ONE stream's shape, like the rest of the rule.
+    if (a.mode == A_DENSE && !a.weights_on_rows && a.rows_per_stream >= 256 && a.K <= 1280) return 1;
     int s = (int)(256 / tiles); if (s > 16) s = 16;
     if (s > nk / 4) s = nk / 4;
     return s < 2 ? 1 : s;
