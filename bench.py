@@ -405,13 +405,18 @@ def main():
     if args.dry_launch:
         return dry_launch(args)
     from rich_text_to_image_amd.engine import Engine, SDXL_CONFIG
-    rank, local_rank, world = launcher.init_distributed()
+    # RTDIFF_DIST_BACKEND / RTDIFF_FORCE_DEVICE (tests only): N ranks on ONE GPU over gloo - RCCL cannot put two ranks on a device, and every
+    # GPU lease of the build had one; the N > 1 control path of this file then runs end to end on real engines (tests/test_launcher_gpu.py)
+    rank, local_rank, world = launcher.init_distributed(os.environ.get("RTDIFF_DIST_BACKEND"))
     if world != args.gpus:
         sys.exit(f"bench: --gpus {args.gpus} but the launch environment says WORLD_SIZE={world}")
+    if "RTDIFF_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["RTDIFF_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
+    gloo = world > 1 and torch.distributed.get_backend() == "gloo"
     # N > 1: prove the collective path (64 MB pattern broadcast on the real backend, verified on every rank) before 5 GB of weights move
-    collective_check = launcher.collective_self_check() if world > 1 else None
+    collective_check = launcher.collective_self_check(device=torch.device("cpu") if gloo else None) if world > 1 else None
     if collective_check is not None and rank == 0:
         print(f"bench: collective self-check {collective_check}", file=sys.stderr, flush=True)
 
@@ -477,7 +482,7 @@ def main():
     torch.cuda.synchronize()
     dt_local = max(time.perf_counter() - t0, 1e-9)
     launcher.barrier()
-    dt = launcher.max_over_ranks(dt_local, device=dev if world > 1 else "cpu")
+    dt = launcher.max_over_ranks(dt_local, device=dev if (world > 1 and not gloo) else "cpu")
     final = eng.read_latents(hw, hw)
     finite = bool(torch.isfinite(final).all())
 
@@ -545,7 +550,7 @@ def main():
         for i in range(args.steps):
             eng.region_step(sched_index(i, args.steps), gs, isa, ibg, xl=True, elide=True)
         eng.synchronize(); torch.cuda.synchronize()
-        dt_e = launcher.max_over_ranks(time.perf_counter() - t0, device=dev if world > 1 else "cpu")
+        dt_e = launcher.max_over_ranks(time.perf_counter() - t0, device=dev if (world > 1 and not gloo) else "cpu")
         same = bool(torch.allclose(eng.read_latents(hw, hw), final, rtol=0, atol=0)) if args.steps <= nsched else None
         elided = dict(value=world * args.steps / dt_e, ms_per_step=dt_e / args.steps * 1e3, identical_latents=same)
 

@@ -77,3 +77,29 @@ def test_receiving_rank_path_arena_copy_then_mark_bound():
         e.set_prompts(emb, pooled, tid)
         outs.append(e.unet_forward(x, 300.0, [0, 1]))
     assert torch.equal(outs[0], outs[1])
+
+
+def test_bench_two_ranks_on_one_gpu_runs_the_whole_n_gt_1_path(tmp_path):
+    """`python bench.py --gpus 2` end to end with REAL engines: self-launch under torch.distributed.run, rendezvous, the collective self-check,
+    rank 0 draws and packs the weights, ONE arena broadcast, per-rank independent requests, barrier + max-over-ranks timing, rank 0 prints the
+    contract line with n_gpus = 2 and value = 2 x steps / max time, scaling "weak".  Both ranks sit on the ONE GPU of the box and the
+    collectives run over gloo (RTDIFF_DIST_BACKEND / RTDIFF_FORCE_DEVICE: RCCL cannot place two ranks on a device) - everything but the
+    transport is the path the driver's N = 2 / 4 / 8 runs take."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(RTDIFF_DIST_BACKEND="gloo", RTDIFF_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-extras"],
+                       env=env, capture_output=True, text=True, timeout=1500, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 alone prints the line"
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 2 and d["scaling"] == "weak" and d["unit"] == "steps/s"
+    assert d["value"] > 0 and abs(d["value"] - 2 * 4 / (d["ms_per_step"] * 4 * 1e-3)) < 1e-6 * d["value"]      # whole-job aggregate: 2 ranks x steps / max-over-ranks time
+    assert d["finite"] is True
+    cc = d["collective_check"]
+    assert cc["ok"] and cc["world"] == 2 and cc["backend"] == "gloo" and cc["bytes"] == 64 << 20
+    assert d["weight_broadcast_calls"] >= 1
