@@ -1020,7 +1020,11 @@ __global__ __launch_bounds__(512) void conv3p_kernel(GemmArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
 
-    const int nc = nc1 * (p.A_lo ? 3 : 1);
+    // split over the input-channel chunks (launch_conv3p_splitk): blockIdx.y owns the chunks [c_first, c_first + nc) and writes raw fp32
+    // partial sums; ring slots and halo parity follow the LOCAL chunk index, so one slice (gridDim.y == 1) is the code it always was
+    const int nc_all = nc1 * (p.A_lo ? 3 : 1);
+    const int c_first = gridDim.y > 1 ? (int)((long)blockIdx.y * nc_all / gridDim.y) : 0;
+    const int nc = gridDim.y > 1 ? (int)((long)(blockIdx.y + 1) * nc_all / gridDim.y) - c_first : nc_all;
     const int nsteps = nc * 9;
     auto wait_vm = [&](int n) {                     // n is wave-uniform: 0, 1, NB, NB + 1 or 2 NB
         if (n >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -1033,10 +1037,10 @@ __global__ __launch_bounds__(512) void conv3p_kernel(GemmArgs p) {
     static_assert(NB >= 1 && NB <= 3, "wait_vm covers up to 3 W pieces (+1 halo piece) per wave and step");
     // prologue: whole halo of chunk 0, W tiles of steps 0..2 (nsteps >= 9); halo + W(0) must have landed
 #pragma unroll
-    for (int i = 0; i < NAH; ++i) stage_halo(0, 0, i);
-    stage_w(0, 0, 0);
-    stage_w(1, 0, 1);
-    stage_w(2, 0, 2);
+    for (int i = 0; i < NAH; ++i) stage_halo(0, c_first, i);
+    stage_w(0, c_first, 0);
+    stage_w(1, c_first, 1);
+    stage_w(2, c_first, 2);
     wait_vm(2 * NB);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -1086,10 +1090,10 @@ __global__ __launch_bounds__(512) void conv3p_kernel(GemmArgs p) {
                     wait_vm((s + 2 < nsteps ? NB : 0) + (prev_had_halo ? 1 : 0));
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
-                    if (tap < NAH && next_chunk) stage_halo((chunk + 1) & 1, chunk + 1, tap);
+                    if (tap < NAH && next_chunk) stage_halo((chunk + 1) & 1, c_first + chunk + 1, tap);
                     if (s + 3 < nsteps) {
                         const int s3 = s + 3, c3 = s3 / 9, t3 = s3 - c3 * 9;
-                        stage_w(s3 % 3, c3, t3);
+                        stage_w(s3 % 3, c_first + c3, t3);
                     }
                     fa[nxt] = *(const bf16x8*)(narow + ((hi ^ nkeya) << 4));
 #pragma unroll
@@ -1103,6 +1107,13 @@ __global__ __launch_bounds__(512) void conv3p_kernel(GemmArgs p) {
         }
     }
     __syncthreads();
+    if (gridDim.y > 1) {
+        GemmArgs q = p;       // partial [slice][M][ldo] fp32 (the launcher passes EPI_F32 without bias / residual)
+        q.out = (float*)p.out + (size_t)blockIdx.y * p.M * p.ldo;
+        gemm_epilogue<EPI, 1, TN, NW, 2 * ASLOT + 3 * BSLOT, true>(q, acc, wave * 32, n0, lane, wave, smem,
+                                                                     (img * p.Hout + y0) * p.Wout + x0, p.Wout);
+        return;
+    }
     gemm_epilogue<EPI, 1, TN, NW, 2 * ASLOT + 3 * BSLOT, true>(p, acc, wave * 32, n0, lane, wave, smem,
                                                                  (img * p.Hout + y0) * p.Wout + x0, p.Wout);
 }
@@ -1234,6 +1245,7 @@ static int g_no_triple = 0;
 static int g_pair = 1;
 static int g_cross77 = 1;
 static int g_xblock = 0;      // measured slower than the separate launches (LABNOTES R5.2): opt-in
+static int g_conv3p_split = 3;   // round 6: under-filled patch-eligible 3x3 convolutions split over their channel chunks on the patch kernel; debug bit 28: on the split-K implicit GEMM (rounds 2 - 5)
 static int g_lnfold = 1;      // round 6: LayerNorm folded into its consumers (gemm16.hip, "LNF"); debug bit 22 restores the LayerNorm launches
 #ifdef RT_PROBE
 int g_conv3p_tn = 0;          // probe override of the patch kernel's column-tile count
@@ -1246,6 +1258,7 @@ void gemm_set_debug(int flags) {
     g_xattn = (flags & 16) ? 0 : 1;
     g_xblock = (flags & 65536) ? 1 : 0;                               // bit 16: the 640-channel cross-attention block as xblock.hip's ONE launch (opt-in: measured slower, LABNOTES R5.2)
     g_cross77 = (flags & 524288) ? 0 : 1;                             // bit 19: cross-attention on the round-4 kernels (EPI_XATTN / attn_kernel<CROSS>) instead of cross77_kernel
+    g_conv3p_split = (flags & 268435456) ? 0 : ((flags & 536870912) ? 1 : 3); /* bit 29: no two-halves rule for the 32x32 maps */                     // bit 28: under-filled 3x3 convolutions on the split-K implicit GEMM instead of the chunk-split patch kernel
     g_lnfold = (flags & 4194304) ? 0 : 1;                             // bit 22: LayerNorm launches + bf16 projections (rounds 1 - 5) instead of the folded form
     g_pair = (flags & 8192) ? 0 : 1;                                  // bit 13: attn1's Q|K and V^T projections as two launches instead of one grouped launch
     g_no_triple = ((flags & 128) ? 1 : 0) | ((flags & 256) ? 2 : 0) | ((flags & 512) ? 4 : 0) | ((flags & 32768) ? 8 : 0);   // bit 15: dense hi / lo contractions as three launches   // (bits 8 / 9: only the gemm16 / only the patch-kernel route)              // bit 7: the precise VAE's contractions as three launches (round 3) instead of one
@@ -1256,18 +1269,19 @@ bool gemm_xblock_enabled() { return g_xblock != 0 && g_use16 != 0 && g_force_cfg
 bool gemm_xattn_enabled() { return g_xattn != 0 && g_use16 != 0 && g_force_cfg < 0; }
 
 template <int EPI, bool UP2, int TN>
-static void launch_conv3p_tn(const GemmArgs& a, int ntm, hipStream_t st) {
+static void launch_conv3p_tn(const GemmArgs& a, int ntm, int slices, hipStream_t st) {
     constexpr int LDS = 2 * (UP2 ? 104 : 328) * 128 + 3 * 32 * TN * 128;
     static bool attr = false;
     if (!attr) {
         HIP_CHECK(hipFuncSetAttribute((const void*)conv3p_kernel<EPI, UP2, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr = true;
     }
-    hipLaunchKernelGGL((conv3p_kernel<EPI, UP2, TN>), dim3(ntm * cdiv(a.N, 32 * TN)), dim3(512), LDS, st, a);
+    hipLaunchKernelGGL((conv3p_kernel<EPI, UP2, TN>), dim3(ntm * cdiv(a.N, 32 * TN), slices), dim3(512), LDS, st, a);
 }
+// slices > 1 (launch_conv3p_splitk): every (patch, column tile) runs `slices` workgroups over disjoint input-channel chunks
 template <int EPI, bool UP2>
-static void launch_conv3p(const GemmArgs& a, hipStream_t st) {
-    const int ntm = (a.M / a.rows_per_batch) * (a.Hout / 16) * (a.Wout / 16);
+static void launch_conv3p(const GemmArgs& a, hipStream_t st, int slices = 1) {
+    const int ntm = (a.M / a.rows_per_batch) * (a.Hout / 16) * (a.Wout / 16) * slices;
     // Narrower column tiles when 160-channel tiles leave CUs idle or start a mostly empty second round (one workgroup per CU: 145 KB
     // of LDS).  Cost model fitted to tools/probes/conv_bench.hip on MI355X: a 96- / 64-channel workgroup takes 0.72 / 0.55 of a
     // 160-channel one; the big workgroups pay whole rounds of 256, the 64-channel ones 0.4 of the rounding.  Results do not
@@ -1289,10 +1303,10 @@ static void launch_conv3p(const GemmArgs& a, hipStream_t st) {
 #ifdef RT_PROBE
     if (g_conv3p_tn) tn = g_conv3p_tn;
 #endif
-    if (tn == 2) launch_conv3p_tn<EPI, UP2, 2>(a, ntm, st);
-    else if (tn == 3) launch_conv3p_tn<EPI, UP2, 3>(a, ntm, st);
-    else if (tn == 4) launch_conv3p_tn<EPI, UP2, 4>(a, ntm, st);
-    else launch_conv3p_tn<EPI, UP2, 5>(a, ntm, st);
+    if (tn == 2) launch_conv3p_tn<EPI, UP2, 2>(a, ntm / slices, slices, st);
+    else if (tn == 3) launch_conv3p_tn<EPI, UP2, 3>(a, ntm / slices, slices, st);
+    else if (tn == 4) launch_conv3p_tn<EPI, UP2, 4>(a, ntm / slices, slices, st);
+    else launch_conv3p_tn<EPI, UP2, 5>(a, ntm / slices, slices, st);
 }
 static bool conv_patch_eligible(const GemmArgs& a) {
     if (!g_conv_patch || a.mode == A_DENSE || a.rows_per_batch <= 0 || a.Hout % 16 || a.Wout % 16 || a.Cin % 64 || a.M % a.rows_per_batch) return false;
@@ -1393,7 +1407,29 @@ static int splitk_slices(const GemmArgs& a) {
     return s < 2 ? 1 : s;
 }
 
+// Round 6: a patch-eligible 3x3 convolution that the rule above would split (SD-v1.5's 16x16 maps: 3 - 5 images of ONE 16x16 patch each,
+// 1280 - 2560 input channels) is split over its INPUT-CHANNEL CHUNKS on the patch kernel instead of over K tiles of the 128x128 implicit
+// GEMM: the implicit GEMM copies 32 KB through the L2 -> LDS path per 128x128x64 step (every input pixel nine times), which is what
+// bounds its workgroups (0.8 us per K tile whatever the MFMA rate: 3 x 16^2 x 2560 -> 1280 took 91 us for 45 GFLOP), the patch kernel
+// 24.6 KB per 256x160x64 step.  Slices = chunks / ceil(chunks / 8): ~8 slices of equal length, a function of Cin alone, so a stream's
+// sum order does not depend on the batch.  0: the problem does not take this route.
+static int conv3p_split_slices(const GemmArgs& a) {
+    if (!g_conv3p_split || !g_splitk || a.A_lo || a.W_lo || a.pair_lo || !(a.mode == A_CONV3 || a.mode == A_CONV3_UP2) || !conv_patch_eligible(a)) return 0;
+    const int nc1 = a.Cin >> 6;
+    if (splitk_slices(a) <= 1) {
+        // one level up (SD-v1.5's 32x32 maps: 4 patches per image, 640 output channels): even the 64-channel column tiles give a nominal
+        // batch of four 160 workgroups (120 at config 1's three streams); two halves over the chunks fill the chip
+        const long u2 = 4L * (a.Hout >> 4) * (a.Wout >> 4) * cdiv(a.N, 64);
+        return (g_conv3p_split & 2) && u2 <= 192 && nc1 >= 8 ? 2 : 0;
+    }
+    const int per = cdiv(nc1, 8);
+    const int s = cdiv(nc1, per);
+    return s >= 2 ? s : 0;
+}
+
 size_t gemm_splitk_scratch_floats(const GemmArgs& a) {
+    const int SP = conv3p_split_slices(a);
+    if (SP > 1) return (size_t)SP * a.M * ((a.N + 3) & ~3);
     const int S = splitk_slices(a);
     return S > 1 ? (size_t)S * a.M * ((a.N + 3) & ~3) : 0;
 }
@@ -1453,6 +1489,24 @@ static void launch_gemm_splitk(const GemmArgs& a, int S, hipStream_t st) {
     const size_t work = (size_t)a.M * ((a.epi == EPI_GEGLU ? a.N / 2 : a.N) / 4);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<size_t>(cdiv((int)std::min<size_t>(work, 1u << 30), 256), 2048)), dim3(256), 0, st, r);
     HIP_CHECK(hipGetLastError());
+}
+
+static void launch_splitk_reduce(const GemmArgs& a, float* buf, int S, size_t slice, int ldp, hipStream_t st) {
+    ReduceArgs r{};
+    r.part = buf; r.S = S; r.slice = slice; r.M = a.M; r.N = a.N; r.ldp = ldp; r.epi = a.epi; r.bias = a.bias; r.res = a.res; r.ldres = a.ldres;
+    r.temb = a.temb; r.temb_ld = a.temb_ld; r.rows_per_batch = a.rows_per_batch; r.out = a.out; r.ldo = a.ldo;
+    const size_t work = (size_t)a.M * ((a.epi == EPI_GEGLU ? a.N / 2 : a.N) / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<size_t>(cdiv((int)std::min<size_t>(work, 1u << 30), 256), 2048)), dim3(256), 0, st, r);
+    HIP_CHECK(hipGetLastError());
+}
+static void launch_conv3p_splitk(const GemmArgs& a, int S, hipStream_t st) {
+    const int ldp = (a.N + 3) & ~3;
+    const size_t slice = (size_t)a.M * ldp, need = slice * S;
+    float* buf = (a.splitk_ws && a.splitk_ws_floats >= need) ? a.splitk_ws : splitk_fallback_buffer(need, st);
+    GemmArgs g = a;
+    g.epi = EPI_F32; g.bias = nullptr; g.res = nullptr; g.temb = nullptr; g.out = buf; g.ldo = ldp;
+    if (a.mode == A_CONV3_UP2) launch_conv3p<EPI_F32, true>(g, st, S); else launch_conv3p<EPI_F32, false>(g, st, S);
+    launch_splitk_reduce(a, buf, S, slice, ldp, st);
 }
 
 static void check_gemm_args(const GemmArgs& a) {
@@ -1554,6 +1608,10 @@ void launch_gemm(const GemmArgs& a, hipStream_t st) {
     // only the patch kernel's epilogue writes GemmArgs.pair_lo: every other route below and above would store fp32 into the bf16 hi plane
     const bool to_patch = conv_patch_eligible(a) && !patch_underfilled;
     if (a.pair_lo && !to_patch) throw rt_error(RT_E_INVALID, "gemm: pair output on a route without it");
+    if (g_force_cfg < 0 && (patch_underfilled || to_patch)) {
+        const int sp = conv3p_split_slices(a);
+        if (sp > 1) { launch_conv3p_splitk(a, sp, st); return; }
+    }
     if (to_patch) {
         if (a.mode == A_CONV3_UP2) { if (a.epi == EPI_F16) launch_conv3p<EPI_F16, true>(a, st); else launch_conv3p<EPI_F32, true>(a, st); }
         else switch (a.epi) {

@@ -352,6 +352,45 @@ def test_conv3x3_patch_kernel_column_tilings_are_bit_identical(H, Cin, Cout, sma
     report(f"patch conv {H}x{H}x{Cin}->{Cout} vs torch", full[: H * H].reshape(1, H, H, Cout), ref, **BF16_OUT)
 
 
+@pytest.mark.parametrize("mode,B,H,Cin,Cout,epi", [(1, 3, 16, 1280, 1280, 2), (1, 3, 16, 2560, 1280, 4), (1, 4, 16, 1920, 1280, 0), (1, 4, 16, 640, 1280, 1),
+                                                   (3, 3, 8, 1280, 1280, 4)])
+def test_conv3x3_patch_kernel_split_over_channel_chunks(mode, B, H, Cin, Cout, epi):
+    """Round 6: SD-v1.5's 16x16 maps (3 - 5 images of ONE patch each, 640 - 2560 input channels) cannot fill the chip; the patch kernel
+    runs them as ~8 slices over the input-channel chunks + the split-K reduction (every epilogue lives there) instead of the split-K
+    implicit GEMM (rt_op_gemm_debug bit 28 = the old route).  Against torch, against the old route, run to run, and an image alone
+    against the same image in the batch (the slicing is a function of Cin only)."""
+    from rich_text_to_image_amd.engine import load_library
+    lib = load_library()
+    x = rnd(B, Cin, H, H, seed=40)
+    w = rnd(Cout, Cin, 3, 3, seed=41, scale=(9 * Cin) ** -0.5)
+    bias = rnd(Cout, seed=42).to(DEV)
+    xb, wb = x.to(torch.bfloat16).float().to(DEV), w.to(torch.bfloat16).float().to(DEV)
+    Ho = H if mode == 1 else 2 * H
+    ref = F.conv2d(xb if mode == 1 else F.interpolate(xb, scale_factor=2.0, mode="nearest"), wb, bias, padding=1).permute(0, 2, 3, 1).reshape(B * Ho * Ho, Cout)
+    kw = {}
+    if epi == 2:
+        temb = rnd(B, Cout, seed=43).to(DEV)
+        kw = dict(temb=temb); ref = (ref.reshape(B, Ho * Ho, Cout) + temb[:, None, :]).reshape(B * Ho * Ho, Cout)
+    if epi in (1, 4):
+        res = rnd(B * Ho * Ho, Cout, seed=44).to(DEV)
+        res = res.to(torch.float16) if epi == 4 else res
+        kw = dict(res=res); ref = ref + res.float()
+    A, Wp = bf(x.permute(0, 2, 3, 1)), bf(_conv_weight_packed(w))
+    try:
+        out = gemm(A, Wp, bias, epi=epi, mode=mode, conv=(Ho, Ho), **kw)
+        assert torch.equal(out, gemm(A, Wp, bias, epi=epi, mode=mode, conv=(Ho, Ho), **kw)), "not run-to-run deterministic"
+        kw1 = {k: (v[:1] if k == "temb" else v[: Ho * Ho]).contiguous() for k, v in kw.items()}
+        one = gemm(A[:1].contiguous(), Wp, bias, epi=epi, mode=mode, conv=(Ho, Ho), **kw1)
+        assert torch.equal(out[: Ho * Ho], one), "an image alone and in the batch differ"
+        lib.rt_op_gemm_debug(1 << 28)
+        old = gemm(A, Wp, bias, epi=epi, mode=mode, conv=(Ho, Ho), **kw)
+    finally:
+        lib.rt_op_gemm_debug(0)
+    tol = {0: BF16_OUT, 2: BF16_OUT, 1: F32_OUT, 4: dict(atol=4e-3, rtol=1.5e-3)}[epi]
+    report(f"chunk-split patch conv mode{mode} {B}x{H}x{H}x{Cin}->{Cout} epi{epi} vs torch", out, ref, **tol)
+    report("chunk-split patch conv vs split-K implicit GEMM", out, old.float(), **tol)
+
+
 @pytest.mark.parametrize("B,H,W_,Cin,Cout", [(2, 16, 16, 64, 96), (1, 8, 24, 128, 200), (7, 32, 32, 1280, 1280)])
 def test_conv3x3_patch_kernel_upsample(B, H, W_, Cin, Cout):
     """Upsample2D folded into the patch kernel (10x10 input halo per 16x16 output patch) vs torch and vs the implicit-GEMM loader."""

@@ -59,4 +59,5 @@ for streams in (3, 5):
         for Cin in (1280, 2560):
             H = 8 if tokens == 64 else 16
             a, b = t(M, 1280, 9 * Cin, 0, conv=(streams, H, Cin)), t(M, 1280, 9 * Cin, 0, conv=(streams, H, Cin), flags=4)
-            print(f"conv  {streams} x {H}x{H} x {Cin} -> 1280        : default {a:6.1f} us | no split-K {b:6.1f} us")
+            c = t(M, 1280, 9 * Cin, 0, conv=(streams, H, Cin), flags=1 << 28)      # bit 28: the split-K implicit GEMM of rounds 2 - 5 instead of the chunk-split patch kernel
+            print(f"conv  {streams} x {H}x{H} x {Cin} -> 1280        : default {a:6.1f} us | no split-K {b:6.1f} us | split-K implicit GEMM {c:6.1f} us")
