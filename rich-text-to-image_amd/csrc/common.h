@@ -280,6 +280,7 @@ struct GroupNormArgs {
 };
 int groupnorm_rows_per_chunk(int HW);
 void launch_groupnorm(const GroupNormArgs& a, hipStream_t st);
+void groupnorm_set_fused(int on);                       // A/B: 0 = always the two-launch form (rt_op_gemm_debug bit 23)
 int groupnorm_nchunk(int HW);
 
 void launch_layernorm(const void* x, int x_f16 /* 0: fp32 rows, 1: fp16 rows (UNet trunk) */, const float* gamma, const float* beta,

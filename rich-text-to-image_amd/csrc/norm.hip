@@ -310,6 +310,187 @@ __global__ __launch_bounds__(512) void gn_apply_kernel(GroupNormArgs p) {
     }
 }
 
+// ---------------------------------------------------------------- GroupNorm in ONE launch (round 6): one workgroup per (batch entry, group)
+// The two-launch form above is a latency chain (LABNOTES R6.2): statistics kernel, kernel boundary, then an apply kernel whose every workgroup
+// first re-reduces the per-chunk partials - 15 us for the 2 MB tensors of SD-v1.5's 16x16 maps, 45 us for 7 x 32^2 x 1280.  Where ONE
+// workgroup can own a whole (batch entry, group) - HW x C/G elements, read twice: the second pass hits the L2 the first one filled - the
+// statistics never leave the workgroup: pass 1 sums (x, x^2) (per-thread fp32 over <= 8 rows in flight, then fp64: 64-lane butterfly +
+// 8-wave LDS step in a fixed order => deterministic and independent of the batch), pass 2 normalises, applies SiLU and writes the bf16
+// operand.  A thread owns ONE VW-channel vector column of the group (gamma / beta loaded once) and every nrl-th row.  Workgroup -> (b, g)
+// order: each XCD takes G / 8 NEIGHBOURING groups of every batch entry, so the 128-B lines that 2 - 3 groups share (40 - 160 B per row and
+// group) are fetched into one L2.  Leaves (mean, rstd) in partial[b][0][g] like gn_finalize_kernel (the VAE backward reads them there).
+template <int IT, int VW>
+__global__ __launch_bounds__(512) void gn_fused_kernel(GroupNormArgs p) {
+    __shared__ double sh_s[8], sh_q[8];
+    __shared__ float sh_stat[2];
+    const int C = p.C1 + p.C2, cpg = C / p.G, nvg = cpg / VW;
+    int g, b;
+    {
+        const int bid = blockIdx.x;
+        if ((p.G & 7) == 0) { const int gpx = p.G >> 3, x = bid & 7, i = bid >> 3; g = x * gpx + i % gpx; b = i / gpx; }
+        else { g = bid % p.G; b = bid / p.G; }
+    }
+    const int nrl = 512 / nvg;                                        // row lanes; threads >= nvg * nrl idle in the passes
+    const int tid = threadIdx.x, rl = tid / nvg, v = tid - rl * nvg;
+    const bool active = rl < nrl;
+    const int c = g * cpg + v * VW;
+    const size_t row0 = (size_t)b * p.HW;
+    constexpr int U = 8;
+    float s = 0.f, q = 0.f;
+    if (active) {
+        for (int r = rl; r < p.HW; r += U * nrl) {
+            float x[U][VW];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int rr = r + u * nrl < p.HW ? r + u * nrl : r;      // clamped, masked below (a branch per load serialises the loads)
+                loadv<IT, VW>(p.x1, p.x2, p.C1, p.C2, row0 + rr, c, x[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool ok = r + u * nrl < p.HW;
+#pragma unroll
+                for (int e = 0; e < VW; ++e) { const float t = ok ? x[u][e] : 0.f; s += t; q += t * t; }
+            }
+        }
+    }
+    double ds = (double)s, dq = (double)q;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) { ds += __shfl_xor(ds, m); dq += __shfl_xor(dq, m); }
+    if ((tid & 63) == 0) { sh_s[tid >> 6] = ds; sh_q[tid >> 6] = dq; }
+    __syncthreads();
+    if (tid == 0) {
+        double ts = 0.0, tq = 0.0;
+        for (int w = 0; w < 8; ++w) { ts += sh_s[w]; tq += sh_q[w]; }
+        const double n = (double)cpg * p.HW, mu = ts / n;
+        double var = tq / n - mu * mu;
+        if (var < 0) var = 0;
+        const float mf = (float)mu, rf = (float)(1.0 / sqrt(var + (double)p.eps));
+        sh_stat[0] = mf; sh_stat[1] = rf;
+        float* dst = p.partial + (size_t)b * p.nchunk * 2 * p.G + 2 * g;
+        dst[0] = mf; dst[1] = rf;
+    }
+    __syncthreads();
+    if (!active) return;
+    float sc[VW], sf[VW];
+    {
+        const float mean = sh_stat[0], rstd = sh_stat[1];
+#pragma unroll
+        for (int e = 0; e < VW; ++e) { sc[e] = rstd * p.gamma[c + e]; sf[e] = p.beta[c + e] - mean * sc[e]; }
+    }
+    for (int r = rl; r < p.HW; r += U * nrl) {
+        float x[U][VW];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int rr = r + u * nrl < p.HW ? r + u * nrl : r;
+            loadv<IT, VW>(p.x1, p.x2, p.C1, p.C2, row0 + rr, c, x[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (r + u * nrl >= p.HW) continue;
+            const size_t row = row0 + r + u * nrl;
+            float y[VW];
+#pragma unroll
+            for (int e = 0; e < VW; ++e) {
+                y[e] = x[u][e] * sc[e] + sf[e];
+                if (p.silu) y[e] = y[e] * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * y[e]));
+            }
+            storev<VW>(p.out + row * C + c, y);
+            if (p.raw_out) storev<VW>(p.raw_out + row * C + c, x[u]);
+        }
+    }
+}
+// The same launch when a thread's share of the (batch entry, group) is at most U rows (fp16 trunk; every SD-v1.5 GroupNorm below its 64^2
+// level, SDXL's 1280-channel GroupNorms): the rows stay in registers between the two passes - ONE memory round trip instead of two - and
+// gamma / beta are requested beside them.  Same summation order as gn_fused_kernel (rows u = 0 .. U-1 ascending, then the same reduction).
+template <int VW, int U>
+__global__ __launch_bounds__(512) void gn_fused_single_kernel(GroupNormArgs p) {
+    __shared__ double sh_s[8], sh_q[8];
+    __shared__ float sh_stat[2];
+    const int C = p.C1 + p.C2, cpg = C / p.G, nvg = cpg / VW;
+    int g, b;
+    {
+        const int bid = blockIdx.x;
+        if ((p.G & 7) == 0) { const int gpx = p.G >> 3, x = bid & 7, i = bid >> 3; g = x * gpx + i % gpx; b = i / gpx; }
+        else { g = bid % p.G; b = bid / p.G; }
+    }
+    const int nrl = 512 / nvg;
+    const int tid = threadIdx.x, rl = tid / nvg, v = tid - rl * nvg;
+    const bool active = rl < nrl && rl < p.HW;
+    const int c = g * cpg + v * VW;
+    const size_t row0 = (size_t)b * p.HW;
+    float x[U][VW], gm[VW], bt[VW];
+    float s = 0.f, q = 0.f;
+    if (active) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int rr = rl + u * nrl < p.HW ? rl + u * nrl : rl;
+            loadv<2, VW>(p.x1, p.x2, p.C1, p.C2, row0 + rr, c, x[u]);
+        }
+#pragma unroll
+        for (int h = 0; h < VW / 4; ++h) {
+            const float4 g4 = *(const float4*)(p.gamma + c + 4 * h), b4 = *(const float4*)(p.beta + c + 4 * h);
+            gm[4 * h] = g4.x; gm[4 * h + 1] = g4.y; gm[4 * h + 2] = g4.z; gm[4 * h + 3] = g4.w;
+            bt[4 * h] = b4.x; bt[4 * h + 1] = b4.y; bt[4 * h + 2] = b4.z; bt[4 * h + 3] = b4.w;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool ok = rl + u * nrl < p.HW;
+#pragma unroll
+            for (int e = 0; e < VW; ++e) { const float t = ok ? x[u][e] : 0.f; s += t; q += t * t; }
+        }
+    }
+    double ds = (double)s, dq = (double)q;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) { ds += __shfl_xor(ds, m); dq += __shfl_xor(dq, m); }
+    if ((tid & 63) == 0) { sh_s[tid >> 6] = ds; sh_q[tid >> 6] = dq; }
+    __syncthreads();
+    if (tid == 0) {
+        double ts = 0.0, tq = 0.0;
+        for (int w = 0; w < 8; ++w) { ts += sh_s[w]; tq += sh_q[w]; }
+        const double n = (double)cpg * p.HW, mu = ts / n;
+        double var = tq / n - mu * mu;
+        if (var < 0) var = 0;
+        const float mf = (float)mu, rf = (float)(1.0 / sqrt(var + (double)p.eps));
+        sh_stat[0] = mf; sh_stat[1] = rf;
+        float* dst = p.partial + (size_t)b * p.nchunk * 2 * p.G + 2 * g;
+        dst[0] = mf; dst[1] = rf;
+    }
+    __syncthreads();
+    if (!active) return;
+    float sc[VW], sf[VW];
+    {
+        const float mean = sh_stat[0], rstd = sh_stat[1];
+#pragma unroll
+        for (int e = 0; e < VW; ++e) { sc[e] = rstd * gm[e]; sf[e] = bt[e] - mean * sc[e]; }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (rl + u * nrl >= p.HW) continue;
+        const size_t row = row0 + rl + u * nrl;
+        float y[VW];
+#pragma unroll
+        for (int e = 0; e < VW; ++e) {
+            y[e] = x[u][e] * sc[e] + sf[e];
+            if (p.silu) y[e] = y[e] * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * y[e]));
+        }
+        storev<VW>(p.out + row * C + c, y);
+        if (p.raw_out) storev<VW>(p.raw_out + row * C + c, x[u]);
+    }
+}
+static int g_gn_fused = 1;
+void groupnorm_set_fused(int on) { g_gn_fused = on; }
+// 0: the two-launch form; else the vector width of the one-launch form.  A function of the shape of ONE batch entry.
+static int gn_fused_vw(const GroupNormArgs& a) {
+    if (!g_gn_fused || a.out_lo || a.raw_lo) return 0;
+    const int C = a.C1 + a.C2, cpg = C / a.G;
+    // measured (profiles/r6_gn_one_launch_bench.txt): wins while a thread's chain is <= ~20 rows (7 x 32^2 x 1280: 27.1 vs 43.1 us, x 2560: 33.8 vs
+    // 40.1); at 4096 rows (40 rows per thread, five dependent round trips per pass) the two-launch form's 448 workgroups are faster (53 vs 46 us)
+    if (a.HW > 1024 || (long)a.HW * cpg > 98304) return 0;
+    const int vw = (cpg % 8 == 0 && a.C1 % 8 == 0 && a.C2 % 8 == 0) ? 8 : ((cpg % 4 == 0) ? 4 : 0);
+    if (!vw || cpg / vw > 512) return 0;
+    return vw;
+}
+
 void launch_groupnorm(const GroupNormArgs& a, hipStream_t st) {
     const int C = a.C1 + a.C2;
     RT_REQUIRE(a.G >= 1 && a.G <= 32 && C % a.G == 0, "groupnorm: bad group count");
@@ -324,6 +505,21 @@ void launch_groupnorm(const GroupNormArgs& a, hipStream_t st) {
     const bool wide = a.C1 % 8 == 0 && a.C2 % 8 == 0;               // 8 channels per thread in the apply pass
     const GnShape sh8 = gn_block_shape(C >> 3);
     dim3 block8(sh8.tcols * sh8.nrl);
+    if (const int vw = gn_fused_vw(a)) {
+        dim3 gridf(a.G * a.B), blockf(512);
+        if (a.in_bf16 == 2) {
+            const int nvg = (C / a.G) / vw, rpt = cdiv(a.HW, 512 / nvg);      // rows per thread
+#define RT_GNS(VW_, U_) { hipLaunchKernelGGL((gn_fused_single_kernel<VW_, U_>), gridf, blockf, 0, st, a); HIP_CHECK(hipGetLastError()); return; }
+            if (vw == 8) { if (rpt <= 4) RT_GNS(8, 4) else if (rpt <= 8) RT_GNS(8, 8) else if (rpt <= 12) RT_GNS(8, 12) }
+            else { if (rpt <= 8) RT_GNS(4, 8) else if (rpt <= 16) RT_GNS(4, 16) else if (rpt <= 24) RT_GNS(4, 24) }
+#undef RT_GNS
+        }
+#define RT_GNF(IT) { if (vw == 8) hipLaunchKernelGGL((gn_fused_kernel<IT, 8>), gridf, blockf, 0, st, a); else hipLaunchKernelGGL((gn_fused_kernel<IT, 4>), gridf, blockf, 0, st, a); }
+        if (a.in_bf16 == 1) RT_GNF(1) else if (a.in_bf16 == 2) RT_GNF(2) else RT_GNF(0)
+#undef RT_GNF
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     GroupNormArgs aa = a;
     // (round 6, measured and dropped - profiles/r6_groupnorm_experiments.txt: a finer apply grid, four rows in flight, the finalize as its own
     //  launch, and the statistics kernel's last workgroup finalizing behind a ticket counter)

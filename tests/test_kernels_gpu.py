@@ -827,7 +827,11 @@ def test_cross_attn_block_fused_kernel_against_reference_arithmetic(B, N, Cc, H)
                                                       (2, 256, 320, 0, 32, False, False), (2, 1024, 96, 0, 8, True, True),
                                                       (1, 16384, 320, 0, 32, True, False),
                                                       (2, 64, 1280, 640, 32, True, "f16"), (2, 1024, 320, 0, 32, False, "f16"),
-                                                      (3, 256, 96, 32, 8, True, "f16")])
+                                                      (3, 256, 96, 32, 8, True, "f16"),
+                                                      # the one-launch form at the UNets' own shapes (SD-v1.5 16^2 / 32^2, SDXL 32^2 / 64^2)
+                                                      (3, 256, 1280, 1280, 32, True, "f16"), (7, 1024, 1280, 0, 32, False, "f16"),
+                                                      (2, 4096, 640, 0, 32, True, "f16"), (3, 1024, 640, 640, 32, True, "f16"),
+                                                      (2, 1024, 1280, 640, 32, True, "f16")])
 def test_groupnorm(B, HW, C1, C2, G, silu, bf16in):
     x1 = rnd(B, HW, C1, seed=60) * 2 + 0.5
     x2 = rnd(B, HW, C2, seed=61) - 0.3 if C2 else None
@@ -847,6 +851,18 @@ def test_groupnorm(B, HW, C1, C2, G, silu, bf16in):
         ref = F.silu(ref)
     report(f"groupnorm B{B} HW{HW} C{C1}+{C2}", out, ref, **BF16_OUT)
     report("groupnorm raw copy", raw, xc, atol=1e-2, rtol=8e-3)
+    # round 6: shapes where one workgroup owns a whole (batch entry, group) run as ONE launch; rt_op_gemm_debug bit 23 = the two-launch
+    # form.  Same statistics to fp32 rounding, and an image alone equals the same image in the batch in either form.
+    from rich_text_to_image_amd.engine import load_library
+    lib = load_library()
+    try:
+        lib.rt_op_gemm_debug(1 << 23)
+        two = groupnorm(xin1, xin2, G, gamma, beta, eps, silu)
+    finally:
+        lib.rt_op_gemm_debug(0)
+    report("groupnorm one launch vs two launches", out, two.float(), atol=2e-2, rtol=8e-3)
+    one = groupnorm(xin1[:1].contiguous(), xin2[:1].contiguous() if C2 else None, G, gamma, beta, eps, silu)
+    assert torch.equal(one, out[:1]), "an image alone and in the batch differ"
 
 
 @pytest.mark.parametrize("f16", [False, True])
