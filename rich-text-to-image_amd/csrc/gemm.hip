@@ -1245,6 +1245,7 @@ static int g_no_triple = 0;
 static int g_pair = 1;
 static int g_cross77 = 1;
 static int g_xblock = 0;      // measured slower than the separate launches (LABNOTES R5.2): opt-in
+static int g_split_small_rows = 1;      // (A/B, debug bit 30)
 static int g_conv3p_split = 3;   // round 6: under-filled patch-eligible 3x3 convolutions split over their channel chunks on the patch kernel; debug bit 28: on the split-K implicit GEMM (rounds 2 - 5)
 static int g_lnfold = 1;      // round 6: LayerNorm folded into its consumers (gemm16.hip, "LNF"); debug bit 22 restores the LayerNorm launches
 #ifdef RT_PROBE
@@ -1258,6 +1259,7 @@ void gemm_set_debug(int flags) {
     g_xattn = (flags & 16) ? 0 : 1;
     g_xblock = (flags & 65536) ? 1 : 0;                               // bit 16: the 640-channel cross-attention block as xblock.hip's ONE launch (opt-in: measured slower, LABNOTES R5.2)
     g_cross77 = (flags & 524288) ? 0 : 1;                             // bit 19: cross-attention on the round-4 kernels (EPI_XATTN / attn_kernel<CROSS>) instead of cross77_kernel
+    g_split_small_rows = (flags & 1073741824) ? 0 : 1;
     g_conv3p_split = (flags & 268435456) ? 0 : ((flags & 536870912) ? 1 : 3); /* bit 29: no two-halves rule for the 32x32 maps */                     // bit 28: under-filled 3x3 convolutions on the split-K implicit GEMM instead of the chunk-split patch kernel
     g_lnfold = (flags & 4194304) ? 0 : 1;                             // bit 22: LayerNorm launches + bf16 projections (rounds 1 - 5) instead of the folded form
     g_pair = (flags & 8192) ? 0 : 1;                                  // bit 13: attn1's Q|K and V^T projections as two launches instead of one grouped launch
@@ -1395,7 +1397,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ReduceArgs p) {
 static int splitk_slices(const GemmArgs& a) {
     // callers that batch independent streams pass the tile count of ONE stream; the rule then assumes a nominal batch of four
     // streams whatever the real batch is, so every stream sees the same K slicing alone or in any batch
-    const long tiles = a.split_tiles > 0 ? 4L * a.split_tiles : (long)cdiv(a.M, 128) * cdiv(a.N, 128);
+    long tiles = a.split_tiles > 0 ? 4L * a.split_tiles : (long)cdiv(a.M, 128) * cdiv(a.N, 128);
+    // streams of fewer than 128 rows (SD-v1.5's 8x8 maps: 64 tokens) SHARE 128-row tiles: four of them are two row tiles, not four -
+    // the nominal count above halved the slices such problems need to fill the chip (3 x 8^2 x 1280 -> 1280: 120 workgroups)
+    const int rows1 = a.mode == A_DENSE ? a.rows_per_stream : a.rows_per_batch;
+    if (g_split_small_rows && a.split_tiles > 0 && !a.weights_on_rows && rows1 > 0 && rows1 < 128) tiles = (long)cdiv(4 * rows1, 128) * cdiv(a.N, 128);
     const int nk = cdiv(a.K, BK);
     if (tiles > 96 || nk < 8) return 1;
     // Round 6 (tools/small_gemm_bench.py): at 256 tokens per stream a K <= 1280 projection is better off unsplit on the 64-row tiles of the
