@@ -240,6 +240,7 @@ void launch_cross77(const AttnArgs& a, hipStream_t st);
 bool gemm_cross77_enabled();      // debug bit 19 clear
 int attention_units_plan_host(const int* q_src, const int* k_src, int B, int N, int DP, int mode, int* launch_of, int* unit_of, int* members_of);   // host-only: the partition launch_attention would take
 void gemm16_set_tall(int on);        // (A/B) rt_op_gemm_debug bit 27
+void gemm16_set_deep(int on);        // (A/B) rt_op_gemm_debug bit 12 clears the 5-slot ring of the 64 x 160 tiles
 void attention_set_units(int mode);  // shared-probability units of the self-attention launches (attention.hip, launch_attention_units; rt_op_gemm_debug bits 24 - 26)
 void attention_set_prio(int on);   // s_setprio around the MFMA phases of attn_kernel (default on; rt_op_gemm_debug bit 14 clears it)
 

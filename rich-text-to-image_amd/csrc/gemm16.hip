@@ -369,8 +369,10 @@ void gemm16_chain_read_times(long long* dst) { HIP_CHECK(hipMemcpyFromSymbol(dst
 void gemm16_chain_reset() { unsigned z[64] = {}; HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_chain_flags), z, sizeof(z))); }
 #endif
 
+int g_g16_deep = 1;            // (A/B, rt_op_gemm_debug bit 12 clears it) 64 x 160 tiles on a 5-slot ring where K gives >= 8 tiles
 int g_g16_tall = 0;            // (A/B, rt_op_gemm_debug bit 27) GEGLU launches that cannot take the W-stationary order run groups of 8 tile rows
 void gemm16_set_tall(int on) { g_g16_tall = on; }
+void gemm16_set_deep(int on) { g_g16_deep = on; }
 // ---------------------------------------------------------------------------------------------- launch
 struct G16Var { int BM, BN, WK, S, geglu_ok; };
 // variant ids (probe / tests).  Within a class (A: WK = 1, B: WK = 2) all variants are bit-identical per output element.
@@ -431,7 +433,7 @@ static void launch_ln(const GemmArgs& a, int v, int wstat, int lnf, hipStream_t 
             case 1: launch_v<A_DENSE, EPI_F16, 4, 5, 2, 2, 2, 3, RT_LNF_EMIT>(a, wstat, st); return;
             case 4: launch_v<A_DENSE, EPI_F16, 7, 5, 2, 4, 1, 2, RT_LNF_EMIT>(a, wstat, st); return;
             case 5: launch_v<A_DENSE, EPI_F16, 8, 5, 2, 4, 1, 2, RT_LNF_EMIT>(a, wstat, st); return;
-            case 9: launch_v<A_DENSE, EPI_F16, 2, 5, 2, 2, 2, 3, RT_LNF_EMIT>(a, wstat, st); return;
+            case 9: if (g_g16_deep && a.K >= 8 * BK16) launch_v<A_DENSE, EPI_F16, 2, 5, 2, 2, 2, 5, RT_LNF_EMIT>(a, wstat, st); else launch_v<A_DENSE, EPI_F16, 2, 5, 2, 2, 2, 3, RT_LNF_EMIT>(a, wstat, st); return;
             case 10: launch_v<A_DENSE, EPI_F16, 4, 5, 2, 4, 1, 2, RT_LNF_EMIT>(a, wstat, st); return;
             default: launch_v<A_DENSE, EPI_F16, 2, 5, 2, 4, 1, 3, RT_LNF_EMIT>(a, wstat, st); return;
         }
@@ -460,7 +462,7 @@ static void launch_ln(const GemmArgs& a, int v, int wstat, int lnf, hipStream_t 
         case 4: launch_v<A_DENSE, EPI_BF16, 7, 5, 2, 4, 1, 2, RT_LNF_ROWS>(a, wstat, st); return;
         case 5: launch_v<A_DENSE, EPI_BF16, 8, 5, 2, 4, 1, 2, RT_LNF_ROWS>(a, wstat, st); return;
         case 8: launch_v<A_DENSE, EPI_BF16, 4, 4, 2, 4, 1, 3, RT_LNF_ROWS>(a, wstat, st); return;
-        case 9: launch_v<A_DENSE, EPI_BF16, 2, 5, 2, 2, 2, 3, RT_LNF_ROWS>(a, wstat, st); return;
+        case 9: if (g_g16_deep && a.K >= 8 * BK16) launch_v<A_DENSE, EPI_BF16, 2, 5, 2, 2, 2, 5, RT_LNF_ROWS>(a, wstat, st); else launch_v<A_DENSE, EPI_BF16, 2, 5, 2, 2, 2, 3, RT_LNF_ROWS>(a, wstat, st); return;
         case 10: launch_v<A_DENSE, EPI_BF16, 4, 5, 2, 4, 1, 2, RT_LNF_ROWS>(a, wstat, st); return;
         default: launch_v<A_DENSE, EPI_BF16, 2, 5, 2, 4, 1, 3, RT_LNF_ROWS>(a, wstat, st); return;
     }
@@ -493,7 +495,7 @@ static void launch_e(const GemmArgs& a, int v, int wstat, hipStream_t st) {
                 case 5: launch_v<MODE, EPI, 8, 5, 2, 4, 1, 2>(a, wstat, st); return;
                 case 6: launch_v<MODE, EPI, 5, 7, 2, 2, 2, 3>(a, wstat, st); return;
                 case 7: launch_v<MODE, EPI, 5, 4, 2, 2, 2, 3>(a, wstat, st); return;
-                case 9: launch_v<MODE, EPI, 2, 5, 2, 2, 2, 3>(a, wstat, st); return;
+                case 9: if (g_g16_deep && a.K >= 8 * BK16 && !a.A_lo) launch_v<MODE, EPI, 2, 5, 2, 2, 2, 5>(a, wstat, st); else launch_v<MODE, EPI, 2, 5, 2, 2, 2, 3>(a, wstat, st); return;
                 case 10: launch_v<MODE, EPI, 4, 5, 2, 4, 1, 2>(a, wstat, st); return;
                 case 11: launch_v<MODE, EPI, 2, 5, 2, 4, 1, 3>(a, wstat, st); return;
                 case 12: launch_v<MODE, EPI, 5, 2, 2, 2, 2, 3>(a, wstat, st); return;

@@ -6,14 +6,14 @@
 // its problem's grid).  LNF: LayerNorm fold (gemm16.hip, "LNF"): 0 none, 1 / 3 consumer (token rows / token columns), 2 producer of the partials.
     constexpr int NW = WM * WN * WK;                       // 8 waves (two per SIMD) or 4 waves (one per SIMD, 512 registers each)
     static_assert(NW == 8 || NW == 4, "4 or 8 waves");
-    static_assert(WK == 1 || (WK == 2 && S == 3), "K split over at most two waves (3-slot ring)");
+    static_assert(WK == 1 || (WK == 2 && (S == 3 || S == 5)), "K split over at most two waves (3-slot ring; 5 slots for the 64-row tiles)");
     constexpr int BM = WM * TMW * 16, BN = WN * TNW * 16;
     constexpr int STAGE = (BM + BN) * 128;                 // bytes per ring slot: A rows then W rows, 128 B (64 k) each
     constexpr int GA = BM / 8, GB = BN / 8, GT = GA + GB;  // 8-row groups = one wave-wide LDS-DMA each
     constexpr int PW = (GT + NW - 1) / NW;                 // LDS-DMA pieces per wave and K tile
     constexpr int KS = 2 / WK;                             // 32-deep k steps per K tile and wave
     static_assert(EPI != EPI_GEGLU || TNW % 4 == 0, "GEGLU: a wave owns whole packed 64-column blocks [32 value | 32 gate]");
-    static_assert((S - 2) * PW <= 63 && S >= 2 && S <= 3, "ring depth");
+    static_assert((S - 2) * PW <= 63 && S >= 2 && (S <= 3 || (S == 5 && WK == 2)), "ring depth");
     constexpr bool LNC = LNF == RT_LNF_ROWS || LNF == RT_LNF_COLS;    // consumer of a folded LayerNorm: fp16 operands, epilogue correction
     static_assert(!LNC || (MODE == A_DENSE && (EPI == EPI_BF16 || EPI == EPI_GEGLU)), "LayerNorm fold: dense bf16-output / GEGLU consumers");
     static_assert(LNF != RT_LNF_EMIT || (MODE == A_DENSE && EPI == EPI_F16 && TNW == 5), "LayerNorm partials: fp16-trunk epilogue, 80-column wave tiles");
@@ -278,7 +278,22 @@
     // the min(S-2, nk-2-t) younger tiles that were issued: no dummy copies, nothing to drain behind the loop.
     if constexpr (KS == 1) {
         // K-split class: CUR alternates per tile, so tiles run in pairs; the host guarantees an even tile count, S = 3, nk >= 4
+        // (S = 5, round 6: the 64-row tiles of small batches - their K tile is 0.13 us of MFMA work against an L2 / fabric round trip of
+        //  ~1.5 us, so the loop runs at (round trip) / (tiles in flight): four in flight instead of two; nk >= 8, same k order and bits)
         int t = 0;
+        if constexpr (S == 5) {
+            using C3 = std::integral_constant<int, 3>;
+            for (; t + 8 <= nk; t += 2) {
+                kstep(t, cur_off, nxt_off, C0{}, C0{}, C2{}, C1{}, C3{}); advance();
+                kstep(t + 1, cur_off, nxt_off, C1{}, C0{}, C2{}, C1{}, C3{}); advance();
+            }
+            kstep(t, cur_off, nxt_off, C0{}, C0{}, C2{}, C1{}, C3{}); advance();         // t = nk-6: the last refill (tile nk-1)
+            kstep(t + 1, cur_off, nxt_off, C1{}, C0{}, C2{}, C0{}, C3{}); advance();     // nk-5: tiles nk-3 .. nk-1 may stay in flight
+            kstep(t + 2, cur_off, nxt_off, C0{}, C0{}, C2{}, C0{}, C2{}); advance();     // nk-4
+            kstep(t + 3, cur_off, nxt_off, C1{}, C0{}, C2{}, C0{}, C1{}); advance();     // nk-3
+            kstep(t + 4, cur_off, nxt_off, C0{}, C0{}, C2{}, C0{}, C0{}); advance();     // nk-2
+            kstep(t + 5, cur_off, nxt_off, C1{}, C0{}, C0{}, C0{}, C0{});                // nk-1
+        } else {
         for (; t + 6 <= nk; t += 2) {
             kstep(t, cur_off, nxt_off, C0{}, C0{}, C2{}, C1{}, CS2{}); advance();
             kstep(t + 1, cur_off, nxt_off, C1{}, C0{}, C2{}, C1{}, CS2{}); advance();
@@ -287,6 +302,7 @@
         kstep(t + 1, cur_off, nxt_off, C1{}, C0{}, C2{}, C0{}, C1{}); advance();         // nk-3: tile nk-1 may stay in flight
         kstep(t + 2, cur_off, nxt_off, C0{}, C0{}, C2{}, C0{}, C0{}); advance();         // nk-2
         kstep(t + 3, cur_off, nxt_off, C1{}, C0{}, C0{}, C0{}, C0{});                    // nk-1
+        }
     } else {
         int t = 0;
         for (; t + S < nk; ++t) {
