@@ -185,6 +185,12 @@ int rt_op_attention_units_plan(const int* q_src, const int* k_src, int B, int to
  * pixels.  *w_stationary = 1 when the launch uses the W-stationary tile -> XCD order.  The summation CLASS of the answer ({2,3,4,5,8,10,11} /
  * {0,1,9} / {6,7,12} / -1) never depends on `streams`; inside a class the tile shape follows the batch. */
 int rt_op_gemm16_pick(int conv3x3, int epi, int streams, int rows_per_stream, int N, int K_or_Cin, int weights_on_rows, int* w_stationary);
+/* Host-only query of the split rule of csrc/gemm.hip for problems that cannot fill the chip (no device needed; tests/test_split_plan.py):
+ * *route 0: one launch | 1: K slices of the 128x128 (implicit) GEMM + reduction launch | 2 (round 6): the 16x16-patch convolution kernel
+ * split over its input-channel chunks + reduction launch; *slices: how many.  conv3x3: 0 dense (K_or_Cin = K), 1 stride-1 3x3 convolution,
+ * 3 the nearest-2x up-sample folded in (rows_per_stream = OUTPUT pixels, a square map).  Route and slice count are functions of ONE
+ * stream's shape (a nominal batch of four), never of `streams`: a stream's k order does not depend on the batch. */
+int rt_op_split_plan(int conv3x3, int epi, int streams, int rows_per_stream, int N, int K_or_Cin, int* route, int* slices);
 /* One tile variant of the 16x16x32-MFMA GEMM family (csrc/gemm16.hip; tests / micro-benchmarks - rt_op_gemm picks by shape):
  * 0: 224x160 K-split  1: 128x160 K-split  2: 224x256  3: 256x256  4: 224x320  5: 256x320  6: 160x224 K-split (V^T)  7: 160x128 K-split
  * 8: 128x256  9: 64x160 K-split  10: 128x320  11: 64x320  12: 160x64 K-split (V^T) - 9..12: the small batches of the plain pass / SD-v1.5;

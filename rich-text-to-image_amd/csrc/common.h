@@ -193,6 +193,7 @@ bool xblock_supported(int C, int H, int DP, int tokens);
 void launch_xblock(const XBlockArgs& a, hipStream_t st);
 void launch_gemm(const GemmArgs& a, hipStream_t st);
 bool gemm_pair_output_ok(const GemmArgs& a);            // host-only: launch_gemm would run this problem on a kernel that can write GemmArgs.pair_lo
+void gemm_split_plan(const GemmArgs& a, int* route, int* slices);      // host-only: 0 one launch / 1 K slices + reduction / 2 chunk-split patch convolution + reduction
 size_t gemm_splitk_scratch_floats(const GemmArgs& a);   // fp32 partial sums launch_gemm needs for this problem (0: not split)
 void gemm_force_config(int cfg);   // -1: shape-based choice; 0..8: force a gemm.hip tile configuration (also keeps gemm16.hip out)
 void gemm_set_debug(int d);        // bit 0: eligible 3x3 convolutions through the implicit-GEMM kernels; bit 1: keep gemm16.hip out; bit 4: no fused cross-attention

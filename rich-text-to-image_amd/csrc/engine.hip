@@ -1414,6 +1414,26 @@ int rt_op_attention(const void* Q, int ldq, const void* K, int ldk, const void* 
 }
 // The shape rule of csrc/gemm16.hip as a host-only query (no device needed): which tile variant a problem takes (-1: stays on gemm.hip /
 // the patch convolution) and whether it uses the W-stationary tile -> XCD order.  `streams` images / streams of rows_per_stream rows each.
+int rt_op_split_plan(int conv3x3, int epi, int streams, int rows_per_stream, int N, int K_or_Cin, int* route, int* slices) {
+    try {
+        GemmArgs g{};
+        g.epi = epi; g.N = N;
+        if (conv3x3) {
+            int side = 1; while (side * side < rows_per_stream) ++side;
+            if (side * side != rows_per_stream) return RT_E_INVALID;                // square maps only in this query
+            g.mode = conv3x3 == 3 ? A_CONV3_UP2 : A_CONV3; g.Cin = K_or_Cin; g.K = 9 * K_or_Cin; g.ldw = g.K; g.ldo = N;
+            g.Hout = g.Wout = side; g.Hin = g.Win = conv3x3 == 3 ? side / 2 : side; g.rows_per_batch = rows_per_stream; g.M = streams * rows_per_stream;
+        } else {
+            g.mode = A_DENSE; g.K = K_or_Cin; g.lda = g.K; g.ldw = g.K; g.rows_per_stream = rows_per_stream; g.M = streams * rows_per_stream;
+        }
+        g.split_tiles = cdiv(rows_per_stream, 128) * cdiv(N, 128);                  // what the engine passes (engine.hip: conv3 / gemm)
+        int r = 0, sl = 1;
+        gemm_split_plan(g, &r, &sl);
+        if (route) *route = r;
+        if (slices) *slices = sl;
+        return RT_OK;
+    } catch (...) { return RT_E_INVALID; }
+}
 int rt_op_gemm16_pick(int conv3x3, int epi, int streams, int rows_per_stream, int N, int K_or_Cin, int weights_on_rows, int* w_stationary) {
     try {
         GemmArgs g{};

@@ -1434,6 +1434,15 @@ static int conv3p_split_slices(const GemmArgs& a) {
     return s >= 2 ? s : 0;
 }
 
+// host-only: what launch_gemm does with an under-filled problem.  route 0: one launch, 1: K slices of the 128x128 implicit GEMM / dense GEMM
+// + reduction, 2: the patch kernel split over input-channel chunks + reduction
+void gemm_split_plan(const GemmArgs& a, int* route, int* slices) {
+    const int sp = conv3p_split_slices(a);
+    if (sp > 1) { *route = 2; *slices = sp; return; }
+    const int s = g_splitk ? splitk_slices(a) : 1;
+    *route = s > 1 ? 1 : 0; *slices = s;
+}
+
 size_t gemm_splitk_scratch_floats(const GemmArgs& a) {
     const int SP = conv3p_split_slices(a);
     if (SP > 1) return (size_t)SP * a.M * ((a.N + 3) & ~3);

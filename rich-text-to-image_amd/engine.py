@@ -70,7 +70,7 @@ _SYMBOLS = [
     "rt_attn_store_read", "rt_attn_module_count", "rt_attn_module_info", "rt_get_state_ptrs", "rt_background_blend", "rt_vae_create", "rt_vae_destroy",
     "rt_vae_last_error", "rt_vae_weight_count", "rt_vae_weight_info", "rt_vae_bind_weight", "rt_vae_synchronize", "rt_vae_decode",
     "rt_vae_color_guidance", "rt_vae_arena_info", "rt_vae_arena_mark_bound", "rt_op_cast_bf16", "rt_op_attention_probs_avg", "rt_op_embed", "rt_op_activation", "rt_op_causal_attention",
-    "rt_op_cross_attn_block", "rt_op_gemm16_variant", "rt_op_gemm16_pick", "rt_profile_read2", "rt_op_gemm_qk_vt", "rt_op_gemm_pair_pick",
+    "rt_op_cross_attn_block", "rt_op_gemm16_variant", "rt_op_gemm16_pick", "rt_op_split_plan", "rt_profile_read2", "rt_op_gemm_qk_vt", "rt_op_gemm_pair_pick",
     "rt_region_step_part", "rt_region_step_finish", "rt_eps_info", "rt_op_split_range",
     "rt_op_ln_gemm", "rt_op_gemm_emit_partials", "rt_op_ln_partials", "rt_op_probes_built", "rt_op_attention_units_plan",
     "rt_plain_step_part", "rt_plain_step_finish",
