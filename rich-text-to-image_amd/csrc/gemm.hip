@@ -921,6 +921,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
 // Requirements: mode A_CONV3 (stride 1, pad 1), H % 16 == 0, W % 16 == 0, Cin % 64 == 0.
 // UP2: the nearest-2x upsample of Upsample2D (resnet.py:137-172) folded in: the 16x16 OUTPUT patch reads a 10x10 input halo
 // (input pixel = output pixel >> 1), so the halo is 100 rows instead of 324.
+// (Round 6, measured and dropped: waves as 4 pixel groups x 2 column halves at TN = 4 - 2 A + 2 W fragments per 4 MFMAs instead of 1 + 4, 20 % less
+//  LDS traffic, bit-identical: precise VAE guidance call 82.9 vs 83.2 ms, single pass 38.2 vs 37.8 ms.  The loop is not bound by LDS bytes.)
 // TN = 32-channel column tiles per workgroup (BN = 32 TN output channels): 5 by default; 3 or 2 when a launch would otherwise put
 // fewer workgroups on the chip than it has CUs (SD-v1.5: 48-160 workgroups at BN = 160).  The k order does not depend on TN, so
 // every TN gives bit-identical results and the launcher may pick it from the actual batch size.
@@ -1246,6 +1248,7 @@ static int g_pair = 1;
 static int g_cross77 = 1;
 static int g_xblock = 0;      // measured slower than the separate launches (LABNOTES R5.2): opt-in
 static int g_split_small_rows = 1;      // (A/B, debug bit 30)
+static int g_conv3p_tn4 = 1;     // (A/B, debug bit 10)
 static int g_conv3p_split = 3;   // round 6: under-filled patch-eligible 3x3 convolutions split over their channel chunks on the patch kernel; debug bit 28: on the split-K implicit GEMM (rounds 2 - 5)
 static int g_lnfold = 1;      // round 6: LayerNorm folded into its consumers (gemm16.hip, "LNF"); debug bit 22 restores the LayerNorm launches
 #ifdef RT_PROBE
@@ -1260,6 +1263,7 @@ void gemm_set_debug(int flags) {
     g_xblock = (flags & 65536) ? 1 : 0;                               // bit 16: the 640-channel cross-attention block as xblock.hip's ONE launch (opt-in: measured slower, LABNOTES R5.2)
     g_cross77 = (flags & 524288) ? 0 : 1;                             // bit 19: cross-attention on the round-4 kernels (EPI_XATTN / attn_kernel<CROSS>) instead of cross77_kernel
     g_split_small_rows = (flags & 1073741824) ? 0 : 1;
+    g_conv3p_tn4 = (flags & 1024) ? 0 : 1;
     g_conv3p_split = (flags & 268435456) ? 0 : ((flags & 536870912) ? 1 : 3); /* bit 29: no two-halves rule for the 32x32 maps */                     // bit 28: under-filled 3x3 convolutions on the split-K implicit GEMM instead of the chunk-split patch kernel
     g_lnfold = (flags & 4194304) ? 0 : 1;                             // bit 22: LayerNorm launches + bf16 projections (rounds 1 - 5) instead of the folded form
     g_pair = (flags & 8192) ? 0 : 1;                                  // bit 13: attn1's Q|K and V^T projections as two launches instead of one grouped launch
@@ -1299,7 +1303,8 @@ static void launch_conv3p(const GemmArgs& a, hipStream_t st, int slices = 1) {
     double best = c5;
     // 128-channel column tiles where the channel count is a multiple of 128 but not of 160 (the VAE's 128 / 256 / 512-wide layers: a
     // 160-wide tile would multiply 20 - 37 % clamped duplicate columns); round 4, same k order as every other TN
-    if (a.N % 128 == 0 && a.N % 160 != 0) { const double c4 = cost(4, 0.86); if (c4 < best * 0.97) { tn = 4; best = c4; } }
+    // (round 6: chunk-split launches may take them at any multiple of 128 - 3 images x 8 slices x 10 tiles of 128 channels are 240 workgroups where 160-channel tiles give 192)
+    if (a.N % 128 == 0 && (a.N % 160 != 0 || (slices > 1 && g_conv3p_tn4))) { const double c4 = cost(4, 0.86); if (c4 < best * 0.97) { tn = 4; best = c4; } }
     if (c3 < best * 0.97) { tn = 3; best = c3; }
     if (c2 < best * 0.97) { tn = 2; best = c2; }
 #ifdef RT_PROBE
