@@ -282,6 +282,7 @@ struct GroupNormArgs {
 };
 int groupnorm_rows_per_chunk(int HW);
 void launch_groupnorm(const GroupNormArgs& a, hipStream_t st);
+void groupnorm_set_chunk_div(int d);                    // A/B
 void groupnorm_set_fused(int on);                       // A/B: 0 = always the two-launch form (rt_op_gemm_debug bit 23)
 int groupnorm_nchunk(int HW);
 

@@ -1322,7 +1322,7 @@ int rt_op_attention_units_plan(const int* q_src, const int* k_src, int B, int to
     if (!q_src || !k_src || !launch_of || !unit_of || !members_of || B < 1 || B > RT_MAXB) return -1;
     return attention_units_plan_host(q_src, k_src, B, tokens, DP, mode, launch_of, unit_of, members_of);
 }
-int rt_op_gemm_debug(int d) { gemm_set_debug(d); g_store_own_stats = (d >> 17) & 1; g_store_apply_v1 = (d >> 18) & 1; g_c77_t1 = (d >> 20) & 3; g_store_legacy = ((d & 32) ? 1 : 0) | ((d & 64) ? 2 : 0); attention_set_prio(((d >> 14) & 1) ^ 1); attention_set_units((d >> 24) & 7); gemm16_set_tall((d >> 27) & 1); groupnorm_set_fused(((d >> 23) & 1) ^ 1); gemm16_set_deep(((d >> 12) & 1) ^ 1); return RT_OK; }
+int rt_op_gemm_debug(int d) { gemm_set_debug(d); g_store_own_stats = (d >> 17) & 1; g_store_apply_v1 = (d >> 18) & 1; g_c77_t1 = (d >> 20) & 3; g_store_legacy = ((d & 32) ? 1 : 0) | ((d & 64) ? 2 : 0); attention_set_prio(((d >> 14) & 1) ^ 1); attention_set_units((d >> 24) & 7); gemm16_set_tall((d >> 27) & 1); groupnorm_set_fused(((d >> 23) & 1) ^ 1); groupnorm_set_chunk_div(((d >> 11) & 1) ? 128 : 64); gemm16_set_deep(((d >> 12) & 1) ^ 1); return RT_OK; }
 int rt_op_probes_built(void) {
 #ifdef RT_PROBES
     return 1;
