@@ -281,6 +281,7 @@ struct GroupNormArgs {
     float* stats; int stats_ld;        // set by launch_groupnorm: where the apply kernel finds (mean, rstd) per (batch entry, group) in the non-fused form
 };
 int groupnorm_rows_per_chunk(int HW);
+int groupnorm_bwd_rows_per_chunk(int HW);              // chunking of launch_groupnorm_bwd (its own partial-sum layout; one image: the forward's (mean, rstd) sit at offset 0 either way)
 void launch_groupnorm(const GroupNormArgs& a, hipStream_t st);
 void groupnorm_set_chunk_div(int d);                    // A/B
 void groupnorm_set_fused(int on);                       // A/B: 0 = always the two-launch form (rt_op_gemm_debug bit 23)

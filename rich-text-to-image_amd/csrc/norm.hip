@@ -9,12 +9,18 @@
 // deterministic two-level reduction (no atomics in global memory).
 #include "common.h"
 
-// rows per chunk = HW / 64 clamped to [16, 128] (rounds 1 - 5: HW / 128): at 4096 rows a workgroup of the two-launch form now owns 64 rows instead
-// of 32 - 7 x 4096 x 640 fp16: 48.5 -> 40.1 us (HW / 32: 41.5), step -0.07 ms; other map sizes keep their chunks.  A function of HW only.
+// rows per chunk = HW / 64 clamped to [16, 256] (rounds 1 - 5: HW / 128 clamped to [16, 128]): a workgroup of the two-launch form owns 64 rows at
+// 4096-row maps (7 x 4096 x 640 fp16: 48.5 -> 40.1 us; 128 rows: 41.5) and 256 at 16384-row maps (7 x 16384 x 320: 65.3 -> 56.9 us; 512 rows: 60.1);
+// config-3 step -0.18 ms same-box.  A function of HW only.
 static int g_gn_chunk_div = 64;     // (A/B: rt_op_gemm_debug bit 11 restores 128)
-void groupnorm_set_chunk_div(int d) { g_gn_chunk_div = d; }
-static inline int gn_rows_per_chunk(int HW) { int r = HW / g_gn_chunk_div; return r < 16 ? 16 : (r > 128 ? 128 : r); }
+static int g_gn_chunk_max = 256;
+void groupnorm_set_chunk_div(int d) { g_gn_chunk_div = d; g_gn_chunk_max = d == 128 ? 128 : 256; }
+static inline int gn_rows_per_chunk(int HW) { int r = HW / g_gn_chunk_div; return r < 16 ? 16 : (r > g_gn_chunk_max ? g_gn_chunk_max : r); }
 int groupnorm_rows_per_chunk(int HW) { return gn_rows_per_chunk(HW); }
+// the VAE (vae.hip: forward and backward GroupNorm of ONE image) keeps the chunks of rounds 1 - 5: with the rule above its backward kernels got slower (guidance call
+// SD 10.7 -> 12.4 ms, SDXL precise 82.9 -> 86.6 ms), and with it on the forward pair alone the calls read 83.25 vs 82.87 ms although the stand-alone
+// 1024^2 x 128 fp32 map gains (471 -> 277 us)
+int groupnorm_bwd_rows_per_chunk(int HW) { int r = HW / 128; return r < 16 ? 16 : (r > 128 ? 128 : r); }
 int groupnorm_nchunk(int HW) { return cdiv(HW, gn_rows_per_chunk(HW)); }
 
 // IT: element type of the input(s): 0 fp32, 1 bf16 (single source), 2 fp16 (the UNet trunk; virtual concat allowed)
@@ -500,7 +506,7 @@ void launch_groupnorm(const GroupNormArgs& a, hipStream_t st) {
     RT_REQUIRE(a.G >= 1 && a.G <= 32 && C % a.G == 0, "groupnorm: bad group count");
     RT_REQUIRE(a.C1 % 4 == 0 && a.C2 % 4 == 0, "groupnorm: channels must be multiples of 4");
     RT_REQUIRE(a.in_bf16 >= 0 && a.in_bf16 <= 2 && !(a.in_bf16 == 1 && a.x2), "groupnorm: input type 0 fp32 / 1 bf16 (no concat) / 2 fp16");
-    RT_REQUIRE(a.nchunk == groupnorm_nchunk(a.HW) && a.rows_per_chunk == gn_rows_per_chunk(a.HW), "groupnorm: nchunk mismatch");
+    RT_REQUIRE(a.rows_per_chunk >= 1 && a.nchunk == cdiv(a.HW, a.rows_per_chunk), "groupnorm: nchunk mismatch");      // (the UNet engine passes groupnorm_rows_per_chunk, the VAE its own rule)
     RT_REQUIRE(C <= GN_MAXC, "groupnorm: too many channels");
     const GnShape shp = gn_block_shape(C >> 2);
     RT_REQUIRE(shp.nrl * C <= GN_MAXC || shp.nrl == 1, "groupnorm: LDS staging too small");

@@ -258,22 +258,22 @@ struct rt_vae {
         return o;
     }
     float* gn_fwd(const void* x, bool x_bf16, int C, int HW, const NormW& n, bool silu, BT out, BT raw) {
-        const int nchunk = groupnorm_nchunk(HW);
+        const int rpc = groupnorm_bwd_rows_per_chunk(HW), nchunk = (HW + rpc - 1) / rpc;      // the VAE's own chunk rule (norm.hip)
         float* part = f32((size_t)nchunk * G * 2);
         if (dry) return part;
         GroupNormArgs a{}; a.x1 = x; a.in_bf16 = x_bf16; a.C1 = C; a.C2 = 0; a.G = G; a.B = 1; a.HW = HW; a.gamma = n.g; a.beta = n.b; a.eps = 1e-6f;
         a.silu = silu; a.out = out.hi; a.out_lo = out.lo; a.raw_out = raw.hi; a.raw_lo = raw.lo; a.partial = part; a.nchunk = nchunk;
-        a.rows_per_chunk = groupnorm_rows_per_chunk(HW);
+        a.rows_per_chunk = rpc;
         launch_groupnorm(a, stream);
         return part;
     }
     void gn_bwd(const void* x, bool x_bf16, BT dA, const float* fwd_part, int C, int HW, const NormW& n, bool silu, const float* add,
                 float* out, BT out_b) {
-        const int nchunk = groupnorm_nchunk(HW);
+        const int rpc = groupnorm_bwd_rows_per_chunk(HW), nchunk = (HW + rpc - 1) / rpc;      // (B = 1: the forward's statistics are at fwd_part[2 g] whatever its chunking)
         float* bp = f32((size_t)nchunk * G * 2);
         if (dry) return;
         GroupNormBwdArgs a{}; a.x = x; a.x_bf16 = x_bf16; a.dA = dA.hi; a.dA_lo = dA.lo; a.fwd_partial = fwd_part; a.bwd_partial = bp; a.gamma = n.g; a.beta = n.b;
-        a.eps = 1e-6f; a.silu = silu; a.C = C; a.G = G; a.B = 1; a.HW = HW; a.nchunk = nchunk; a.rows_per_chunk = groupnorm_rows_per_chunk(HW); a.add = add;
+        a.eps = 1e-6f; a.silu = silu; a.C = C; a.G = G; a.B = 1; a.HW = HW; a.nchunk = nchunk; a.rows_per_chunk = rpc; a.add = add;
         a.out = out; a.out_bf16 = out_b.hi; a.out_bf16_lo = out_b.lo;
         launch_groupnorm_bwd(a, stream);
     }
